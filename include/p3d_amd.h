@@ -1,0 +1,172 @@
+/*
+ * p3d_amd.h -- C ABI of libp3d_amd.so: the MI355X (gfx950) implementation of PyTorch3D's
+ * differentiable-rasterization hot path.
+ *
+ * One entry point per operator of the reference's pybind surface `pytorch3d._C`
+ * (pytorch3d/csrc/ext.cpp:38-73).  Every function
+ *   - takes plain device pointers and sizes (no torch types),
+ *   - is asynchronous on the HIP stream it is handed (no allocation, no host sync),
+ *   - writes every element of its outputs (padding value -1 included: callers pass
+ *     uninitialised memory, there is no pre-fill pass),
+ *   - returns P3D_OK or a negative error code (p3d_error_string()).
+ * Scratch memory comes from the caller: ask p3d_*_workspace_bytes() first.
+ * The current HIP device must be the one that owns the pointers and the stream.
+ *
+ * Layouts are the reference's: packed AoS face_verts (F,3,3) f32; per-mesh
+ * first-index/count vectors (N) i64; outputs (N,H,W,K[,3]).  Output pixel (y, x) looks
+ * along flipped axes (+Y up, +X left), rasterize_meshes.cu:271-277.
+ */
+#ifndef P3D_AMD_H_
+#define P3D_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P3D_ABI_VERSION 1
+
+#define P3D_OK 0
+#define P3D_ERR_INVALID_ARG (-1)   /* null pointer / negative size / bad mode                    */
+#define P3D_ERR_K_TOO_LARGE (-2)   /* K > 150 (rasterization_utils.cuh:49, rasterize_meshes.cu:361) */
+#define P3D_ERR_TOO_MANY_BINS (-3) /* bins per side >= 22 (rasterize_coarse.cu:244-249)           */
+#define P3D_ERR_WORKSPACE (-4)     /* workspace smaller than p3d_*_workspace_bytes()              */
+#define P3D_ERR_LAUNCH (-5)        /* HIP reported a launch failure                              */
+#define P3D_ERR_UNSUPPORTED (-6)
+
+#define P3D_MAX_K 150
+#define P3D_MAX_BINS_PER_SIDE 21
+
+typedef void* p3d_stream_t; /* hipStream_t */
+
+int p3d_abi_version(void);
+const char* p3d_error_string(int code);
+
+/* ---- meshes -------------------------------------------------------------------------- */
+
+/* Scratch bytes for p3d_rasterize_meshes / p3d_rasterize_meshes_coarse (0 when bin_size == 0). */
+size_t p3d_rasterize_meshes_workspace_bytes(int64_t F, int N, int H, int W, int bin_size, int max_faces_per_bin);
+
+/* replaces RasterizeMeshes, pytorch3d/csrc/rasterize_meshes/rasterize_meshes.h:513-562
+ * (_C.rasterize_meshes).  bin_size == 0 or max_faces_per_bin == 0 -> naive path, else
+ * coarse binning + fine rasterization.  Outputs: pix_to_face (N,H,W,K) i64, zbuf (N,H,W,K) f32,
+ * bary (N,H,W,K,3) f32, dists (N,H,W,K) f32. */
+int p3d_rasterize_meshes(const float* face_verts, const int64_t* mesh_to_face_first_idx,
+                         const int64_t* num_faces_per_mesh, const int64_t* clipped_faces_neighbor_idx, int64_t F, int N,
+                         int H, int W, float blur_radius, int faces_per_pixel, int bin_size, int max_faces_per_bin,
+                         int perspective_correct, int clip_barycentric_coords, int cull_backfaces, int64_t* pix_to_face,
+                         float* zbuf, float* bary, float* dists, void* workspace, size_t workspace_bytes,
+                         p3d_stream_t stream);
+
+/* replaces RasterizeMeshesNaive, rasterize_meshes.h:108-156 (_C._rasterize_meshes_naive). */
+int p3d_rasterize_meshes_naive(const float* face_verts, const int64_t* mesh_to_face_first_idx,
+                               const int64_t* num_faces_per_mesh, const int64_t* clipped_faces_neighbor_idx, int64_t F,
+                               int N, int H, int W, float blur_radius, int faces_per_pixel, int perspective_correct,
+                               int clip_barycentric_coords, int cull_backfaces, int64_t* pix_to_face, float* zbuf,
+                               float* bary, float* dists, p3d_stream_t stream);
+
+/* replaces RasterizeMeshesCoarse, rasterize_meshes.h:292-329 (_C._rasterize_meshes_coarse).
+ * bin_faces (N,BH,BW,M) i32, -1 padded, each bin's list ascending; a bin with more than M faces keeps
+ * its first M (the reference drops an unspecified subset, rasterize_coarse.cu:186-201). */
+int p3d_rasterize_meshes_coarse(const float* face_verts, const int64_t* mesh_to_face_first_idx,
+                                const int64_t* num_faces_per_mesh, int64_t F, int N, int H, int W, float blur_radius,
+                                int bin_size, int max_faces_per_bin, int32_t* bin_faces, void* workspace,
+                                size_t workspace_bytes, p3d_stream_t stream);
+
+/* Scratch bytes for p3d_rasterize_meshes_fine / p3d_rasterize_points_fine. */
+size_t p3d_rasterize_fine_workspace_bytes(int N, int BH, int BW, int M);
+
+/* replaces RasterizeMeshesFine, rasterize_meshes.h:406-441 (_C._rasterize_meshes_fine).
+ * bin_faces (N,BH,BW,M) i32 with -1 sentinels anywhere. */
+int p3d_rasterize_meshes_fine(const float* face_verts, const int32_t* bin_faces,
+                              const int64_t* clipped_faces_neighbor_idx, int64_t F, int N, int BH, int BW, int M, int H,
+                              int W, float blur_radius, int bin_size, int faces_per_pixel, int perspective_correct,
+                              int clip_barycentric_coords, int cull_backfaces, int64_t* pix_to_face, float* zbuf,
+                              float* bary, float* dists, void* workspace, size_t workspace_bytes, p3d_stream_t stream);
+
+/* replaces RasterizeMeshesBackward, rasterize_meshes.h:211-252 (_C.rasterize_meshes_backward).
+ * grad_face_verts (F,3,3) f32 is zeroed and accumulated here. */
+int p3d_rasterize_meshes_backward(const float* face_verts, const int64_t* pix_to_face, const float* grad_zbuf,
+                                  const float* grad_bary, const float* grad_dists, int64_t F, int N, int H, int W, int K,
+                                  int perspective_correct, int clip_barycentric_coords, float* grad_face_verts,
+                                  p3d_stream_t stream);
+
+/* ---- point clouds -------------------------------------------------------------------- */
+
+size_t p3d_rasterize_points_workspace_bytes(int64_t P, int N, int H, int W, int bin_size, int max_points_per_bin);
+
+/* replaces RasterizePoints, pytorch3d/csrc/rasterize_points/rasterize_points.h:343-374 (_C.rasterize_points).
+ * Outputs idxs (N,H,W,K) i32, zbuf, dists (squared) f32. */
+int p3d_rasterize_points(const float* points, const int64_t* cloud_to_packed_first_idx,
+                         const int64_t* num_points_per_cloud, const float* radius, int64_t P, int N, int H, int W,
+                         int points_per_pixel, int bin_size, int max_points_per_bin, int32_t* idxs, float* zbuf,
+                         float* dists, void* workspace, size_t workspace_bytes, p3d_stream_t stream);
+
+/* replaces RasterizePointsNaive, rasterize_points.h:70-99 (_C._rasterize_points_naive). */
+int p3d_rasterize_points_naive(const float* points, const int64_t* cloud_to_packed_first_idx,
+                               const int64_t* num_points_per_cloud, const float* radius, int64_t P, int N, int H, int W,
+                               int points_per_pixel, int32_t* idxs, float* zbuf, float* dists, p3d_stream_t stream);
+
+/* replaces RasterizePointsCoarse, rasterize_points.h:146-191 (_C._rasterize_points_coarse). */
+int p3d_rasterize_points_coarse(const float* points, const int64_t* cloud_to_packed_first_idx,
+                                const int64_t* num_points_per_cloud, const float* radius, int64_t P, int N, int H, int W,
+                                int bin_size, int max_points_per_bin, int32_t* bin_points, void* workspace,
+                                size_t workspace_bytes, p3d_stream_t stream);
+
+/* replaces RasterizePointsFine, rasterize_points.h:222-247. */
+int p3d_rasterize_points_fine(const float* points, const int32_t* bin_points, const float* radius, int64_t P, int N,
+                              int BH, int BW, int M, int H, int W, int bin_size, int points_per_pixel, int32_t* idxs,
+                              float* zbuf, float* dists, void* workspace, size_t workspace_bytes, p3d_stream_t stream);
+
+/* replaces RasterizePointsBackward, rasterize_points.h:281-305 (_C.rasterize_points_backward). */
+int p3d_rasterize_points_backward(const float* points, const int32_t* idxs, const float* grad_zbuf,
+                                  const float* grad_dists, int64_t P, int N, int H, int W, int K, float* grad_points,
+                                  p3d_stream_t stream);
+
+/* ---- compositors --------------------------------------------------------------------- */
+
+#define P3D_COMPOSITE_ALPHA 0    /* alphaComposite*,  compositing/alpha_composite.h:59-115    */
+#define P3D_COMPOSITE_NORM_SUM 1 /* weightedSumNorm*, compositing/norm_weighted_sum.h:57-115  */
+#define P3D_COMPOSITE_SUM 2      /* weightedSum*,     compositing/weighted_sum.h:55-111       */
+
+/* features (C,P) f32 contiguous; alphas / points_idx are logically (N,K,H,W) and addressed through
+ * element strides (so the permuted (N,H,W,K) views the renderers pass need no copy);
+ * result (N,C,H,W) f32 contiguous. */
+int p3d_composite_forward(int mode, const float* features, const float* alphas, const int64_t* points_idx, int N, int C,
+                          int64_t P, int K, int H, int W, const int64_t alphas_strides[4],
+                          const int64_t idx_strides[4], float* result, p3d_stream_t stream);
+
+/* grad_features (C,P) and grad_alphas (N,K,H,W) contiguous, both fully written. */
+int p3d_composite_backward(int mode, const float* grad_outputs, const float* features, const float* alphas,
+                           const int64_t* points_idx, int N, int C, int64_t P, int K, int H, int W,
+                           const int64_t alphas_strides[4], const int64_t idx_strides[4], float* grad_features,
+                           float* grad_alphas, p3d_stream_t stream);
+
+/* ---- interpolate_face_attributes ----------------------------------------------------- */
+
+/* replaces InterpFaceAttrsForward/Backward, pytorch3d/csrc/interp_face_attrs/interp_face_attrs.h:46-116.
+ * dtype: 0 = f32, 1 = f64 (the reference dispatches both).  pix_attrs (P,D) fully written. */
+int p3d_interp_face_attrs_forward(int dtype, const int64_t* pix_to_face, const void* barycentric_coords,
+                                  const void* face_attrs, int64_t P, int64_t F, int64_t D, void* pix_attrs,
+                                  p3d_stream_t stream);
+int p3d_interp_face_attrs_backward(int dtype, const int64_t* pix_to_face, const void* barycentric_coords,
+                                   const void* face_attrs, const void* grad_pix_attrs, int64_t P, int64_t F, int64_t D,
+                                   void* grad_barycentric_coords, void* grad_face_attrs, p3d_stream_t stream);
+
+/* ---- built-in per-kernel timing (HIP events on the launch stream) --------------------- */
+
+/* enable != 0: every kernel launch is bracketed by hipEventRecord on its stream. */
+void p3d_profile_enable(int enable);
+/* Synchronise the recorded events and fold them into per-kernel totals. */
+void p3d_profile_collect(void);
+/* Number of distinct kernel names seen; name/launch count/total milliseconds of entry i. */
+int p3d_profile_num_entries(void);
+const char* p3d_profile_entry(int i, int64_t* launches, double* total_ms);
+void p3d_profile_reset(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P3D_AMD_H_ */

@@ -1,0 +1,172 @@
+"""ctypes front-end of the C oracle (TEST INFRASTRUCTURE, not product code).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+All functions take and return CPU torch tensors with the reference's shapes/dtypes.
+"""
+import ctypes
+import importlib.util
+import os
+import sys
+
+import torch
+
+from . import build as _build
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = _build.build_oracle()
+        _lib = ctypes.CDLL(path)
+    return _lib
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _f32(t):
+    return t.detach().to(device="cpu", dtype=torch.float32).contiguous()
+
+
+def _i64(t):
+    return t.detach().to(device="cpu", dtype=torch.int64).contiguous()
+
+
+def _i32(t):
+    return t.detach().to(device="cpu", dtype=torch.int32).contiguous()
+
+
+def rasterize_meshes_naive(face_verts, mesh_first, mesh_count, neighbor_idx, image_size, blur_radius, K,
+                           perspective_correct, clip_barycentric_coords, cull_backfaces, cpu_order=False):
+    fv, mf, mc = _f32(face_verts), _i64(mesh_first), _i64(mesh_count)
+    nb = _i64(neighbor_idx) if neighbor_idx is not None else None
+    H, W = image_size
+    N = mf.shape[0]
+    p2f = torch.empty((N, H, W, K), dtype=torch.int64)
+    zbuf = torch.empty((N, H, W, K), dtype=torch.float32)
+    bary = torch.empty((N, H, W, K, 3), dtype=torch.float32)
+    dists = torch.empty((N, H, W, K), dtype=torch.float32)
+    lib().orc_rasterize_meshes_naive(_p(fv), _p(mf), _p(mc), _p(nb) if nb is not None else None, N, H, W,
+                                     ctypes.c_float(blur_radius), K, int(perspective_correct),
+                                     int(clip_barycentric_coords), int(cull_backfaces), int(cpu_order), _p(p2f),
+                                     _p(zbuf), _p(bary), _p(dists))
+    return p2f, zbuf, bary, dists
+
+
+def rasterize_meshes_backward(face_verts, pix_to_face, grad_zbuf, grad_bary, grad_dists, perspective_correct,
+                              clip_barycentric_coords, cuda_semantics=True, acc64=True):
+    fv, p2f = _f32(face_verts), _i64(pix_to_face)
+    gz, gb, gd = _f32(grad_zbuf), _f32(grad_bary), _f32(grad_dists)
+    N, H, W, K = p2f.shape
+    F = fv.shape[0]
+    out = torch.zeros((F, 3, 3), dtype=torch.float32)
+    lib().orc_rasterize_meshes_backward(_p(fv), _p(p2f), _p(gz), _p(gb), _p(gd), ctypes.c_int64(F), N, H, W, K,
+                                        int(perspective_correct), int(clip_barycentric_coords), int(cuda_semantics),
+                                        int(acc64), _p(out))
+    return out
+
+
+def _coarse(kind, elems, aux, first, count, image_size, blur_radius, bin_size, M):
+    H, W = image_size
+    N = first.shape[0]
+    BH, BW = 1 + (H - 1) // bin_size, 1 + (W - 1) // bin_size
+    out = torch.empty((N, BH, BW, M), dtype=torch.int32)
+    ovf = ctypes.c_int32(0)
+    lib().orc_rasterize_coarse(kind, _p(elems), _p(aux) if aux is not None else None, _p(first), _p(count), N, H, W,
+                               ctypes.c_float(blur_radius), bin_size, M, _p(out), ctypes.byref(ovf))
+    return out, bool(ovf.value)
+
+
+def rasterize_meshes_coarse(face_verts, mesh_first, mesh_count, image_size, blur_radius, bin_size, M):
+    return _coarse(0, _f32(face_verts), None, _i64(mesh_first), _i64(mesh_count), image_size, blur_radius, bin_size, M)
+
+
+def rasterize_points_coarse(points, first, count, image_size, radius, bin_size, M):
+    return _coarse(1, _f32(points), _f32(radius), _i64(first), _i64(count), image_size, 0.0, bin_size, M)
+
+
+def rasterize_points_naive(points, first, count, image_size, radius, K):
+    pts, fi, ct, r = _f32(points), _i64(first), _i64(count), _f32(radius)
+    H, W = image_size
+    N = fi.shape[0]
+    idx = torch.empty((N, H, W, K), dtype=torch.int32)
+    zbuf = torch.empty((N, H, W, K), dtype=torch.float32)
+    dists = torch.empty((N, H, W, K), dtype=torch.float32)
+    lib().orc_rasterize_points_naive(_p(pts), _p(fi), _p(ct), _p(r), N, H, W, K, _p(idx), _p(zbuf), _p(dists))
+    return idx, zbuf, dists
+
+
+def rasterize_points_backward(points, idxs, grad_zbuf, grad_dists, acc64=True):
+    pts, ix, gz, gd = _f32(points), _i32(idxs), _f32(grad_zbuf), _f32(grad_dists)
+    N, H, W, K = ix.shape
+    P = pts.shape[0]
+    out = torch.zeros((P, 3), dtype=torch.float32)
+    lib().orc_rasterize_points_backward(_p(pts), _p(ix), _p(gz), _p(gd), ctypes.c_int64(P), N, H, W, K, int(acc64),
+                                        _p(out))
+    return out
+
+
+_MODES = {"alphacomposite": 0, "weightedsumnorm": 1, "weightedsum": 2}
+
+
+def composite_forward(mode, features, alphas, points_idx):
+    f, a, ix = _f32(features), _f32(alphas), _i64(points_idx)
+    C, P = f.shape
+    N, K, H, W = a.shape
+    out = torch.zeros((N, C, H, W), dtype=torch.float32)
+    lib().orc_composite_forward(_MODES[mode], _p(f), _p(a), _p(ix), N, C, ctypes.c_int64(P), K, H, W, _p(out))
+    return out
+
+
+def composite_backward(mode, grad_out, features, alphas, points_idx):
+    g, f, a, ix = _f32(grad_out), _f32(features), _f32(alphas), _i64(points_idx)
+    C, P = f.shape
+    N, K, H, W = a.shape
+    gf = torch.zeros((C, P), dtype=torch.float32)
+    ga = torch.zeros((N, K, H, W), dtype=torch.float32)
+    lib().orc_composite_backward(_MODES[mode], _p(g), _p(f), _p(a), _p(ix), N, C, ctypes.c_int64(P), K, H, W, _p(gf),
+                                 _p(ga))
+    return gf, ga
+
+
+def interp_forward(pix_to_face, bary, face_attrs):
+    p2f, b, fa = _i64(pix_to_face), _f32(bary), _f32(face_attrs)
+    P = p2f.shape[0]
+    F, _, D = fa.shape
+    out = torch.zeros((P, D), dtype=torch.float32)
+    lib().orc_interp_forward(_p(p2f), _p(b), _p(fa), ctypes.c_int64(P), ctypes.c_int64(F), D, _p(out))
+    return out
+
+
+def interp_backward(pix_to_face, bary, face_attrs, grad_pix_attrs):
+    p2f, b, fa, g = _i64(pix_to_face), _f32(bary), _f32(face_attrs), _f32(grad_pix_attrs)
+    P = p2f.shape[0]
+    F, _, D = fa.shape
+    gb = torch.zeros((P, 3), dtype=torch.float32)
+    gf = torch.zeros((F, 3, D), dtype=torch.float32)
+    lib().orc_interp_backward(_p(p2f), _p(b), _p(fa), _p(g), ctypes.c_int64(P), ctypes.c_int64(F), D, _p(gb), _p(gf))
+    return gb, gf
+
+
+# ---------------------------------------------------------------------------
+# The real reference, when its CPU build is present (oracle/_ref/p3d_ref_cpu.so).
+# ---------------------------------------------------------------------------
+_ref_mod = None
+
+
+def ref_module():
+    """Return the reference's own CPU extension (or None when it was never built)."""
+    global _ref_mod
+    if _ref_mod is not None:
+        return _ref_mod
+    path = _build.build_ref() if _build.have_reference() else (_build.REF_SO if os.path.exists(_build.REF_SO) else None)
+    if path is None or not os.path.exists(path):
+        return None
+    spec = importlib.util.spec_from_file_location("p3d_ref_cpu", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    _ref_mod = mod
+    return mod

@@ -1,0 +1,493 @@
+"""The `pytorch3d._C` operator surface for the rasterization hot path, on MI355X.
+
+Same names, positional signatures, return conventions and error behaviour as the reference's
+pybind module (pytorch3d/csrc/ext.cpp:38-73); each function validates like the reference's
+dispatcher, allocates outputs with torch (caching allocator, uninitialised -- the kernels write
+every element), and calls the C ABI of libp3d_amd.so on torch's current HIP stream.
+
+GPU tensors only: there is no CPU implementation and no fallback in this package.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+# constants pytorch3d/renderer/points/pulsar/renderer.py reads at import (ext.cpp:180-185)
+EPS = 1e-6
+MAX_FLOAT = 3.4e38
+MAX_INT = 2147483647
+MAX_UINT = 4294967295
+MAX_USHORT = 65535
+PULSAR_MAX_GRAD_SPHERES = 128
+
+kMaxPointsPerPixel = 150
+kMaxItemsPerBin = 22
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr() if t is not None and t.numel() > 0 else None)
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _need_gpu(t, name):
+    if not t.is_cuda:
+        # mirrors CHECK_CUDA (pytorch3d_cutils.h:12-21) -- but there is no CPU path to fall to.
+        raise RuntimeError(f"{name} must be a CUDA/HIP tensor: pytorch3d_amd implements the GPU path only.")
+
+
+def _same_device(*named):
+    dev = named[0][1].device
+    for name, t in named:
+        _need_gpu(t, name)
+        if t.device != dev:
+            raise RuntimeError(f"Expected all tensors to be on the same GPU, but {name} is on {t.device} "
+                               f"and {named[0][0]} is on {dev}")
+    return dev
+
+
+def _c(t, dtype):
+    if t.dtype != dtype:
+        raise RuntimeError(f"expected dtype {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+def _hw(image_size):
+    h, w = image_size
+    return int(h), int(w)
+
+
+def _check_k(K):
+    if K > kMaxPointsPerPixel:
+        raise RuntimeError(f"Must have points_per_pixel <= {kMaxPointsPerPixel}")
+
+
+def _num_bins(H, W, bin_size, who):
+    by, bx = 1 + (H - 1) // bin_size, 1 + (W - 1) // bin_size
+    if by >= kMaxItemsPerBin or bx >= kMaxItemsPerBin:
+        raise RuntimeError(f"In {who} got num_bins_y: {by}, num_bins_x: {bx}, ; that's too many!")
+    return by, bx
+
+
+def _workspace(nbytes, device):
+    return torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=device)
+
+
+# ----------------------------------------------------------------------------------------------
+# meshes
+# ----------------------------------------------------------------------------------------------
+def _check_face_verts(face_verts):
+    if not (face_verts.dim() == 3 and face_verts.size(1) == 3 and face_verts.size(2) == 3):
+        raise RuntimeError("face_verts must have dimensions (num_faces, 3, 3)")
+
+
+def _mesh_outputs(N, H, W, K, device):
+    p2f = torch.empty((N, H, W, K), dtype=torch.int64, device=device)
+    zbuf = torch.empty((N, H, W, K), dtype=torch.float32, device=device)
+    bary = torch.empty((N, H, W, K, 3), dtype=torch.float32, device=device)
+    dists = torch.empty((N, H, W, K), dtype=torch.float32, device=device)
+    return p2f, zbuf, bary, dists
+
+
+def rasterize_meshes(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, image_size,
+                     blur_radius, faces_per_pixel, bin_size, max_faces_per_bin, perspective_correct,
+                     clip_barycentric_coords, cull_backfaces):
+    """RasterizeMeshes, rasterize_meshes.h:513-562.  Returns (pix_to_face, zbuf, bary, dists)."""
+    dev = _same_device(("face_verts", face_verts), ("mesh_to_face_first_idx", mesh_to_face_first_idx),
+                       ("num_faces_per_mesh", num_faces_per_mesh),
+                       ("clipped_faces_neighbor_idx", clipped_faces_neighbor_idx))
+    _check_face_verts(face_verts)
+    if num_faces_per_mesh.size(0) != mesh_to_face_first_idx.size(0):
+        raise RuntimeError("num_faces_per_mesh must have save size first dimension as mesh_to_faces_packed_first_idx")
+    if clipped_faces_neighbor_idx.size(0) != face_verts.size(0):
+        raise RuntimeError("clipped_faces_neighbor_idx must have save size first dimension as face_verts")
+    K = int(faces_per_pixel)
+    _check_k(K)
+    H, W = _hw(image_size)
+    bin_size, M = int(bin_size), int(max_faces_per_bin)
+    binned = bin_size > 0 and M > 0
+    if binned:
+        _num_bins(H, W, bin_size, "RasterizeCoarseCuda")
+    fv = _c(face_verts, torch.float32)
+    first, count = _c(mesh_to_face_first_idx, torch.int64), _c(num_faces_per_mesh, torch.int64)
+    nb = _c(clipped_faces_neighbor_idx, torch.int64)
+    N, F = count.size(0), fv.size(0)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        out = _mesh_outputs(N, H, W, K, dev)
+        if out[0].numel() == 0:
+            return out
+        nbytes = lib.p3d_rasterize_meshes_workspace_bytes(F, N, H, W, bin_size, M) if binned else 0
+        ws = _workspace(nbytes, dev)
+        rc = lib.p3d_rasterize_meshes(_ptr(fv), _ptr(first), _ptr(count), _ptr(nb), F, N, H, W, float(blur_radius), K,
+                                      bin_size if binned else 0, M if binned else 0, int(bool(perspective_correct)),
+                                      int(bool(clip_barycentric_coords)), int(bool(cull_backfaces)), _ptr(out[0]),
+                                      _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _ptr(ws), ws.numel(), _stream(dev))
+        _lib.check(rc, "rasterize_meshes")
+    return out
+
+
+def _rasterize_meshes_naive(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx,
+                            image_size, blur_radius, faces_per_pixel, perspective_correct, clip_barycentric_coords,
+                            cull_backfaces):
+    """RasterizeMeshesNaive, rasterize_meshes.h:108-156."""
+    return rasterize_meshes(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx,
+                            image_size, blur_radius, faces_per_pixel, 0, 0, perspective_correct,
+                            clip_barycentric_coords, cull_backfaces)
+
+
+def _rasterize_meshes_coarse(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, image_size, blur_radius, bin_size,
+                             max_faces_per_bin):
+    """RasterizeMeshesCoarse, rasterize_meshes.h:292-329.  Returns bin_faces (N,BH,BW,M) int32."""
+    dev = _same_device(("face_verts", face_verts), ("mesh_to_face_first_idx", mesh_to_face_first_idx),
+                       ("num_faces_per_mesh", num_faces_per_mesh))
+    _check_face_verts(face_verts)
+    H, W = _hw(image_size)
+    bin_size, M = int(bin_size), int(max_faces_per_bin)
+    BH, BW = _num_bins(H, W, bin_size, "RasterizeCoarseCuda")
+    fv = _c(face_verts, torch.float32)
+    first, count = _c(mesh_to_face_first_idx, torch.int64), _c(num_faces_per_mesh, torch.int64)
+    N, F = count.size(0), fv.size(0)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        out = torch.empty((N, BH, BW, M), dtype=torch.int32, device=dev)
+        if out.numel() == 0:
+            return out
+        ws = _workspace(lib.p3d_rasterize_meshes_workspace_bytes(F, N, H, W, bin_size, M), dev)
+        rc = lib.p3d_rasterize_meshes_coarse(_ptr(fv), _ptr(first), _ptr(count), F, N, H, W, float(blur_radius),
+                                             bin_size, M, _ptr(out), _ptr(ws), ws.numel(), _stream(dev))
+        _lib.check(rc, "_rasterize_meshes_coarse")
+    return out
+
+
+def _rasterize_meshes_fine(face_verts, bin_faces, clipped_faces_neighbor_idx, image_size, blur_radius, bin_size,
+                           faces_per_pixel, perspective_correct, clip_barycentric_coords, cull_backfaces):
+    """RasterizeMeshesFine, rasterize_meshes.h:406-441."""
+    dev = _same_device(("face_verts", face_verts), ("bin_faces", bin_faces),
+                       ("clipped_faces_neighbor_idx", clipped_faces_neighbor_idx))
+    _check_face_verts(face_verts)
+    if bin_faces.dim() != 4:
+        raise RuntimeError("bin_faces must have 4 dimensions")
+    if clipped_faces_neighbor_idx.size(0) != face_verts.size(0):
+        raise RuntimeError("clipped_faces_neighbor_idx must have the same first dimension as face_verts")
+    K = int(faces_per_pixel)
+    if K > kMaxPointsPerPixel:
+        raise RuntimeError("Must have num_closest <= 150")
+    H, W = _hw(image_size)
+    fv = _c(face_verts, torch.float32)
+    bf = _c(bin_faces, torch.int32)
+    nb = _c(clipped_faces_neighbor_idx, torch.int64)
+    N, BH, BW, M = bf.shape
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        out = _mesh_outputs(N, H, W, K, dev)
+        if out[0].numel() == 0:
+            return out
+        ws = _workspace(lib.p3d_rasterize_fine_workspace_bytes(N, BH, BW, M), dev)
+        rc = lib.p3d_rasterize_meshes_fine(_ptr(fv), _ptr(bf), _ptr(nb), fv.size(0), N, BH, BW, M, H, W,
+                                           float(blur_radius), int(bin_size), K, int(bool(perspective_correct)),
+                                           int(bool(clip_barycentric_coords)), int(bool(cull_backfaces)), _ptr(out[0]),
+                                           _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _ptr(ws), ws.numel(), _stream(dev))
+        _lib.check(rc, "_rasterize_meshes_fine")
+    return out
+
+
+def rasterize_meshes_backward(face_verts, pix_to_face, grad_zbuf, grad_bary, grad_dists, perspective_correct,
+                              clip_barycentric_coords):
+    """RasterizeMeshesBackward, rasterize_meshes.h:211-252.  Returns grad_face_verts (F,3,3)."""
+    dev = _same_device(("face_verts", face_verts), ("pix_to_face", pix_to_face), ("grad_zbuf", grad_zbuf),
+                       ("grad_bary", grad_bary), ("grad_dists", grad_dists))
+    # float atomics: the accumulation order is not deterministic (rasterize_meshes.cu:587)
+    if torch.are_deterministic_algorithms_enabled() and not torch.is_deterministic_algorithms_warn_only_enabled():
+        raise RuntimeError("RasterizeMeshesBackwardCuda does not have a deterministic implementation")
+    fv = _c(face_verts, torch.float32)
+    p2f = _c(pix_to_face, torch.int64)
+    gz, gb, gd = _c(grad_zbuf, torch.float32), _c(grad_bary, torch.float32), _c(grad_dists, torch.float32)
+    N, H, W, K = p2f.shape
+    F = fv.size(0)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        out = torch.empty((F, 3, 3), dtype=torch.float32, device=dev)
+        if F == 0:
+            return out
+        rc = lib.p3d_rasterize_meshes_backward(_ptr(fv), _ptr(p2f), _ptr(gz), _ptr(gb), _ptr(gd), F, N, H, W, K,
+                                               int(bool(perspective_correct)), int(bool(clip_barycentric_coords)),
+                                               _ptr(out), _stream(dev))
+        _lib.check(rc, "rasterize_meshes_backward")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# point clouds
+# ----------------------------------------------------------------------------------------------
+def _check_points(points):
+    if not (points.dim() == 2 and points.size(1) == 3):
+        raise RuntimeError("points must have dimensions (num_points, 3)")
+
+
+def _point_outputs(N, H, W, K, device):
+    idx = torch.empty((N, H, W, K), dtype=torch.int32, device=device)
+    zbuf = torch.empty((N, H, W, K), dtype=torch.float32, device=device)
+    dists = torch.empty((N, H, W, K), dtype=torch.float32, device=device)
+    return idx, zbuf, dists
+
+
+def rasterize_points(points, cloud_to_packed_first_idx, num_points_per_cloud, image_size, radius, points_per_pixel,
+                     bin_size, max_points_per_bin):
+    """RasterizePoints, rasterize_points.h:343-374.  Returns (idxs int32, zbuf, dists2)."""
+    dev = _same_device(("points", points), ("cloud_to_packed_first_idx", cloud_to_packed_first_idx),
+                       ("num_points_per_cloud", num_points_per_cloud), ("radius", radius))
+    _check_points(points)
+    if radius.dim() != 1 or radius.size(0) != points.size(0):
+        raise RuntimeError("radius must be of shape (P,)")
+    K = int(points_per_pixel)
+    _check_k(K)
+    H, W = _hw(image_size)
+    bin_size, M = int(bin_size), int(max_points_per_bin)
+    binned = bin_size > 0 and M > 0
+    if binned:
+        _num_bins(H, W, bin_size, "RasterizeCoarseCuda")
+    pts, rad = _c(points, torch.float32), _c(radius, torch.float32)
+    first, count = _c(cloud_to_packed_first_idx, torch.int64), _c(num_points_per_cloud, torch.int64)
+    N, P = count.size(0), pts.size(0)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        out = _point_outputs(N, H, W, K, dev)
+        if out[0].numel() == 0:
+            return out
+        nbytes = lib.p3d_rasterize_points_workspace_bytes(P, N, H, W, bin_size, M) if binned else 0
+        ws = _workspace(nbytes, dev)
+        rc = lib.p3d_rasterize_points(_ptr(pts), _ptr(first), _ptr(count), _ptr(rad), P, N, H, W, K,
+                                      bin_size if binned else 0, M if binned else 0, _ptr(out[0]), _ptr(out[1]),
+                                      _ptr(out[2]), _ptr(ws), ws.numel(), _stream(dev))
+        _lib.check(rc, "rasterize_points")
+    return out
+
+
+def _rasterize_points_naive(points, cloud_to_packed_first_idx, num_points_per_cloud, image_size, radius,
+                            points_per_pixel):
+    """RasterizePointsNaive, rasterize_points.h:70-99."""
+    return rasterize_points(points, cloud_to_packed_first_idx, num_points_per_cloud, image_size, radius,
+                            points_per_pixel, 0, 0)
+
+
+def _rasterize_points_coarse(points, cloud_to_packed_first_idx, num_points_per_cloud, image_size, radius, bin_size,
+                             max_points_per_bin):
+    """RasterizePointsCoarse, rasterize_points.h:146-191.  Returns bin_points (N,BH,BW,M) int32."""
+    dev = _same_device(("points", points), ("cloud_to_packed_first_idx", cloud_to_packed_first_idx),
+                       ("num_points_per_cloud", num_points_per_cloud), ("radius", radius))
+    _check_points(points)
+    H, W = _hw(image_size)
+    bin_size, M = int(bin_size), int(max_points_per_bin)
+    BH, BW = _num_bins(H, W, bin_size, "RasterizeCoarseCuda")
+    pts, rad = _c(points, torch.float32), _c(radius, torch.float32)
+    first, count = _c(cloud_to_packed_first_idx, torch.int64), _c(num_points_per_cloud, torch.int64)
+    N, P = count.size(0), pts.size(0)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        out = torch.empty((N, BH, BW, M), dtype=torch.int32, device=dev)
+        if out.numel() == 0:
+            return out
+        ws = _workspace(lib.p3d_rasterize_points_workspace_bytes(P, N, H, W, bin_size, M), dev)
+        rc = lib.p3d_rasterize_points_coarse(_ptr(pts), _ptr(first), _ptr(count), _ptr(rad), P, N, H, W, bin_size, M,
+                                             _ptr(out), _ptr(ws), ws.numel(), _stream(dev))
+        _lib.check(rc, "_rasterize_points_coarse")
+    return out
+
+
+def _rasterize_points_fine(points, bin_points, image_size, radius, bin_size, points_per_pixel):
+    """RasterizePointsFine, rasterize_points.h:222-247."""
+    dev = _same_device(("points", points), ("bin_points", bin_points), ("radius", radius))
+    _check_points(points)
+    K = int(points_per_pixel)
+    if K > kMaxPointsPerPixel:
+        raise RuntimeError("Must have num_closest <= 150")
+    H, W = _hw(image_size)
+    pts, rad = _c(points, torch.float32), _c(radius, torch.float32)
+    bp = _c(bin_points, torch.int32)
+    N, BH, BW, M = bp.shape
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        out = _point_outputs(N, H, W, K, dev)
+        if out[0].numel() == 0:
+            return out
+        ws = _workspace(lib.p3d_rasterize_fine_workspace_bytes(N, BH, BW, M), dev)
+        rc = lib.p3d_rasterize_points_fine(_ptr(pts), _ptr(bp), _ptr(rad), pts.size(0), N, BH, BW, M, H, W,
+                                           int(bin_size), K, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(ws),
+                                           ws.numel(), _stream(dev))
+        _lib.check(rc, "_rasterize_points_fine")
+    return out
+
+
+def rasterize_points_backward(points, idxs, grad_zbuf, grad_dists):
+    """RasterizePointsBackward, rasterize_points.h:281-305.  Returns grad_points (P,3)."""
+    dev = _same_device(("points", points), ("idxs", idxs), ("grad_zbuf", grad_zbuf), ("grad_dists", grad_dists))
+    if torch.are_deterministic_algorithms_enabled() and not torch.is_deterministic_algorithms_warn_only_enabled():
+        raise RuntimeError("RasterizePointsBackwardCuda does not have a deterministic implementation")
+    pts = _c(points, torch.float32)
+    ix = _c(idxs, torch.int32)
+    gz, gd = _c(grad_zbuf, torch.float32), _c(grad_dists, torch.float32)
+    N, H, W, K = ix.shape
+    P = pts.size(0)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        out = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        if P == 0:
+            return out
+        rc = lib.p3d_rasterize_points_backward(_ptr(pts), _ptr(ix), _ptr(gz), _ptr(gd), P, N, H, W, K, _ptr(out),
+                                               _stream(dev))
+        _lib.check(rc, "rasterize_points_backward")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# compositors
+# ----------------------------------------------------------------------------------------------
+_ALPHA, _NORM, _SUM = 0, 1, 2
+
+
+def _strides4(t):
+    return (ctypes.c_int64 * 4)(*[int(s) for s in t.stride()])
+
+
+def _composite_check(features, alphas, points_idx):
+    dev = _same_device(("features", features), ("alphas", alphas), ("points_idx", points_idx))
+    if features.dim() != 2:
+        raise RuntimeError("features must have 2 dimensions (C, P)")
+    if alphas.dim() != 4 or points_idx.dim() != 4 or alphas.shape != points_idx.shape:
+        raise RuntimeError("alphas and points_idx must both have shape (N, K, H, W)")
+    if features.dtype != torch.float32 or alphas.dtype != torch.float32 or points_idx.dtype != torch.int64:
+        raise RuntimeError("features/alphas must be float32 and points_idx int64")
+    return dev
+
+
+def _composite_forward(mode, name, features, alphas, points_idx):
+    dev = _composite_check(features, alphas, points_idx)
+    feats = features.contiguous()
+    N, K, H, W = alphas.shape
+    C, P = feats.shape
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        out = torch.empty((N, C, H, W), dtype=torch.float32, device=dev)
+        if out.numel() == 0:
+            return out
+        rc = lib.p3d_composite_forward(mode, _ptr(feats), _ptr(alphas), _ptr(points_idx), N, C, P, K, H, W,
+                                       _strides4(alphas), _strides4(points_idx), _ptr(out), _stream(dev))
+        _lib.check(rc, name)
+    return out
+
+
+def _composite_backward(mode, name, grad_outputs, features, alphas, points_idx):
+    dev = _composite_check(features, alphas, points_idx)
+    _need_gpu(grad_outputs, "grad_outputs")
+    feats = features.contiguous()
+    go = _c(grad_outputs, torch.float32)
+    N, K, H, W = alphas.shape
+    C, P = feats.shape
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        gf = torch.empty((C, P), dtype=torch.float32, device=dev)
+        ga = torch.empty((N, K, H, W), dtype=torch.float32, device=dev)
+        rc = lib.p3d_composite_backward(mode, _ptr(go), _ptr(feats), _ptr(alphas), _ptr(points_idx), N, C, P, K, H, W,
+                                        _strides4(alphas), _strides4(points_idx), _ptr(gf), _ptr(ga), _stream(dev))
+        _lib.check(rc, name)
+    return gf, ga
+
+
+def accum_alphacomposite(features, alphas, points_idx):
+    """alphaCompositeForward, compositing/alpha_composite.h:59-82."""
+    return _composite_forward(_ALPHA, "accum_alphacomposite", features, alphas, points_idx)
+
+
+def accum_alphacomposite_backward(grad_outputs, features, alphas, points_idx):
+    """alphaCompositeBackward, alpha_composite.h:84-115.  Returns (grad_features, grad_alphas)."""
+    return _composite_backward(_ALPHA, "accum_alphacomposite_backward", grad_outputs, features, alphas, points_idx)
+
+
+def accum_weightedsumnorm(features, alphas, points_idx):
+    """weightedSumNormForward, compositing/norm_weighted_sum.h:57-80."""
+    return _composite_forward(_NORM, "accum_weightedsumnorm", features, alphas, points_idx)
+
+
+def accum_weightedsumnorm_backward(grad_outputs, features, alphas, points_idx):
+    return _composite_backward(_NORM, "accum_weightedsumnorm_backward", grad_outputs, features, alphas, points_idx)
+
+
+def accum_weightedsum(features, alphas, points_idx):
+    """weightedSumForward, compositing/weighted_sum.h:55-78."""
+    return _composite_forward(_SUM, "accum_weightedsum", features, alphas, points_idx)
+
+
+def accum_weightedsum_backward(grad_outputs, features, alphas, points_idx):
+    return _composite_backward(_SUM, "accum_weightedsum_backward", grad_outputs, features, alphas, points_idx)
+
+
+# ----------------------------------------------------------------------------------------------
+# interpolate_face_attributes
+# ----------------------------------------------------------------------------------------------
+_DTYPES = {torch.float32: 0, torch.float64: 1}
+
+
+def interp_face_attrs_forward(pix_to_face, barycentric_coords, face_attrs):
+    """InterpFaceAttrsForward, interp_face_attrs/interp_face_attrs.h:46-66.  Returns pix_attrs (P, D)."""
+    dev = _same_device(("pix_to_face", pix_to_face), ("barycentric_coords", barycentric_coords),
+                       ("face_attributes", face_attrs))
+    if barycentric_coords.dtype != face_attrs.dtype or face_attrs.dtype not in _DTYPES:
+        raise RuntimeError("barycentric_coords and face_attributes must have the same floating dtype")
+    P = pix_to_face.size(0)
+    if barycentric_coords.dim() != 2 or barycentric_coords.size(0) != P or barycentric_coords.size(1) != 3:
+        raise RuntimeError("barycentric_coords must have size (P, 3)")
+    if face_attrs.dim() != 3 or face_attrs.size(1) != 3:
+        raise RuntimeError("face_attrs must have size (F, 3, D)")
+    p2f = _c(pix_to_face, torch.int64)
+    bary, attrs = barycentric_coords.contiguous(), face_attrs.contiguous()
+    F, _, D = attrs.shape
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        out = torch.empty((P, D), dtype=attrs.dtype, device=dev)
+        if out.numel() == 0:
+            return out
+        rc = lib.p3d_interp_face_attrs_forward(_DTYPES[attrs.dtype], _ptr(p2f), _ptr(bary), _ptr(attrs), P, F, D,
+                                               _ptr(out), _stream(dev))
+        _lib.check(rc, "interp_face_attrs_forward")
+    return out
+
+
+def interp_face_attrs_backward(pix_to_face, barycentric_coords, face_attrs, grad_pix_attrs):
+    """InterpFaceAttrsBackward, interp_face_attrs.h:95-116.  Returns (grad_bary (P,3), grad_face_attrs (F,3,D))."""
+    dev = _same_device(("pix_to_face", pix_to_face), ("barycentric_coords", barycentric_coords),
+                       ("face_attributes", face_attrs), ("pix_attrs", grad_pix_attrs))
+    if not (barycentric_coords.dtype == face_attrs.dtype == grad_pix_attrs.dtype) or face_attrs.dtype not in _DTYPES:
+        raise RuntimeError("barycentric_coords, face_attributes and pix_attrs must have the same floating dtype")
+    if torch.are_deterministic_algorithms_enabled() and not torch.is_deterministic_algorithms_warn_only_enabled():
+        raise RuntimeError("InterpFaceAttrsBackwardCuda does not have a deterministic implementation")
+    P = pix_to_face.size(0)
+    if barycentric_coords.dim() != 2 or barycentric_coords.size(0) != P or barycentric_coords.size(1) != 3:
+        raise RuntimeError("barycentric_coords must have size (P, 3)")
+    if face_attrs.dim() != 3 or face_attrs.size(1) != 3:
+        raise RuntimeError("face_attrs must have size (F, 3, D)")
+    F, _, D = face_attrs.shape
+    if grad_pix_attrs.dim() != 2 or grad_pix_attrs.size(0) != P or grad_pix_attrs.size(1) != D:
+        raise RuntimeError("grad_pix_attrs must have size (P, D)")
+    p2f = _c(pix_to_face, torch.int64)
+    bary, attrs, g = barycentric_coords.contiguous(), face_attrs.contiguous(), grad_pix_attrs.contiguous()
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        gb = torch.empty((P, 3), dtype=attrs.dtype, device=dev)
+        gf = torch.empty((F, 3, D), dtype=attrs.dtype, device=dev)
+        rc = lib.p3d_interp_face_attrs_backward(_DTYPES[attrs.dtype], _ptr(p2f), _ptr(bary), _ptr(attrs), _ptr(g), P, F,
+                                                D, _ptr(gb), _ptr(gf), _stream(dev))
+        _lib.check(rc, "interp_face_attrs_backward")
+    return gb, gf
+
+
+HOT_PATH_EXPORTS = (
+    "rasterize_meshes", "rasterize_meshes_backward", "_rasterize_meshes_naive", "_rasterize_meshes_coarse",
+    "_rasterize_meshes_fine", "rasterize_points", "rasterize_points_backward", "_rasterize_points_naive",
+    "_rasterize_points_coarse", "_rasterize_points_fine", "accum_alphacomposite", "accum_alphacomposite_backward",
+    "accum_weightedsumnorm", "accum_weightedsumnorm_backward", "accum_weightedsum", "accum_weightedsum_backward",
+    "interp_face_attrs_forward", "interp_face_attrs_backward",
+)

@@ -1,0 +1,114 @@
+"""ctypes binding of libp3d_amd.so (the C ABI declared in include/p3d_amd.h).
+
+There is no fallback: if the HIP library is missing or cannot be loaded, every operator of this
+package raises.  Build it with `python -m pytorch3d_amd.build` (hipcc, gfx950).
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libp3d_amd.so")
+
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_f32 = ctypes.c_float
+c_ptr = ctypes.c_void_p
+c_size = ctypes.c_size_t
+
+_SIGNATURES = {
+    # name: (restype, [argtypes])
+    "p3d_abi_version": (c_int, []),
+    "p3d_error_string": (ctypes.c_char_p, [c_int]),
+    "p3d_rasterize_meshes_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int, c_int, c_int]),
+    "p3d_rasterize_meshes": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_f32, c_int, c_int, c_int,
+                                     c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "p3d_rasterize_meshes_naive": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_f32, c_int, c_int,
+                                           c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "p3d_rasterize_meshes_coarse": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_f32, c_int, c_int, c_ptr,
+                                            c_ptr, c_size, c_ptr]),
+    "p3d_rasterize_fine_workspace_bytes": (c_size, [c_int, c_int, c_int, c_int]),
+    "p3d_rasterize_meshes_fine": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_f32,
+                                          c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size,
+                                          c_ptr]),
+    "p3d_rasterize_meshes_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int,
+                                              c_int, c_int, c_ptr, c_ptr]),
+    "p3d_rasterize_points_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int, c_int, c_int]),
+    "p3d_rasterize_points": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr,
+                                     c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "p3d_rasterize_points_naive": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_ptr,
+                                           c_ptr, c_ptr]),
+    "p3d_rasterize_points_coarse": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_int, c_ptr,
+                                            c_ptr, c_size, c_ptr]),
+    "p3d_rasterize_points_fine": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                          c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "p3d_rasterize_points_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr,
+                                              c_ptr]),
+    "p3d_composite_forward": (c_int, [c_int, c_ptr, c_ptr, c_ptr, c_int, c_int, c_i64, c_int, c_int, c_int,
+                                      ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_ptr, c_ptr]),
+    "p3d_composite_backward": (c_int, [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_i64, c_int, c_int, c_int,
+                                       ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_ptr, c_ptr, c_ptr]),
+    "p3d_interp_face_attrs_forward": (c_int, [c_int, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
+    "p3d_interp_face_attrs_backward": (c_int, [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr,
+                                               c_ptr]),
+    "p3d_profile_enable": (None, [c_int]),
+    "p3d_profile_collect": (None, []),
+    "p3d_profile_num_entries": (c_int, []),
+    "p3d_profile_entry": (ctypes.c_char_p, [c_int, ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_double)]),
+    "p3d_profile_reset": (None, []),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lock = threading.Lock()
+_lib = None
+
+
+class ExtensionMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load libp3d_amd.so; raise loudly when it is absent (there is no CPU or eager fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ExtensionMissing(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run `python -m pytorch3d_amd.build` "
+                "(hipcc --offload-arch=gfx950). pytorch3d_amd has no CPU/eager fallback.")
+        try:
+            lib = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # e.g. libamdhip64 missing
+            raise ExtensionMissing(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        if lib.p3d_abi_version() != 1:
+            raise ExtensionMissing(f"{LIB_PATH}: ABI version {lib.p3d_abi_version()} != 1; rebuild")
+        _lib = lib
+    return _lib
+
+
+def check(code, where):
+    if code != 0:
+        msg = load().p3d_error_string(code).decode()
+        raise RuntimeError(f"{where}: {msg} (p3d error {code})")
+
+
+def profile_snapshot():
+    """{kernel name: (launches, total_ms)} since the last reset; synchronises the recorded events."""
+    lib = load()
+    lib.p3d_profile_collect()
+    out = {}
+    for i in range(lib.p3d_profile_num_entries()):
+        n = c_i64(0)
+        ms = ctypes.c_double(0.0)
+        name = lib.p3d_profile_entry(i, ctypes.byref(n), ctypes.byref(ms))
+        if name is not None and n.value > 0:
+            out[name.decode()] = (n.value, ms.value)
+    return out

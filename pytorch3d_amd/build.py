@@ -1,0 +1,71 @@
+"""Build libp3d_amd.so (the C-ABI HIP library, include/p3d_amd.h) in-tree with hipcc for gfx950.
+
+    python -m pytorch3d_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off is part of the arithmetic contract
+(bit-exact pix_to_face needs the reference's expression trees without FMA contraction);
+-munsafe-fp-atomics selects the hardware global_atomic_add_f32 for the backward scatters.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libp3d_amd.so")
+ARCH = "gfx950"
+
+SOURCES = ["binning.hip", "raster_mesh.hip", "raster_points.hip", "composite.hip", "interp.hip", "profile.cpp"]
+HEADERS = ["binning.h", "p3d_common.h", "p3d_geom.h", "topk.h", os.path.join("..", "..", "include", "p3d_amd.h")]
+
+FLAGS = [
+    f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off",
+    "-munsafe-fp-atomics", "-Wno-unused-result",
+]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _newest(paths):
+    return max(os.path.getmtime(p) for p in paths if os.path.exists(p))
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return _newest(deps) > os.path.getmtime(LIB)
+
+
+def build(force=False, verbose=False):
+    if not (force or needs_build()):
+        return LIB
+    hipcc = _hipcc()
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src + ".o")
+        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,65 @@
+// binning.h -- coarse stage: per-(batch element, bin) ascending CSR lists of primitives.
+//
+// Replaces TriangleBoundingBoxKernel / PointBoundingBoxKernel / RasterizeCoarseCudaKernel
+// (pytorch3d/csrc/rasterize_coarse/rasterize_coarse.cu:20-219) with a count -> scan -> fill
+// pipeline: deterministic, sorted, exactly sized, O(E) instead of O(N * E).
+#pragma once
+
+#include "p3d_common.h"
+
+namespace p3d {
+
+constexpr int kBinChunk = 1024;  // primitives per workgroup in the count / fill passes
+constexpr int kMaxBins = P3D_MAX_BINS_PER_SIDE * P3D_MAX_BINS_PER_SIDE;
+
+enum BinKind { kTriangles = 0, kPoints = 1 };
+
+struct BinGeom {
+  int H, W, bin_size, BH, BW, nbins;
+};
+
+inline BinGeom make_geom(int H, int W, int bin_size) {
+  BinGeom g;
+  g.H = H;
+  g.W = W;
+  g.bin_size = bin_size;
+  g.BH = 1 + (H - 1) / bin_size;
+  g.BW = 1 + (W - 1) / bin_size;
+  g.nbins = g.BH * g.BW;
+  return g;
+}
+
+// Device-side CSR view consumed by the fine kernels.
+struct BinCSR {
+  const int64_t* offset;  // (N*nbins) start of each bin's list inside `list`
+  const int* total;       // (N*nbins) entries in each bin's list
+  const int* list;        // primitive ids (packed, global), ascending per bin
+};
+
+struct BinWorkspace {
+  int* chunk_start;  // (N+1)
+  int* counts;       // (max_chunks * nbins)
+  int* total;        // (N*nbins)
+  int64_t* offset;   // (N*nbins + 1)
+  int* list;         // (capacity)
+  int64_t max_chunks;
+  int64_t capacity;
+};
+
+int64_t bin_capacity(int64_t E, int N, const BinGeom& g, int M);
+size_t bin_workspace_bytes(int64_t E, int N, const BinGeom& g, int M);
+// Carve `arena`; returns false when it is too small.
+bool bin_carve(Arena& arena, int64_t E, int N, const BinGeom& g, int M, BinWorkspace* ws);
+
+// Build the CSR lists.  elems: face_verts (E,3,3) or points (E,3); aux: radius (E) for points.
+int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t* first, const int64_t* count, int64_t E,
+              int N, const BinGeom& g, int M, float sqrt_blur, const BinWorkspace& ws, hipStream_t stream);
+
+// CSR -> the reference's padded (N,BH,BW,M) int32 layout, -1 filled.
+int bin_expand_padded(const BinWorkspace& ws, int N, const BinGeom& g, int M, int32_t* out, hipStream_t stream);
+
+// Padded (N,BH,BW,M) with -1 sentinels anywhere -> compacted lists at row*M inside ws_list, totals, offsets.
+int bin_compact_padded(const int32_t* padded, int64_t rows, int M, int* ws_list, int* ws_total, int64_t* ws_offset,
+                       hipStream_t stream);
+
+}  // namespace p3d

@@ -1,0 +1,439 @@
+// binning.hip -- coarse rasterization for gfx950: count -> scan -> fill.
+//
+// What it computes is RasterizeCoarseCudaKernel's bin membership
+// (pytorch3d/csrc/rasterize_coarse/rasterize_coarse.cu:143-167), with the same float
+// expressions for the bin edges so that membership is bit-identical; how it computes it is
+// different: a workgroup owns 1024 consecutive primitives of ONE batch element, every
+// primitive derives its bin rectangle from two monotone edge tables held in LDS (the
+// reference brute-forces all bins), waves count members per bin with a 64-bit ballot +
+// popcount, and a second pass re-derives the ballots and places ids at
+// offset + mbcnt-prefix.  Lists come out ascending and exactly sized; nothing is pre-filled.
+#include "binning.h"
+#include "p3d_geom.h"
+
+namespace p3d {
+
+namespace {
+
+constexpr int kWavesPerChunk = kBinChunk / kWave;  // 16
+
+// ---------------------------------------------------------------------------------------
+// plan: chunk_start[n] = sum_{m<n} ceil(count[m] / 1024); chunk_start[N] = total chunks.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void bin_plan_kernel(const int64_t* __restrict__ count, int N,
+                                                        int* __restrict__ chunk_start) {
+  __shared__ int scan[1024];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < N; base += 1024) {
+    const int i = base + tid;
+    int v = 0;
+    if (i < N) {
+      const int64_t c = count[i];
+      v = c > 0 ? (int)((c + kBinChunk - 1) / kBinChunk) : 0;
+    }
+    scan[tid] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const int add = tid >= d ? scan[tid - d] : 0;
+      __syncthreads();
+      scan[tid] += add;
+      __syncthreads();
+    }
+    const int carry = carry_s;
+    if (i < N) chunk_start[i] = carry + scan[tid] - v;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + scan[1023];
+    __syncthreads();
+  }
+  if (tid == 0) chunk_start[N] = carry_s;
+}
+
+// Per-primitive bin rectangle.  lo > hi means "covers nothing".
+struct BinRect {
+  int x0, x1, y0, y1;
+};
+
+struct ChunkCtx {
+  int n;        // batch element
+  int64_t e;    // this thread's primitive (global packed id), -1 if none
+  BinRect r;    // its rectangle
+  BinRect u;    // union over the wave
+};
+
+// Shared prologue of the count and fill kernels.
+template <int KIND>
+__device__ __forceinline__ bool chunk_prologue(const float* __restrict__ elems, const float* __restrict__ aux,
+                                               const int64_t* __restrict__ first, const int64_t* __restrict__ count,
+                                               const int* __restrict__ chunk_start, int N, int H, int W, int bin_size,
+                                               int BH, int BW, float sqrt_blur, float* xlo_t, float* xhi_t,
+                                               float* ylo_t, float* yhi_t, ChunkCtx* c) {
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x;
+  if (chunk >= chunk_start[N]) return false;
+  // largest n with chunk_start[n] <= chunk
+  int lo = 0, hi = N;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (chunk_start[mid] <= chunk)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  c->n = lo;
+  // Bin edge tables (rasterize_coarse.cu:148-160), monotone in the bin index.
+  if (tid < BW) {
+    xlo_t[tid] = bin_lo(tid, bin_size, W, H);
+    xhi_t[tid] = bin_hi(tid, bin_size, W, H);
+  } else if (tid >= 64 && tid < 64 + BH) {
+    const int b = tid - 64;
+    ylo_t[b] = bin_lo(b, bin_size, H, W);
+    yhi_t[b] = bin_hi(b, bin_size, H, W);
+  }
+  __syncthreads();
+
+  const int64_t local = (int64_t)(chunk - chunk_start[lo]) * kBinChunk + tid;
+  const int64_t cnt = count[lo];
+  BinRect r;
+  r.x0 = r.y0 = 1 << 20;
+  r.x1 = r.y1 = -1;
+  c->e = -1;
+  if (local < cnt) {
+    const int64_t e = first[lo] + local;
+    c->e = e;
+    float xmin, xmax, ymin, ymax;
+    bool skip;
+    if (KIND == kTriangles) {
+      // TriangleBoundingBoxKernel, rasterize_coarse.cu:28-44
+      const float* q = elems + e * 9;
+      const float v0x = q[0], v0y = q[1], v0z = q[2];
+      const float v1x = q[3], v1y = q[4], v1z = q[5];
+      const float v2x = q[6], v2y = q[7], v2z = q[8];
+      xmin = min3(v0x, v1x, v2x) - sqrt_blur;
+      xmax = max3(v0x, v1x, v2x) + sqrt_blur;
+      ymin = min3(v0y, v1y, v2y) - sqrt_blur;
+      ymax = max3(v0y, v1y, v2y) + sqrt_blur;
+      skip = (double)min3(v0z, v1z, v2z) < P3D_KEPS;
+    } else {
+      // PointBoundingBoxKernel, rasterize_coarse.cu:61-72
+      const float* q = elems + e * 3;
+      const float rad = aux[e];
+      xmin = q[0] - rad;
+      xmax = q[0] + rad;
+      ymin = q[1] - rad;
+      ymax = q[1] + rad;
+      skip = q[2] < 0.0f;
+    }
+    if (!skip) {
+      // overlap(b) = (min <= hi_t[b]) && (lo_t[b] < max); both predicates are monotone in b,
+      // so the overlapping bins are the interval [#(hi_t < min), #(lo_t < max) - 1].
+      int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+      for (int b = 0; b < BW; ++b) {
+        x0 += (xmin <= xhi_t[b]) ? 0 : 1;
+        x1 += (xlo_t[b] < xmax) ? 1 : 0;
+      }
+      for (int b = 0; b < BH; ++b) {
+        y0 += (ymin <= yhi_t[b]) ? 0 : 1;
+        y1 += (ylo_t[b] < ymax) ? 1 : 0;
+      }
+      x1 -= 1;
+      y1 -= 1;
+      if (x0 <= x1 && y0 <= y1) {
+        r.x0 = x0;
+        r.x1 = x1;
+        r.y0 = y0;
+        r.y1 = y1;
+      }
+    }
+  }
+  c->r = r;
+  // union rectangle over the wave (butterfly)
+  BinRect u = r;
+  for (int d = 32; d >= 1; d >>= 1) {
+    u.x0 = min(u.x0, __shfl_xor(u.x0, d));
+    u.y0 = min(u.y0, __shfl_xor(u.y0, d));
+    u.x1 = max(u.x1, __shfl_xor(u.x1, d));
+    u.y1 = max(u.y1, __shfl_xor(u.y1, d));
+  }
+  c->u = u;
+  return true;
+}
+
+__device__ __forceinline__ bool rect_has(const BinRect& r, int by, int bx) {
+  return bx >= r.x0 && bx <= r.x1 && by >= r.y0 && by <= r.y1;
+}
+
+// ---------------------------------------------------------------------------------------
+// count: counts[chunk][bin] = members of `bin` among the chunk's 1024 primitives.
+// ---------------------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(kBinChunk) void bin_count_kernel(const float* __restrict__ elems,
+                                                              const float* __restrict__ aux,
+                                                              const int64_t* __restrict__ first,
+                                                              const int64_t* __restrict__ count,
+                                                              const int* __restrict__ chunk_start, int N, int H, int W,
+                                                              int bin_size, int BH, int BW, float sqrt_blur,
+                                                              int* __restrict__ counts) {
+  __shared__ float xlo_t[32], xhi_t[32], ylo_t[32], yhi_t[32];
+  __shared__ int blk_cnt[kMaxBins];
+  const int nbins = BH * BW;
+  for (int b = threadIdx.x; b < nbins; b += kBinChunk) blk_cnt[b] = 0;
+  ChunkCtx c;
+  if (!chunk_prologue<KIND>(elems, aux, first, count, chunk_start, N, H, W, bin_size, BH, BW, sqrt_blur, xlo_t, xhi_t,
+                            ylo_t, yhi_t, &c))
+    return;
+  const int lane = lane_id();
+  for (int by = c.u.y0; by <= c.u.y1; ++by) {
+    for (int bx = c.u.x0; bx <= c.u.x1; ++bx) {
+      const unsigned long long m = __ballot(rect_has(c.r, by, bx));
+      if (lane == 0 && m) atomicAdd(&blk_cnt[by * BW + bx], __popcll(m));
+    }
+  }
+  __syncthreads();
+  int* out = counts + (int64_t)blockIdx.x * nbins;
+  for (int b = threadIdx.x; b < nbins; b += kBinChunk) out[b] = blk_cnt[b];
+}
+
+// ---------------------------------------------------------------------------------------
+// row scan: for each (n, bin) an exclusive scan of counts over n's chunks, in place.
+// One wave per row.  total[row] = min(sum, M).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bin_scan_rows_kernel(int* __restrict__ counts,
+                                                            const int* __restrict__ chunk_start, int N, int nbins, int M,
+                                                            int* __restrict__ total) {
+  const int lane = lane_id();
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+  if (row >= (int64_t)N * nbins) return;
+  const int n = (int)(row / nbins);
+  const int b = (int)(row % nbins);
+  const int c0 = chunk_start[n];
+  const int nch = chunk_start[n + 1] - c0;
+  int carry = 0;
+  for (int base = 0; base < nch; base += kWave) {
+    const int i = base + lane;
+    int* p = counts + ((int64_t)(c0 + i)) * nbins + b;
+    const int v = i < nch ? *p : 0;
+    int x = v;
+    for (int d = 1; d < kWave; d <<= 1) {
+      const int y = __shfl_up(x, d);
+      if (lane >= d) x += y;
+    }
+    if (i < nch) *p = carry + x - v;
+    carry += __shfl(x, kWave - 1);
+  }
+  if (lane == 0) total[row] = carry < M ? carry : M;
+}
+
+// ---------------------------------------------------------------------------------------
+// offsets: exclusive scan of total[] -> offset[] (int64), single workgroup.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void bin_scan_offsets_kernel(const int* __restrict__ total, int64_t rows,
+                                                                int64_t* __restrict__ offset) {
+  __shared__ int wsum[16];
+  __shared__ long long carry_s;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < rows; base += 1024) {
+    const int64_t i = base + tid;
+    const int v = i < rows ? total[i] : 0;
+    int x = v;
+    for (int d = 1; d < kWave; d <<= 1) {
+      const int y = __shfl_up(x, d);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    int wbase = 0;
+    for (int j = 0; j < w; ++j) wbase += wsum[j];
+    const long long carry = carry_s;
+    if (i < rows) offset[i] = carry + wbase + x - v;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + wbase + x;
+    __syncthreads();
+  }
+  if (tid == 0) offset[rows] = carry_s;
+}
+
+// ---------------------------------------------------------------------------------------
+// fill: re-derive the ballots and write ids at offset + row prefix + wave prefix + lane rank.
+// ---------------------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(kBinChunk) void bin_fill_kernel(const float* __restrict__ elems,
+                                                             const float* __restrict__ aux,
+                                                             const int64_t* __restrict__ first,
+                                                             const int64_t* __restrict__ count,
+                                                             const int* __restrict__ chunk_start, int N, int H, int W,
+                                                             int bin_size, int BH, int BW, float sqrt_blur, int M,
+                                                             const int* __restrict__ counts,
+                                                             const int64_t* __restrict__ offset,
+                                                             int* __restrict__ list) {
+  __shared__ float xlo_t[32], xhi_t[32], ylo_t[32], yhi_t[32];
+  __shared__ int wcnt[kWavesPerChunk][kMaxBins];
+  const int nbins = BH * BW;
+  for (int i = threadIdx.x; i < kWavesPerChunk * kMaxBins; i += kBinChunk) (&wcnt[0][0])[i] = 0;
+  ChunkCtx c;
+  if (!chunk_prologue<KIND>(elems, aux, first, count, chunk_start, N, H, W, bin_size, BH, BW, sqrt_blur, xlo_t, xhi_t,
+                            ylo_t, yhi_t, &c))
+    return;
+  const int lane = lane_id();
+  const int w = threadIdx.x / kWave;
+  // pass A: per-wave member counts (the prologue's barrier ordered the zero fill)
+  for (int by = c.u.y0; by <= c.u.y1; ++by) {
+    for (int bx = c.u.x0; bx <= c.u.x1; ++bx) {
+      const unsigned long long m = __ballot(rect_has(c.r, by, bx));
+      if (lane == 0) wcnt[w][by * BW + bx] = __popcll(m);
+    }
+  }
+  __syncthreads();
+  // pass B: exclusive prefix over the 16 waves, seeded with this chunk's row prefix
+  for (int b = threadIdx.x; b < nbins; b += kBinChunk) {
+    int run = counts[(int64_t)blockIdx.x * nbins + b];
+    for (int j = 0; j < kWavesPerChunk; ++j) {
+      const int v = wcnt[j][b];
+      wcnt[j][b] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  // pass C: place
+  const int64_t row0 = (int64_t)c.n * nbins;
+  for (int by = c.u.y0; by <= c.u.y1; ++by) {
+    for (int bx = c.u.x0; bx <= c.u.x1; ++bx) {
+      const bool mem = rect_has(c.r, by, bx);
+      const unsigned long long m = __ballot(mem);
+      if (mem) {
+        const int b = by * BW + bx;
+        const int pos = wcnt[w][b] + mask_rank(m);
+        if (pos < M) list[offset[row0 + b] + pos] = (int)c.e;
+      }
+    }
+  }
+}
+
+__global__ void bin_expand_kernel(const int64_t* __restrict__ offset, const int* __restrict__ total,
+                                  const int* __restrict__ list, int64_t rows, int M, int32_t* __restrict__ out) {
+  const int64_t n = rows * M;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / M;
+    const int m = (int)(i - row * M);
+    out[i] = m < total[row] ? list[offset[row] + m] : -1;
+  }
+}
+
+// padded row -> compacted (order kept) at row*M; one wave per row.
+__global__ __launch_bounds__(256) void bin_compact_kernel(const int32_t* __restrict__ padded, int64_t rows, int M,
+                                                          int* __restrict__ list, int* __restrict__ total,
+                                                          int64_t* __restrict__ offset) {
+  const int lane = lane_id();
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+  if (row >= rows) return;
+  const int32_t* src = padded + row * M;
+  int* dst = list + row * M;
+  int carry = 0;
+  for (int base = 0; base < M; base += kWave) {
+    const int i = base + lane;
+    const int v = i < M ? src[i] : -1;
+    const unsigned long long m = __ballot(v >= 0);
+    if (v >= 0) dst[carry + mask_rank(m)] = v;
+    carry += __popcll(m);
+  }
+  if (lane == 0) {
+    total[row] = carry;
+    offset[row] = row * M;
+  }
+}
+
+}  // namespace
+
+int64_t bin_capacity(int64_t E, int N, const BinGeom& g, int M) {
+  // Every bin holds at most M ids (the reference's own cap) and at most E_n ids.
+  const int64_t a = E * (int64_t)g.nbins;
+  const int64_t b = (int64_t)N * g.nbins * (int64_t)M;
+  int64_t c = a < b ? a : b;
+  if (c < 1) c = 1;
+  return c;
+}
+
+bool bin_carve(Arena& arena, int64_t E, int N, const BinGeom& g, int M, BinWorkspace* ws) {
+  ws->max_chunks = ceil_div(E, kBinChunk) + N;
+  ws->capacity = bin_capacity(E, N, g, M);
+  ws->chunk_start = arena.take<int>((size_t)N + 1);
+  ws->counts = arena.take<int>((size_t)ws->max_chunks * g.nbins);
+  ws->total = arena.take<int>((size_t)N * g.nbins);
+  ws->offset = arena.take<int64_t>((size_t)N * g.nbins + 1);
+  ws->list = arena.take<int>((size_t)ws->capacity);
+  return arena.ok();
+}
+
+size_t bin_workspace_bytes(int64_t E, int N, const BinGeom& g, int M) {
+  Arena probe(nullptr, 0);
+  BinWorkspace ws;
+  bin_carve(probe, E, N, g, M, &ws);
+  return probe.off;
+}
+
+int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t* first, const int64_t* count, int64_t E,
+              int N, const BinGeom& g, int M, float sqrt_blur, const BinWorkspace& ws, hipStream_t stream) {
+  if (N <= 0) return P3D_OK;
+  const int64_t rows = (int64_t)N * g.nbins;
+  {
+    LaunchScope ls("bin_plan", stream);
+    bin_plan_kernel<<<1, 1024, 0, stream>>>(count, N, ws.chunk_start);
+  }
+  const unsigned chunks = (unsigned)ws.max_chunks;
+  {
+    LaunchScope ls("bin_count", stream);
+    if (kind == kTriangles)
+      bin_count_kernel<kTriangles><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, ws.chunk_start, N, g.H,
+                                                                    g.W, g.bin_size, g.BH, g.BW, sqrt_blur, ws.counts);
+    else
+      bin_count_kernel<kPoints><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, ws.chunk_start, N, g.H, g.W,
+                                                                 g.bin_size, g.BH, g.BW, sqrt_blur, ws.counts);
+  }
+  {
+    LaunchScope ls("bin_scan_rows", stream);
+    bin_scan_rows_kernel<<<(unsigned)ceil_div(rows, 4), 256, 0, stream>>>(ws.counts, ws.chunk_start, N, g.nbins, M,
+                                                                         ws.total);
+  }
+  {
+    LaunchScope ls("bin_scan_offsets", stream);
+    bin_scan_offsets_kernel<<<1, 1024, 0, stream>>>(ws.total, rows, ws.offset);
+  }
+  {
+    LaunchScope ls("bin_fill", stream);
+    if (kind == kTriangles)
+      bin_fill_kernel<kTriangles><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, ws.chunk_start, N, g.H,
+                                                                   g.W, g.bin_size, g.BH, g.BW, sqrt_blur, M, ws.counts,
+                                                                   ws.offset, ws.list);
+    else
+      bin_fill_kernel<kPoints><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, ws.chunk_start, N, g.H, g.W,
+                                                                g.bin_size, g.BH, g.BW, sqrt_blur, M, ws.counts,
+                                                                ws.offset, ws.list);
+  }
+  return launch_status();
+}
+
+int bin_expand_padded(const BinWorkspace& ws, int N, const BinGeom& g, int M, int32_t* out, hipStream_t stream) {
+  const int64_t rows = (int64_t)N * g.nbins;
+  const int64_t n = rows * M;
+  if (n <= 0) return P3D_OK;
+  int64_t blocks = ceil_div(n, 256);
+  if (blocks > 8192) blocks = 8192;
+  LaunchScope ls("bin_expand", stream);
+  bin_expand_kernel<<<(unsigned)blocks, 256, 0, stream>>>(ws.offset, ws.total, ws.list, rows, M, out);
+  return launch_status();
+}
+
+int bin_compact_padded(const int32_t* padded, int64_t rows, int M, int* ws_list, int* ws_total, int64_t* ws_offset,
+                       hipStream_t stream) {
+  if (rows <= 0) return P3D_OK;
+  LaunchScope ls("bin_compact", stream);
+  bin_compact_kernel<<<(unsigned)ceil_div(rows, 4), 256, 0, stream>>>(padded, rows, M, ws_list, ws_total, ws_offset);
+  return launch_status();
+}
+
+}  // namespace p3d

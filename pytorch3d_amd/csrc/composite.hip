@@ -1,0 +1,351 @@
+// composite.hip -- alpha / normalised-weighted-sum / weighted-sum compositing for gfx950.
+//
+// Replaces alphaCompositeCuda{Forward,Backward}Kernel (pytorch3d/csrc/compositing/
+// alpha_composite.cu:24-141), weightedSumNormCuda* (norm_weighted_sum.cu:24-154) and
+// weightedSumCuda* (weighted_sum.cu:22-113).
+//
+// The reference runs one thread per (channel, pixel): each of the C threads of a pixel re-reads
+// the pixel's K (index, alpha) pairs, accumulates into its own output element with atomicAdd and
+// forces contiguous (N,K,H,W) copies of what arrive as permuted (N,H,W,K) views
+// (alpha_composite.h:63-65).  Here one thread owns a pixel: it loads the K pairs once into
+// VGPRs (through the caller's strides -- no copy), walks the channels, and writes each output
+// element exactly once; grad_alphas is accumulated in registers and written once, only
+// grad_features (a genuine scatter) uses f32 atomics.
+#include "p3d_common.h"
+
+namespace p3d {
+namespace {
+
+struct CompArgs {
+  const float* features;     // (C, P)
+  const float* alphas;       // logical (N,K,H,W)
+  const int64_t* idx;        // logical (N,K,H,W)
+  const float* grad_out;     // (N,C,H,W)
+  int N, C, K, H, W;
+  int64_t P;
+  int64_t as[4], is[4];      // element strides
+  float* result;             // (N,C,H,W)
+  float* grad_features;      // (C,P)
+  float* grad_alphas;        // (N,K,H,W) contiguous
+};
+
+constexpr float kEpsAlpha = 1e-9f;  // alpha_composite.cu:20
+constexpr float kEpsNorm = 1e-4f;   // norm_weighted_sum.cu:20
+
+// KT > 0: the K pairs are cached in registers (K <= KT).  KT == 0: re-read per channel.
+template <int MODE, int KT>
+__global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs a) {
+  const int64_t npix = (int64_t)a.N * a.H * a.W;
+  const int K = a.K, C = a.C;
+  const int64_t HW = (int64_t)a.H * a.W;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < npix; t += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(t / HW);
+    const int64_t yx = t % HW;
+    const int y = (int)(yx / a.W), x = (int)(yx % a.W);
+    const int64_t abase = n * a.as[0] + y * a.as[2] + x * a.as[3];
+    const int64_t ibase = n * a.is[0] + y * a.is[2] + x * a.is[3];
+    float* out = a.result + ((int64_t)n * C) * HW + yx;
+
+    if constexpr (KT > 0) {
+      int id[KT];
+      float al[KT];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        id[k] = -1;
+        al[k] = 0.0f;
+        if (k < K) {
+          id[k] = (int)a.idx[ibase + k * a.is[1]];
+          al[k] = a.alphas[abase + k * a.as[1]];
+        }
+      }
+      float norm = 0.0f;
+      if (MODE == P3D_COMPOSITE_NORM_SUM) {
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+          if (id[k] >= 0) norm += al[k];
+        if (norm < kEpsNorm) norm = kEpsNorm;
+      }
+      for (int c = 0; c < C; ++c) {
+        const float* f = a.features + (int64_t)c * a.P;
+        float res = 0.0f;
+        float cum = 1.0f;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+          if (id[k] >= 0) {
+            const float fv = f[id[k]];
+            if (MODE == P3D_COMPOSITE_ALPHA) {
+              res += fv * cum * al[k];
+              cum = cum * (1 - al[k]);
+            } else if (MODE == P3D_COMPOSITE_NORM_SUM) {
+              res += fv * al[k] / norm;
+            } else {
+              res += fv * al[k];
+            }
+          }
+        }
+        out[(int64_t)c * HW] = res;
+      }
+    } else {
+      float norm = 0.0f;
+      if (MODE == P3D_COMPOSITE_NORM_SUM) {
+        for (int k = 0; k < K; ++k)
+          if ((int)a.idx[ibase + k * a.is[1]] >= 0) norm += a.alphas[abase + k * a.as[1]];
+        if (norm < kEpsNorm) norm = kEpsNorm;
+      }
+      for (int c = 0; c < C; ++c) {
+        const float* f = a.features + (int64_t)c * a.P;
+        float res = 0.0f;
+        float cum = 1.0f;
+        for (int k = 0; k < K; ++k) {
+          const int id = (int)a.idx[ibase + k * a.is[1]];
+          if (id < 0) continue;
+          const float al = a.alphas[abase + k * a.as[1]];
+          const float fv = f[id];
+          if (MODE == P3D_COMPOSITE_ALPHA) {
+            res += fv * cum * al;
+            cum = cum * (1 - al);
+          } else if (MODE == P3D_COMPOSITE_NORM_SUM) {
+            res += fv * al / norm;
+          } else {
+            res += fv * al;
+          }
+        }
+        out[(int64_t)c * HW] = res;
+      }
+    }
+  }
+}
+
+template <int MODE, int KT>
+__global__ __launch_bounds__(256) void composite_bwd_kernel(CompArgs a) {
+  const int64_t npix = (int64_t)a.N * a.H * a.W;
+  const int K = a.K, C = a.C;
+  const int64_t HW = (int64_t)a.H * a.W;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < npix; t += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(t / HW);
+    const int64_t yx = t % HW;
+    const int y = (int)(yx / a.W), x = (int)(yx % a.W);
+    const int64_t abase = n * a.as[0] + y * a.as[2] + x * a.as[3];
+    const int64_t ibase = n * a.is[0] + y * a.is[2] + x * a.is[3];
+    const float* go_p = a.grad_out + ((int64_t)n * C) * HW + yx;
+    float* ga_p = a.grad_alphas + ((int64_t)n * K) * HW + yx;  // + k*HW
+
+    if constexpr (KT > 0) {
+      int id[KT];
+      float al[KT], ga[KT];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        id[k] = -1;
+        al[k] = 0.0f;
+        ga[k] = 0.0f;
+        if (k < K) {
+          id[k] = (int)a.idx[ibase + k * a.is[1]];
+          al[k] = a.alphas[abase + k * a.as[1]];
+        }
+      }
+      float sum_alpha = 0.0f;
+      if (MODE == P3D_COMPOSITE_NORM_SUM) {
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+          if (id[k] >= 0) sum_alpha += al[k];
+        if (sum_alpha < kEpsNorm) sum_alpha = kEpsNorm;
+      }
+      for (int c = 0; c < C; ++c) {
+        const float* f = a.features + (int64_t)c * a.P;
+        float* gf = a.grad_features + (int64_t)c * a.P;
+        const float go = go_p[(int64_t)c * HW];
+        if (MODE == P3D_COMPOSITE_ALPHA) {
+          float cum = 1.0f;
+#pragma unroll
+          for (int k = 0; k < KT; ++k) {
+            if (id[k] >= 0) {
+              const float fv = f[id[k]];
+              ga[k] += cum * fv * go;
+              unsafeAtomicAdd(gf + id[k], cum * al[k] * go);
+              const float back = -go * fv * cum * al[k];
+#pragma unroll
+              for (int tt = 0; tt < KT; ++tt) {
+                if (tt < k && id[tt] >= 0) ga[tt] += back / (1 - al[tt] + kEpsAlpha);
+              }
+              cum = cum * (1 - al[k]);
+            }
+          }
+        } else if (MODE == P3D_COMPOSITE_NORM_SUM) {
+          float sum_af = 0.0f;
+#pragma unroll
+          for (int k = 0; k < KT; ++k)
+            if (id[k] >= 0) sum_af += al[k] * f[id[k]];
+#pragma unroll
+          for (int k = 0; k < KT; ++k) {
+            if (id[k] >= 0) {
+              ga[k] += (f[id[k]] * sum_alpha - sum_af) / (sum_alpha * sum_alpha) * go;
+              unsafeAtomicAdd(gf + id[k], al[k] * go / sum_alpha);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < KT; ++k) {
+            if (id[k] >= 0) {
+              ga[k] += f[id[k]] * go;
+              unsafeAtomicAdd(gf + id[k], al[k] * go);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < KT; ++k)
+        if (k < K) ga_p[(int64_t)k * HW] = ga[k];
+    } else {
+      // generic K: this thread owns grad_alphas[n, :, y, x]; accumulate there without atomics
+      for (int k = 0; k < K; ++k) ga_p[(int64_t)k * HW] = 0.0f;
+      float sum_alpha = 0.0f;
+      if (MODE == P3D_COMPOSITE_NORM_SUM) {
+        for (int k = 0; k < K; ++k)
+          if ((int)a.idx[ibase + k * a.is[1]] >= 0) sum_alpha += a.alphas[abase + k * a.as[1]];
+        if (sum_alpha < kEpsNorm) sum_alpha = kEpsNorm;
+      }
+      for (int c = 0; c < C; ++c) {
+        const float* f = a.features + (int64_t)c * a.P;
+        float* gf = a.grad_features + (int64_t)c * a.P;
+        const float go = go_p[(int64_t)c * HW];
+        float cum = 1.0f;
+        float sum_af = 0.0f;
+        if (MODE == P3D_COMPOSITE_NORM_SUM) {
+          for (int k = 0; k < K; ++k) {
+            const int id = (int)a.idx[ibase + k * a.is[1]];
+            if (id >= 0) sum_af += a.alphas[abase + k * a.as[1]] * f[id];
+          }
+        }
+        for (int k = 0; k < K; ++k) {
+          const int id = (int)a.idx[ibase + k * a.is[1]];
+          if (id < 0) continue;
+          const float al = a.alphas[abase + k * a.as[1]];
+          const float fv = f[id];
+          if (MODE == P3D_COMPOSITE_ALPHA) {
+            ga_p[(int64_t)k * HW] += cum * fv * go;
+            unsafeAtomicAdd(gf + id, cum * al * go);
+            const float back = -go * fv * cum * al;
+            for (int tt = 0; tt < k; ++tt) {
+              if ((int)a.idx[ibase + tt * a.is[1]] < 0) continue;
+              ga_p[(int64_t)tt * HW] += back / (1 - a.alphas[abase + tt * a.as[1]] + kEpsAlpha);
+            }
+            cum = cum * (1 - al);
+          } else if (MODE == P3D_COMPOSITE_NORM_SUM) {
+            ga_p[(int64_t)k * HW] += (fv * sum_alpha - sum_af) / (sum_alpha * sum_alpha) * go;
+            unsafeAtomicAdd(gf + id, al * go / sum_alpha);
+          } else {
+            ga_p[(int64_t)k * HW] += fv * go;
+            unsafeAtomicAdd(gf + id, al * go);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int MODE>
+int launch_fwd(const CompArgs& a, unsigned grid, hipStream_t s) {
+  if (a.K <= 8)
+    composite_fwd_kernel<MODE, 8><<<grid, 256, 0, s>>>(a);
+  else if (a.K <= 16)
+    composite_fwd_kernel<MODE, 16><<<grid, 256, 0, s>>>(a);
+  else
+    composite_fwd_kernel<MODE, 0><<<grid, 256, 0, s>>>(a);
+  return launch_status();
+}
+
+template <int MODE>
+int launch_bwd(const CompArgs& a, unsigned grid, hipStream_t s) {
+  if (a.K <= 8)
+    composite_bwd_kernel<MODE, 8><<<grid, 256, 0, s>>>(a);
+  else if (a.K <= 16)
+    composite_bwd_kernel<MODE, 16><<<grid, 256, 0, s>>>(a);
+  else
+    composite_bwd_kernel<MODE, 0><<<grid, 256, 0, s>>>(a);
+  return launch_status();
+}
+
+unsigned pick_grid(int64_t npix) {
+  int64_t blocks = ceil_div(npix, 256);
+  if (blocks > 16384) blocks = 16384;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+}  // namespace
+}  // namespace p3d
+
+using namespace p3d;
+
+P3D_API int p3d_composite_forward(int mode, const float* features, const float* alphas, const int64_t* points_idx, int N,
+                                  int C, int64_t P, int K, int H, int W, const int64_t alphas_strides[4],
+                                  const int64_t idx_strides[4], float* result, p3d_stream_t stream) {
+  if (mode < 0 || mode > 2 || N < 0 || C < 0 || K < 0 || H < 0 || W < 0 || P < 0) return P3D_ERR_INVALID_ARG;
+  const int64_t nout = (int64_t)N * C * H * W;
+  if (nout == 0) return P3D_OK;
+  if (!result || !alphas_strides || !idx_strides) return P3D_ERR_INVALID_ARG;
+  if (K > 0 && (!alphas || !points_idx || !features)) return P3D_ERR_INVALID_ARG;
+  CompArgs a{};
+  a.features = features;
+  a.alphas = alphas;
+  a.idx = points_idx;
+  a.N = N;
+  a.C = C;
+  a.K = K;
+  a.H = H;
+  a.W = W;
+  a.P = P;
+  for (int i = 0; i < 4; ++i) {
+    a.as[i] = alphas_strides[i];
+    a.is[i] = idx_strides[i];
+  }
+  a.result = result;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = pick_grid((int64_t)N * H * W);
+  LaunchScope ls(mode == 0 ? "alpha_composite_fwd" : (mode == 1 ? "norm_weighted_sum_fwd" : "weighted_sum_fwd"), s);
+  if (mode == P3D_COMPOSITE_ALPHA) return launch_fwd<P3D_COMPOSITE_ALPHA>(a, grid, s);
+  if (mode == P3D_COMPOSITE_NORM_SUM) return launch_fwd<P3D_COMPOSITE_NORM_SUM>(a, grid, s);
+  return launch_fwd<P3D_COMPOSITE_SUM>(a, grid, s);
+}
+
+P3D_API int p3d_composite_backward(int mode, const float* grad_outputs, const float* features, const float* alphas,
+                                   const int64_t* points_idx, int N, int C, int64_t P, int K, int H, int W,
+                                   const int64_t alphas_strides[4], const int64_t idx_strides[4], float* grad_features,
+                                   float* grad_alphas, p3d_stream_t stream) {
+  if (mode < 0 || mode > 2 || N < 0 || C < 0 || K < 0 || H < 0 || W < 0 || P < 0) return P3D_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if ((int64_t)C * P > 0) {
+    if (!grad_features) return P3D_ERR_INVALID_ARG;
+    if (hipMemsetAsync(grad_features, 0, (size_t)C * P * sizeof(float), s) != hipSuccess) return P3D_ERR_LAUNCH;
+  }
+  const int64_t nga = (int64_t)N * K * H * W;
+  if (nga == 0) return P3D_OK;
+  if (!grad_alphas || !alphas || !points_idx || !alphas_strides || !idx_strides) return P3D_ERR_INVALID_ARG;
+  if (C == 0) {
+    if (hipMemsetAsync(grad_alphas, 0, (size_t)nga * sizeof(float), s) != hipSuccess) return P3D_ERR_LAUNCH;
+    return P3D_OK;
+  }
+  if (!grad_outputs || !features) return P3D_ERR_INVALID_ARG;
+  CompArgs a{};
+  a.features = features;
+  a.alphas = alphas;
+  a.idx = points_idx;
+  a.grad_out = grad_outputs;
+  a.N = N;
+  a.C = C;
+  a.K = K;
+  a.H = H;
+  a.W = W;
+  a.P = P;
+  for (int i = 0; i < 4; ++i) {
+    a.as[i] = alphas_strides[i];
+    a.is[i] = idx_strides[i];
+  }
+  a.grad_features = grad_features;
+  a.grad_alphas = grad_alphas;
+  const unsigned grid = pick_grid((int64_t)N * H * W);
+  LaunchScope ls(mode == 0 ? "alpha_composite_bwd" : (mode == 1 ? "norm_weighted_sum_bwd" : "weighted_sum_bwd"), s);
+  if (mode == P3D_COMPOSITE_ALPHA) return launch_bwd<P3D_COMPOSITE_ALPHA>(a, grid, s);
+  if (mode == P3D_COMPOSITE_NORM_SUM) return launch_bwd<P3D_COMPOSITE_NORM_SUM>(a, grid, s);
+  return launch_bwd<P3D_COMPOSITE_SUM>(a, grid, s);
+}

@@ -1,0 +1,409 @@
+// p3d_geom.h -- the arithmetic contract of the rasterization hot path.
+//
+// Every function here is a per-(pixel, primitive) scalar routine shared by all
+// gfx950 kernels in this directory.  The expression trees follow the CUDA
+// variant of the reference (pytorch3d/csrc/utils/geometry_utils.cuh:37-462,
+// pytorch3d/csrc/rasterize_points/rasterization_utils.cuh:16-42) operation by
+// operation, because pix_to_face must come out bit-exact: no FMA contraction
+// (the translation units are compiled with -ffp-contract=off), IEEE division and
+// sqrt, and the reference's mixed float/double epsilon arithmetic
+// (`const auto kEpsilon = 1e-8` is a double, geometry_utils.cuh:18).
+//
+// The header is also host-compilable (plain C++), so tests/ can build it with
+// g++ and check the very same functions against oracle/ without a GPU.
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define P3D_HD __host__ __device__ __forceinline__
+#define P3D_HDM __host__ __device__ __forceinline__
+#else
+#define P3D_HD static inline
+#define P3D_HDM inline
+#endif
+
+namespace p3d {
+
+// geometry_utils.cuh:18 -- a double; comparisons against it promote the float side.
+#define P3D_KEPS 1e-8
+
+struct f2 {
+  float x, y;
+};
+struct f3 {
+  float x, y, z;
+};
+
+P3D_HD f2 mk2(float x, float y) {
+  f2 r;
+  r.x = x;
+  r.y = y;
+  return r;
+}
+P3D_HD f3 mk3(float x, float y, float z) {
+  f3 r;
+  r.x = x;
+  r.y = y;
+  r.z = z;
+  return r;
+}
+
+P3D_HD float min3(float a, float b, float c) { return fminf(a, fminf(b, c)); }
+P3D_HD float max3(float a, float b, float c) { return fmaxf(a, fmaxf(b, c)); }
+// __saturatef semantics: clamp to [+0, 1], NaN -> +0.
+P3D_HD float sat01(float t) { return fminf(fmaxf(t, 0.0f), 1.0f); }
+
+// ---------------------------------------------------------------------------
+// Pixel <-> NDC (rasterization_utils.cuh:16-42).  The short image side spans
+// [-1, 1]; the long side is scaled by the aspect ratio.  Pixel centres.
+// ---------------------------------------------------------------------------
+P3D_HD float ndc_range(int S1, int S2) {
+  float range = 2.0f;
+  if (S1 > S2) {
+    range = ((float)S1 * range) / (float)S2;
+  }
+  return range;
+}
+
+P3D_HD float pix_to_ndc(int i, int S1, int S2) {
+  const float range = ndc_range(S1, S2);
+  const float offset = range / 2.0f;
+  return -offset + (range * (float)i + offset) / (float)S1;
+}
+
+// Half a pixel in NDC units along the S1 axis (rasterize_coarse.cu:99-105).
+P3D_HD float half_pixel(int S1, int S2) { return (ndc_range(S1, S2) / 2.0f) / (float)S1; }
+
+// Lower/upper NDC edge of bin b along an axis (rasterize_coarse.cu:148-160).
+P3D_HD float bin_lo(int b, int bin_size, int S1, int S2) {
+  return pix_to_ndc(b * bin_size, S1, S2) - half_pixel(S1, S2);
+}
+P3D_HD float bin_hi(int b, int bin_size, int S1, int S2) {
+  return pix_to_ndc((b + 1) * bin_size - 1, S1, S2) + half_pixel(S1, S2);
+}
+
+// ---------------------------------------------------------------------------
+// 2D edge function and barycentrics (geometry_utils.cuh:37-86).
+// ---------------------------------------------------------------------------
+P3D_HD float edge_fn(f2 p, f2 a, f2 b) { return (p.x - a.x) * (b.y - a.y) - (p.y - a.y) * (b.x - a.x); }
+
+// area = float(double(edge) + 1e-8): one double add, then narrowing.
+P3D_HD float bary_area(f2 v0, f2 v1, f2 v2) { return (float)((double)edge_fn(v2, v0, v1) + P3D_KEPS); }
+
+P3D_HD f3 bary_coords(f2 p, f2 v0, f2 v1, f2 v2) {
+  const float area = bary_area(v0, v1, v2);
+  const float w0 = edge_fn(p, v1, v2) / area;
+  const float w1 = edge_fn(p, v2, v0) / area;
+  const float w2 = edge_fn(p, v0, v1) / area;
+  return mk3(w0, w1, w2);
+}
+
+// Perspective correction (geometry_utils.cuh:172-185).  Product order is the
+// CUDA one: (b.x*z1)*z2, (z0*b.y)*z2, (z0*z1)*b.z.
+P3D_HD f3 bary_perspective(f3 b, float z0, float z1, float z2) {
+  const float t0 = b.x * z1 * z2;
+  const float t1 = z0 * b.y * z2;
+  const float t2 = z0 * z1 * b.z;
+  const float denom = fmaxf(t0 + t1 + t2, (float)P3D_KEPS);
+  return mk3(t0 / denom, t1 / denom, t2 / denom);
+}
+
+// Clip to >= 0 and renormalise (geometry_utils.cuh:246-259).
+P3D_HD f3 bary_clip(f3 b) {
+  float w0 = b.x > 0.0f ? b.x : 0.0f;
+  float w1 = b.y > 0.0f ? b.y : 0.0f;
+  float w2 = b.z > 0.0f ? b.z : 0.0f;
+  float s = w0 + w1 + w2;
+  s = fmaxf(s, 1e-5f);
+  return mk3(w0 / s, w1 / s, w2 / s);
+}
+
+// Squared distance from p to segment (a, b) (geometry_utils.cuh:340-352).
+P3D_HD float seg_dist2(f2 p, f2 a, f2 b) {
+  const float bax = b.x - a.x;
+  const float bay = b.y - a.y;
+  const float l2 = bax * bax + bay * bay;
+  float t = (bax * (p.x - a.x) + bay * (p.y - a.y)) / l2;
+  if ((double)l2 <= P3D_KEPS) {
+    const float ex = p.x - b.x;
+    const float ey = p.y - b.y;
+    return ex * ex + ey * ey;
+  }
+  t = sat01(t);
+  const float dx = (a.x + t * bax) - p.x;
+  const float dy = (a.y + t * bay) - p.y;
+  return dx * dx + dy * dy;
+}
+
+// Squared distance to the triangle boundary (geometry_utils.cuh:397-408).
+P3D_HD float tri_dist2(f2 p, f2 v0, f2 v1, f2 v2) {
+  const float e01 = seg_dist2(p, v0, v1);
+  const float e02 = seg_dist2(p, v0, v2);
+  const float e12 = seg_dist2(p, v1, v2);
+  return fminf(fminf(e01, e02), e12);
+}
+
+// ---------------------------------------------------------------------------
+// Pixel-independent face setup (what CheckPixelInsideFace recomputes per pixel,
+// rasterize_meshes.cu:138-150).  `reject` collects every test that does not
+// depend on the pixel: zmax < 0, culled back face, zero area, zmin < 1e-8.
+// ---------------------------------------------------------------------------
+struct FaceSetup {
+  float xlo, xhi, ylo, yhi;  // bbox expanded by sqrt(blur_radius)
+  bool reject;
+};
+
+P3D_HD FaceSetup face_setup(f3 v0, f3 v1, f3 v2, float sqrt_blur, bool cull_backfaces) {
+  FaceSetup s;
+  s.xlo = min3(v0.x, v1.x, v2.x) - sqrt_blur;
+  s.ylo = min3(v0.y, v1.y, v2.y) - sqrt_blur;
+  s.xhi = max3(v0.x, v1.x, v2.x) + sqrt_blur;
+  s.yhi = max3(v0.y, v1.y, v2.y) + sqrt_blur;
+  const float zmin = min3(v0.z, v1.z, v2.z);
+  const float zmax = max3(v0.z, v1.z, v2.z);
+  const float area = edge_fn(mk2(v0.x, v0.y), mk2(v1.x, v1.y), mk2(v2.x, v2.y));
+  const bool back_face = area < 0.0f;
+  const bool zero_area = ((double)area <= P3D_KEPS) && ((double)area >= -1.0 * P3D_KEPS);
+  const bool z_invalid = (double)zmin < P3D_KEPS;
+  s.reject = (zmax < 0.0f) || (cull_backfaces && back_face) || zero_area || z_invalid;
+  return s;
+}
+
+// Per-pixel bbox reject (rasterize_meshes.cu:94-97), strict comparisons.
+P3D_HD bool outside_box(const FaceSetup& s, f2 p) { return p.x > s.xhi || p.x < s.xlo || p.y > s.yhi || p.y < s.ylo; }
+
+// Result of testing one pixel against one face.
+struct FaceHit {
+  float z;
+  float dist;  // signed: negative inside
+  f3 bary;     // clipped when clip_barycentric_coords
+};
+
+// The pixel-dependent part of CheckPixelInsideFace (rasterize_meshes.cu:152-177).
+// Returns false when the face does not contribute to this pixel.
+P3D_HD bool face_hit(f3 v0, f3 v1, f3 v2, f2 p, float blur_radius, bool perspective_correct, bool clip_bary,
+                     FaceHit* out) {
+  const f2 a = mk2(v0.x, v0.y);
+  const f2 b = mk2(v1.x, v1.y);
+  const f2 c = mk2(v2.x, v2.y);
+  const f3 bw = bary_coords(p, a, b, c);
+  const f3 bp = perspective_correct ? bary_perspective(bw, v0.z, v1.z, v2.z) : bw;
+  const f3 bc = clip_bary ? bary_clip(bp) : bp;
+  const float pz = bc.x * v0.z + bc.y * v1.z + bc.z * v2.z;
+  if (pz < 0.0f) {
+    return false;
+  }
+  const float dist = tri_dist2(p, a, b, c);
+  const bool inside = bp.x > 0.0f && bp.y > 0.0f && bp.z > 0.0f;
+  if (!inside && dist >= blur_radius) {
+    return false;
+  }
+  out->z = pz;
+  out->dist = inside ? -dist : dist;
+  out->bary = bc;
+  return true;
+}
+
+// ---------------------------------------------------------------------------
+// Backward pieces (geometry_utils.cuh:54-64, 101-161, 200-228, 273-329,
+// 365-385, 421-462).  Gradients are tolerance-gated, the expression order is
+// kept anyway; pow(x, 2.0f) is written x*x.
+// ---------------------------------------------------------------------------
+struct EdgeGrad {
+  f2 dp, da, db;
+};
+
+P3D_HD EdgeGrad edge_fn_bwd(f2 p, f2 a, f2 b, float g) {
+  EdgeGrad r;
+  r.dp = mk2(g * (b.y - a.y), g * (a.x - b.x));
+  r.da = mk2(g * (p.y - b.y), g * (b.x - p.x));
+  r.db = mk2(g * (a.y - p.y), g * (p.x - a.x));
+  return r;
+}
+
+struct TriGrad {
+  f2 d0, d1, d2;
+};
+
+P3D_HD f2 add2(f2 a, f2 b) { return mk2(a.x + b.x, a.y + b.y); }
+
+P3D_HD TriGrad bary_coords_bwd(f2 p, f2 v0, f2 v1, f2 v2, f3 g) {
+  const float area = bary_area(v0, v1, v2);
+  const float area2 = area * area;
+  const float e0 = edge_fn(p, v1, v2);
+  const float e1 = edge_fn(p, v2, v0);
+  const float e2 = edge_fn(p, v0, v1);
+  const float inv_area = 1.0f / area;
+
+  // w0 = e0(p, v1, v2) / area(v2, v0, v1)
+  const EdgeGrad n0 = edge_fn_bwd(p, v1, v2, g.x * inv_area);
+  const EdgeGrad a0 = edge_fn_bwd(v2, v0, v1, g.x * (-e0 / area2));
+  const f2 w0_v0 = a0.da;
+  const f2 w0_v1 = add2(n0.da, a0.db);
+  const f2 w0_v2 = add2(n0.db, a0.dp);
+
+  // w1 = e1(p, v2, v0) / area
+  const EdgeGrad n1 = edge_fn_bwd(p, v2, v0, g.y * inv_area);
+  const EdgeGrad a1 = edge_fn_bwd(v2, v0, v1, g.y * (-e1 / area2));
+  const f2 w1_v0 = add2(n1.db, a1.da);
+  const f2 w1_v1 = a1.db;
+  const f2 w1_v2 = add2(n1.da, a1.dp);
+
+  // w2 = e2(p, v0, v1) / area
+  const EdgeGrad n2 = edge_fn_bwd(p, v0, v1, g.z * inv_area);
+  const EdgeGrad a2 = edge_fn_bwd(v2, v0, v1, g.z * (-e2 / area2));
+  const f2 w2_v0 = add2(n2.da, a2.da);
+  const f2 w2_v1 = add2(n2.db, a2.db);
+  const f2 w2_v2 = a2.dp;
+
+  TriGrad r;
+  r.d0 = add2(add2(w0_v0, w1_v0), w2_v0);
+  r.d1 = add2(add2(w0_v1, w1_v1), w2_v1);
+  r.d2 = add2(add2(w0_v2, w1_v2), w2_v2);
+  return r;
+}
+
+struct PerspGrad {
+  f3 dbary;
+  float dz0, dz1, dz2;
+};
+
+P3D_HD PerspGrad bary_perspective_bwd(f3 b, float z0, float z1, float z2, f3 g) {
+  const float t0 = b.x * z1 * z2;
+  const float t1 = z0 * b.y * z2;
+  const float t2 = z0 * z1 * b.z;
+  const float denom = fmaxf(t0 + t1 + t2, (float)P3D_KEPS);
+  const float gd_top = -t0 * g.x - t1 * g.y - t2 * g.z;
+  const float gd = gd_top / (denom * denom);
+  const float g0 = gd + g.x / denom;
+  const float g1 = gd + g.y / denom;
+  const float g2 = gd + g.z / denom;
+  PerspGrad r;
+  r.dbary = mk3(g0 * z1 * z2, g1 * z0 * z2, g2 * z0 * z1);
+  r.dz0 = g1 * b.y * z2 + g2 * b.z * z1;
+  r.dz1 = g0 * b.x * z2 + g2 * b.z * z0;
+  r.dz2 = g0 * b.x * z1 + g1 * b.y * z0;
+  return r;
+}
+
+P3D_HD f3 bary_clip_bwd(f3 b, f3 g) {
+  const float w0 = b.x > 0.0f ? b.x : 0.0f;
+  const float w1 = b.y > 0.0f ? b.y : 0.0f;
+  const float w2 = b.z > 0.0f ? b.z : 0.0f;
+  float s = w0 + w1 + w2;
+  float live = 1.0f;
+  if ((double)s < 1e-5) {  // reference compares the float sum with a double literal
+    live = 0.0f;
+    s = 1e-5f;
+  }
+  const float m0 = b.x < 0.0f ? 0.0f : 1.0f;
+  const float m1 = b.y < 0.0f ? 0.0f : 1.0f;
+  const float m2 = b.z < 0.0f ? 0.0f : 1.0f;
+  const float s2 = s * s;
+  const float q0 = -w0 / s2 * live;
+  const float q1 = -w1 / s2 * live;
+  const float q2 = -w2 / s2 * live;
+  const float inv = 1.0f / s;
+  return mk3(m0 * (g.x * (inv + q0) + g.y * q1 + g.z * q2), m1 * (g.y * (inv + q1) + g.x * q0 + g.z * q2),
+             m2 * (g.z * (inv + q2) + g.x * q0 + g.y * q1));
+}
+
+struct SegGrad {
+  f2 da, db;
+};
+
+P3D_HD SegGrad seg_dist2_bwd(f2 p, f2 a, f2 b, float g) {
+  const float bax = b.x - a.x;
+  const float bay = b.y - a.y;
+  const float bot = bax * bax + bay * bay;
+  const float top = bax * (p.x - a.x) + bay * (p.y - a.y);
+  const float tt = sat01(top / bot);
+  const float dx = ((1.0f - tt) * a.x + tt * b.x) - p.x;
+  const float dy = ((1.0f - tt) * a.y + tt * b.y) - p.y;
+  const float sa = g * (1.0f - tt) * 2.0f;
+  const float sb = g * tt * 2.0f;
+  SegGrad r;
+  r.da = mk2(sa * dx, sa * dy);
+  r.db = mk2(sb * dx, sb * dy);
+  return r;
+}
+
+// Gradient of tri_dist2 wrt the three vertices: only the closest edge gets one,
+// ties resolved e01, e02, e12 (geometry_utils.cuh:441-459).
+P3D_HD TriGrad tri_dist2_bwd(f2 p, f2 v0, f2 v1, f2 v2, float g) {
+  const float e01 = seg_dist2(p, v0, v1);
+  const float e02 = seg_dist2(p, v0, v2);
+  const float e12 = seg_dist2(p, v1, v2);
+  TriGrad r;
+  r.d0 = mk2(0.0f, 0.0f);
+  r.d1 = mk2(0.0f, 0.0f);
+  r.d2 = mk2(0.0f, 0.0f);
+  if (e01 <= e02 && e01 <= e12) {
+    const SegGrad s = seg_dist2_bwd(p, v0, v1, g);
+    r.d0 = s.da;
+    r.d1 = s.db;
+  } else if (e02 <= e01 && e02 <= e12) {
+    const SegGrad s = seg_dist2_bwd(p, v0, v2, g);
+    r.d0 = s.da;
+    r.d2 = s.db;
+  } else if (e12 <= e01 && e12 <= e02) {
+    const SegGrad s = seg_dist2_bwd(p, v1, v2, g);
+    r.d1 = s.da;
+    r.d2 = s.db;
+  }
+  return r;
+}
+
+// Nine partials of one (pixel, k) sample wrt its face's vertices
+// (rasterize_meshes.cu:486-561).  The CUDA variant feeds the *pre-perspective*
+// barycentrics to the clip backward (rasterize_meshes.cu:528); the CPU variant
+// uses the post-perspective ones (rasterize_meshes_cpu.cpp:499).  We follow
+// CUDA; `clip_bwd_on_corrected` selects the CPU behaviour (used only to pin the
+// oracle against the reference's CPU build).
+struct FaceGrad {
+  float g[9];
+};
+
+P3D_HD FaceGrad face_sample_bwd(f3 v0, f3 v1, f3 v2, f2 p, float g_zbuf, f3 g_bary, float g_dist,
+                                bool perspective_correct, bool clip_bary, bool clip_bwd_on_corrected) {
+  const f2 a = mk2(v0.x, v0.y);
+  const f2 b = mk2(v1.x, v1.y);
+  const f2 c = mk2(v2.x, v2.y);
+  const f3 bw = bary_coords(p, a, b, c);
+  const f3 bp = perspective_correct ? bary_perspective(bw, v0.z, v1.z, v2.z) : bw;
+  const f3 bc = clip_bary ? bary_clip(bp) : bp;
+  const bool inside = bp.x > 0.0f && bp.y > 0.0f && bp.z > 0.0f;
+  const float sign = inside ? -1.0f : 1.0f;
+
+  const TriGrad dd = tri_dist2_bwd(p, a, b, c, sign * g_dist);
+
+  f3 gb = mk3(g_bary.x + g_zbuf * v0.z, g_bary.y + g_zbuf * v1.z, g_bary.z + g_zbuf * v2.z);
+  if (clip_bary) {
+    gb = bary_clip_bwd(clip_bwd_on_corrected ? bp : bw, gb);
+  }
+  float dz0 = 0.0f, dz1 = 0.0f, dz2 = 0.0f;
+  if (perspective_correct) {
+    const PerspGrad pg = bary_perspective_bwd(bw, v0.z, v1.z, v2.z, gb);
+    gb = pg.dbary;
+    dz0 = pg.dz0;
+    dz1 = pg.dz1;
+    dz2 = pg.dz2;
+  }
+  const TriGrad db = bary_coords_bwd(p, a, b, c, gb);
+
+  FaceGrad r;
+  r.g[0] = db.d0.x + dd.d0.x;
+  r.g[1] = db.d0.y + dd.d0.y;
+  r.g[2] = g_zbuf * bc.x + dz0;
+  r.g[3] = db.d1.x + dd.d1.x;
+  r.g[4] = db.d1.y + dd.d1.y;
+  r.g[5] = g_zbuf * bc.y + dz1;
+  r.g[6] = db.d2.x + dd.d2.x;
+  r.g[7] = db.d2.y + dd.d2.y;
+  r.g[8] = g_zbuf * bc.z + dz2;
+  return r;
+}
+
+}  // namespace p3d

@@ -1,0 +1,546 @@
+// raster_mesh.hip -- mesh rasterization for gfx950: fine / naive forward and SoftRas backward.
+//
+// Forward (replaces RasterizeMeshesFineCudaKernel and RasterizeMeshesNaiveCudaKernel,
+// pytorch3d/csrc/rasterize_meshes/rasterize_meshes.cu:245-334, 630-736):
+//   * one 256-thread workgroup per 16x16-pixel tile of one bin; the four waves own the four
+//     8x8 sub-tiles, one pixel per lane;
+//   * the bin's face list is streamed through LDS 256 faces at a time.  While staging, each
+//     thread does the pixel-independent part of CheckPixelInsideFace ONCE per face (blur-expanded
+//     bbox, zmax < 0, back-face, zero area, zmin < eps -- the reference redoes it per pixel) and
+//     drops faces that cannot touch the tile; survivors are compacted in order (ballot + mbcnt);
+//   * each wave then culls the staged faces against its own 8x8 sub-tile 64 faces at a time
+//     (one lane per face, conflict-free LDS reads), and only the surviving faces are evaluated
+//     per pixel, their vertex records read as LDS broadcasts;
+//   * the per-pixel queue lives in VGPRs (topk.h); every output element, -1 padding included, is
+//     written exactly once by the kernel, a pixel's K values as 16-byte stores.
+// The naive operator is the same kernel with "the bin" being the whole image and "the list"
+// being the mesh's face range, so naive and binned results are identical by construction.
+//
+// Backward (replaces RasterizeMeshesBackwardCudaKernel, rasterize_meshes.cu:433-564): one
+// thread per pixel, per-sample recompute through p3d_geom.h, hardware f32 atomics.
+#include "binning.h"
+#include "p3d_geom.h"
+#include "topk.h"
+
+namespace p3d {
+
+namespace {
+
+constexpr int kTile = 16;       // pixels per tile side (4 waves x 8x8)
+constexpr int kStage = 256;     // faces staged per round = threads per workgroup
+constexpr int kMeshPayload = 4; // dist, bary.x, bary.y, bary.z
+
+struct MeshArgs {
+  const float* face_verts;
+  const int64_t* neighbor;
+  const int64_t* mesh_first;
+  const int64_t* mesh_count;
+  BinCSR csr;
+  int N, H, W, K;
+  int bin_size, BH, BW, Ty, Tx;
+  long long total_tiles;
+  long long tiles_per_xcd;
+  float blur, sqrt_blur;
+  int persp, clip, cull;
+  int64_t* p2f;
+  float* zbuf;
+  float* bary;
+  float* dists;
+};
+
+template <int KT>
+__device__ __forceinline__ void store_row(float* dst, const float (&v)[KT]) {
+  if constexpr (KT % 4 == 0) {
+#pragma unroll
+    for (int k = 0; k < KT; k += 4) {
+      float4 t;
+      t.x = v[k];
+      t.y = v[k + 1];
+      t.z = v[k + 2];
+      t.w = v[k + 3];
+      *reinterpret_cast<float4*>(dst + k) = t;
+    }
+  } else if constexpr (KT == 2) {
+    float2 t;
+    t.x = v[0];
+    t.y = v[1];
+    *reinterpret_cast<float2*>(dst) = t;
+  } else {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) dst[k] = v[k];
+  }
+}
+
+template <typename Queue, int KT, bool IN_REGS>
+__device__ __forceinline__ void write_pixel(const MeshArgs& a, const Queue& q, int64_t opix) {
+  const int K = a.K;
+  const int64_t base = opix * K;
+  if constexpr (IN_REGS) {
+    if (K == KT) {
+      // exact-capacity fast path: 16-byte stores
+      float zv[KT], dv[KT], bv[3 * KT];
+      long long iv[KT];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        const bool ok = q.valid(k);
+        iv[k] = ok ? (long long)q.idx[k] : -1ll;
+        zv[k] = ok ? q.z[k] : -1.0f;
+        dv[k] = ok ? q.pl[0][k] : -1.0f;
+        bv[3 * k + 0] = ok ? q.pl[1][k] : -1.0f;
+        bv[3 * k + 1] = ok ? q.pl[2][k] : -1.0f;
+        bv[3 * k + 2] = ok ? q.pl[3][k] : -1.0f;
+      }
+      store_row<KT>(a.zbuf + base, zv);
+      store_row<KT>(a.dists + base, dv);
+      if constexpr (KT % 4 == 0) {
+        float* bp = a.bary + base * 3;
+#pragma unroll
+        for (int k = 0; k < 3 * KT; k += 4) {
+          float4 t;
+          t.x = bv[k];
+          t.y = bv[k + 1];
+          t.z = bv[k + 2];
+          t.w = bv[k + 3];
+          *reinterpret_cast<float4*>(bp + k) = t;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 3 * KT; ++k) a.bary[base * 3 + k] = bv[k];
+      }
+      if constexpr (KT % 2 == 0) {
+        long long* ip = reinterpret_cast<long long*>(a.p2f + base);
+#pragma unroll
+        for (int k = 0; k < KT; k += 2) {
+          longlong2 t;
+          t.x = iv[k];
+          t.y = iv[k + 1];
+          *reinterpret_cast<longlong2*>(ip + k) = t;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < KT; ++k) a.p2f[base + k] = iv[k];
+      }
+      return;
+    }
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      if (k < K) {
+        const bool ok = q.valid(k);
+        a.p2f[base + k] = ok ? (int64_t)q.idx[k] : (int64_t)-1;
+        a.zbuf[base + k] = ok ? q.z[k] : -1.0f;
+        a.dists[base + k] = ok ? q.pl[0][k] : -1.0f;
+        a.bary[(base + k) * 3 + 0] = ok ? q.pl[1][k] : -1.0f;
+        a.bary[(base + k) * 3 + 1] = ok ? q.pl[2][k] : -1.0f;
+        a.bary[(base + k) * 3 + 2] = ok ? q.pl[3][k] : -1.0f;
+      }
+    }
+  } else {
+    for (int k = 0; k < K; ++k) {
+      const bool ok = q.valid(k);
+      a.p2f[base + k] = ok ? (int64_t)q.idx[k] : (int64_t)-1;
+      a.zbuf[base + k] = ok ? q.z[k] : -1.0f;
+      a.dists[base + k] = ok ? q.pl[0][k] : -1.0f;
+      a.bary[(base + k) * 3 + 0] = ok ? q.pl[1][k] : -1.0f;
+      a.bary[(base + k) * 3 + 1] = ok ? q.pl[2][k] : -1.0f;
+      a.bary[(base + k) * 3 + 2] = ok ? q.pl[3][k] : -1.0f;
+    }
+  }
+}
+
+template <typename Queue, int KT, bool IN_REGS, bool BINNED>
+__global__ __launch_bounds__(kStage) void mesh_raster_kernel(MeshArgs a) {
+  __shared__ float4 s_box[kStage];       // xlo, xhi, ylo, yhi (blur-expanded)
+  __shared__ float4 s_vert[kStage][3];   // v0x v0y v0z v1x | v1y v1z v2x v2y | v2z idx nb -
+  __shared__ int s_wcnt[kStage / kWave];
+
+  // XCD-aware tile order: consecutive logical tiles (which share a bin's face list) run on the
+  // same XCD and hit the same L2 (workgroup b is dispatched to XCD b % 8).
+  const long long lt = (long long)(blockIdx.x % 8) * a.tiles_per_xcd + (long long)(blockIdx.x / 8);
+  if (lt >= a.total_tiles) return;
+  long long t = lt;
+  const int tx = (int)(t % a.Tx);
+  t /= a.Tx;
+  const int ty = (int)(t % a.Ty);
+  t /= a.Ty;
+  const int bx = (int)(t % a.BW);
+  t /= a.BW;
+  const int by = (int)(t % a.BH);
+  const int n = (int)(t / a.BH);
+
+  const int H = a.H, W = a.W;
+  const int y_end = min(H, (by + 1) * a.bin_size);
+  const int x_end = min(W, (bx + 1) * a.bin_size);
+  const int ty0 = by * a.bin_size + ty * kTile;
+  const int tx0 = bx * a.bin_size + tx * kTile;
+  if (ty0 >= y_end || tx0 >= x_end) return;  // tile has no pixel (uniform)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = tid >> 6;
+  const int sy0 = ty0 + (w >> 1) * 8;
+  const int sx0 = tx0 + (w & 1) * 8;
+  const int yi = sy0 + (lane >> 3);
+  const int xi = sx0 + (lane & 7);
+  const bool pix_ok = yi < y_end && xi < x_end;
+  const bool wave_ok = sy0 < y_end && sx0 < x_end;
+  const f2 p = mk2(pix_to_ndc(xi, W, H), pix_to_ndc(yi, H, W));
+
+  // pixel-centre extents (pix_to_ndc is monotone in the pixel index)
+  const float tile_x0 = pix_to_ndc(tx0, W, H), tile_x1 = pix_to_ndc(min(tx0 + kTile, x_end) - 1, W, H);
+  const float tile_y0 = pix_to_ndc(ty0, H, W), tile_y1 = pix_to_ndc(min(ty0 + kTile, y_end) - 1, H, W);
+  const float sub_x0 = pix_to_ndc(sx0, W, H), sub_x1 = pix_to_ndc(min(sx0 + 8, x_end) - 1, W, H);
+  const float sub_y0 = pix_to_ndc(sy0, H, W), sub_y1 = pix_to_ndc(min(sy0 + 8, y_end) - 1, H, W);
+
+  int64_t src_base;
+  int count;
+  if (BINNED) {
+    const int64_t row = ((int64_t)n * a.BH + by) * a.BW + bx;
+    src_base = a.csr.offset[row];
+    count = a.csr.total[row];
+  } else {
+    src_base = a.mesh_first[n];
+    count = (int)a.mesh_count[n];
+  }
+
+  Queue q;
+  q.init();
+  const int K = a.K;
+  const bool persp = a.persp != 0, clip = a.clip != 0, cull = a.cull != 0;
+
+  for (int base = 0; base < count; base += kStage) {
+    // ---- stage: per-face setup, tile cull, ordered compaction into LDS -------------------
+    const int i = base + tid;
+    bool keep = false;
+    f3 v0, v1, v2;
+    FaceSetup fs;
+    int fid = -1;
+    if (i < count) {
+      fid = BINNED ? a.csr.list[src_base + i] : (int)(src_base + i);
+      const float* g = a.face_verts + (int64_t)fid * 9;
+      v0 = mk3(g[0], g[1], g[2]);
+      v1 = mk3(g[3], g[4], g[5]);
+      v2 = mk3(g[6], g[7], g[8]);
+      fs = face_setup(v0, v1, v2, a.sqrt_blur, cull);
+      const bool off_tile = tile_x0 > fs.xhi || tile_x1 < fs.xlo || tile_y0 > fs.yhi || tile_y1 < fs.ylo;
+      keep = !fs.reject && !off_tile;
+    }
+    const unsigned long long km = __ballot(keep);
+    if (lane == 0) s_wcnt[w] = __popcll(km);
+    __syncthreads();
+    int pos = mask_rank(km);
+    int staged = 0;
+#pragma unroll
+    for (int j = 0; j < kStage / kWave; ++j) {
+      const int c = s_wcnt[j];
+      if (j < w) pos += c;
+      staged += c;
+    }
+    if (keep) {
+      const int nb = (int)a.neighbor[fid];
+      s_box[pos] = make_float4(fs.xlo, fs.xhi, fs.ylo, fs.yhi);
+      s_vert[pos][0] = make_float4(v0.x, v0.y, v0.z, v1.x);
+      s_vert[pos][1] = make_float4(v1.y, v1.z, v2.x, v2.y);
+      s_vert[pos][2] = make_float4(v2.z, __int_as_float(fid), __int_as_float(nb), 0.0f);
+    }
+    __syncthreads();
+
+    // ---- per wave: sub-tile cull 64 faces at a time, then per-pixel evaluation -----------
+    if (wave_ok) {
+      for (int jb = 0; jb < staged; jb += kWave) {
+        const int j = jb + lane;
+        bool touch = false;
+        if (j < staged) {
+          const float4 b = s_box[j];
+          touch = !(sub_x0 > b.y || sub_x1 < b.x || sub_y0 > b.w || sub_y1 < b.z);
+        }
+        unsigned long long cand = __ballot(touch);
+        while (cand) {
+          const int jj = jb + __builtin_ctzll(cand);
+          cand &= cand - 1;
+          const float4 b = s_box[jj];
+          const bool out = p.x > b.y || p.x < b.x || p.y > b.w || p.y < b.z;
+          if (pix_ok && !out) {
+            const float4 r0 = s_vert[jj][0], r1 = s_vert[jj][1], r2 = s_vert[jj][2];
+            const f3 a0 = mk3(r0.x, r0.y, r0.z);
+            const f3 a1 = mk3(r0.w, r1.x, r1.y);
+            const f3 a2 = mk3(r1.z, r1.w, r2.x);
+            FaceHit h;
+            if (face_hit(a0, a1, a2, p, a.blur, persp, clip, &h)) {
+              const int f = __float_as_int(r2.y);
+              const int nb = __float_as_int(r2.z);
+              const float pl[kMeshPayload] = {h.dist, h.bary.x, h.bary.y, h.bary.z};
+              if (nb != -1) {
+                // clipped-face neighbour rule (rasterize_meshes.cu:186-215,
+                // rasterize_meshes_cpu.cpp:249-277): at most one of the two halves of a split
+                // face stays in the queue -- the one closer to the pixel.
+                const int at = q.find(nb);
+                if (at >= 0) {
+                  if (fabsf(h.dist) < fabsf(q.payload_at(0, at))) {
+                    q.erase(at);
+                    q.insert(K, h.z, f, pl);
+                  }
+                } else {
+                  q.insert(K, h.z, f, pl);
+                }
+              } else {
+                q.insert(K, h.z, f, pl);
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (pix_ok) {
+    const int64_t opix = ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi);
+    write_pixel<Queue, KT, IN_REGS>(a, q, opix);
+  }
+}
+
+template <bool BINNED>
+int launch_mesh_raster(const MeshArgs& a, hipStream_t stream) {
+  const unsigned grid = (unsigned)(a.tiles_per_xcd * 8);
+  const char* name = BINNED ? "mesh_fine" : "mesh_naive";
+  LaunchScope ls(name, stream);
+  const int K = a.K;
+  if (K == 1)
+    mesh_raster_kernel<TopKReg<1, kMeshPayload>, 1, true, BINNED><<<grid, kStage, 0, stream>>>(a);
+  else if (K == 2)
+    mesh_raster_kernel<TopKReg<2, kMeshPayload>, 2, true, BINNED><<<grid, kStage, 0, stream>>>(a);
+  else if (K <= 4)
+    mesh_raster_kernel<TopKReg<4, kMeshPayload>, 4, true, BINNED><<<grid, kStage, 0, stream>>>(a);
+  else if (K <= 8)
+    mesh_raster_kernel<TopKReg<8, kMeshPayload>, 8, true, BINNED><<<grid, kStage, 0, stream>>>(a);
+  else
+    mesh_raster_kernel<TopKMem<P3D_MAX_K, kMeshPayload>, P3D_MAX_K, false, BINNED><<<grid, kStage, 0, stream>>>(a);
+  return launch_status();
+}
+
+void set_tiles(MeshArgs* a, int bin_size, int BH, int BW) {
+  a->bin_size = bin_size;
+  a->BH = BH;
+  a->BW = BW;
+  const int span_y = bin_size < a->H ? bin_size : a->H;
+  const int span_x = bin_size < a->W ? bin_size : a->W;
+  a->Ty = (int)ceil_div(span_y, kTile);
+  a->Tx = (int)ceil_div(span_x, kTile);
+  a->total_tiles = (long long)a->N * BH * BW * a->Ty * a->Tx;
+  a->tiles_per_xcd = ceil_div(a->total_tiles, 8);
+}
+
+// ---------------------------------------------------------------------------------------
+// Backward.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mesh_backward_kernel(const float* __restrict__ face_verts,
+                                                            const int64_t* __restrict__ p2f,
+                                                            const float* __restrict__ grad_zbuf,
+                                                            const float* __restrict__ grad_bary,
+                                                            const float* __restrict__ grad_dists, int N, int H, int W,
+                                                            int K, int persp, int clip, float* __restrict__ grad_fv) {
+  const int64_t npix = (int64_t)N * H * W;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < npix; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = t % ((int64_t)H * W);
+    const int yo = (int)(pix / W), xo = (int)(pix % W);
+    const int yi = H - 1 - yo, xi = W - 1 - xo;  // rasterize_meshes.cu:458-462
+    const f2 p = mk2(pix_to_ndc(xi, W, H), pix_to_ndc(yi, H, W));
+    for (int k = 0; k < K; ++k) {
+      const int64_t i = t * K + k;
+      const int64_t f = p2f[i];
+      if (f < 0) continue;
+      const float* g = face_verts + f * 9;
+      const f3 v0 = mk3(g[0], g[1], g[2]);
+      const f3 v1 = mk3(g[3], g[4], g[5]);
+      const f3 v2 = mk3(g[6], g[7], g[8]);
+      const f3 gb = mk3(grad_bary[i * 3 + 0], grad_bary[i * 3 + 1], grad_bary[i * 3 + 2]);
+      const FaceGrad r = face_sample_bwd(v0, v1, v2, p, grad_zbuf[i], gb, grad_dists[i], persp != 0, clip != 0, false);
+      float* o = grad_fv + f * 9;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) unsafeAtomicAdd(o + j, r.g[j]);
+    }
+  }
+}
+
+int check_common(int N, int H, int W, int K) {
+  if (N < 0 || H < 0 || W < 0 || K < 0) return P3D_ERR_INVALID_ARG;
+  if (K > P3D_MAX_K) return P3D_ERR_K_TOO_LARGE;
+  return P3D_OK;
+}
+
+}  // namespace
+
+}  // namespace p3d
+
+using namespace p3d;
+
+P3D_API size_t p3d_rasterize_meshes_workspace_bytes(int64_t F, int N, int H, int W, int bin_size,
+                                                    int max_faces_per_bin) {
+  if (bin_size <= 0 || max_faces_per_bin <= 0 || N <= 0 || H <= 0 || W <= 0) return 0;
+  const BinGeom g = make_geom(H, W, bin_size);
+  return bin_workspace_bytes(F, N, g, max_faces_per_bin) + 256;
+}
+
+P3D_API size_t p3d_rasterize_fine_workspace_bytes(int N, int BH, int BW, int M) {
+  const size_t rows = (size_t)N * BH * BW;
+  return align_up(rows * (size_t)M * sizeof(int), 256) + align_up(rows * sizeof(int), 256) +
+         align_up((rows + 1) * sizeof(int64_t), 256) + 256;
+}
+
+P3D_API int p3d_rasterize_meshes_naive(const float* face_verts, const int64_t* mesh_first, const int64_t* mesh_count,
+                                       const int64_t* neighbor, int64_t F, int N, int H, int W, float blur_radius, int K,
+                                       int persp, int clip, int cull, int64_t* p2f, float* zbuf, float* bary,
+                                       float* dists, p3d_stream_t stream) {
+  (void)F;
+  const int rc = check_common(N, H, W, K);
+  if (rc != P3D_OK) return rc;
+  if ((int64_t)N * H * W * K == 0) return P3D_OK;
+  if (!face_verts && F > 0) return P3D_ERR_INVALID_ARG;
+  if (!mesh_first || !mesh_count || !neighbor || !p2f || !zbuf || !bary || !dists) return P3D_ERR_INVALID_ARG;
+  MeshArgs a{};
+  a.face_verts = face_verts;
+  a.neighbor = neighbor;
+  a.mesh_first = mesh_first;
+  a.mesh_count = mesh_count;
+  a.N = N;
+  a.H = H;
+  a.W = W;
+  a.K = K;
+  a.blur = blur_radius;
+  a.sqrt_blur = sqrtf(blur_radius);
+  a.persp = persp;
+  a.clip = clip;
+  a.cull = cull;
+  a.p2f = p2f;
+  a.zbuf = zbuf;
+  a.bary = bary;
+  a.dists = dists;
+  set_tiles(&a, H > W ? H : W, 1, 1);
+  return launch_mesh_raster<false>(a, (hipStream_t)stream);
+}
+
+static int mesh_fine_from_csr(const float* face_verts, const int64_t* neighbor, const BinCSR& csr, int N, int H, int W,
+                              const BinGeom& g, float blur_radius, int K, int persp, int clip, int cull, int64_t* p2f,
+                              float* zbuf, float* bary, float* dists, hipStream_t stream) {
+  MeshArgs a{};
+  a.face_verts = face_verts;
+  a.neighbor = neighbor;
+  a.csr = csr;
+  a.N = N;
+  a.H = H;
+  a.W = W;
+  a.K = K;
+  a.blur = blur_radius;
+  a.sqrt_blur = sqrtf(blur_radius);
+  a.persp = persp;
+  a.clip = clip;
+  a.cull = cull;
+  a.p2f = p2f;
+  a.zbuf = zbuf;
+  a.bary = bary;
+  a.dists = dists;
+  set_tiles(&a, g.bin_size, g.BH, g.BW);
+  return launch_mesh_raster<true>(a, stream);
+}
+
+P3D_API int p3d_rasterize_meshes(const float* face_verts, const int64_t* mesh_first, const int64_t* mesh_count,
+                                 const int64_t* neighbor, int64_t F, int N, int H, int W, float blur_radius, int K,
+                                 int bin_size, int max_faces_per_bin, int persp, int clip, int cull, int64_t* p2f,
+                                 float* zbuf, float* bary, float* dists, void* workspace, size_t workspace_bytes,
+                                 p3d_stream_t stream) {
+  if (bin_size <= 0 || max_faces_per_bin <= 0) {
+    return p3d_rasterize_meshes_naive(face_verts, mesh_first, mesh_count, neighbor, F, N, H, W, blur_radius, K, persp,
+                                      clip, cull, p2f, zbuf, bary, dists, stream);
+  }
+  const int rc = check_common(N, H, W, K);
+  if (rc != P3D_OK) return rc;
+  if ((int64_t)N * H * W * K == 0) return P3D_OK;
+  if (!face_verts && F > 0) return P3D_ERR_INVALID_ARG;
+  if (!mesh_first || !mesh_count || !neighbor || !p2f || !zbuf || !bary || !dists) return P3D_ERR_INVALID_ARG;
+  const BinGeom g = make_geom(H, W, bin_size);
+  if (g.BH > P3D_MAX_BINS_PER_SIDE || g.BW > P3D_MAX_BINS_PER_SIDE) return P3D_ERR_TOO_MANY_BINS;
+  Arena arena(workspace, workspace_bytes);
+  BinWorkspace ws;
+  if (!workspace || !bin_carve(arena, F, N, g, max_faces_per_bin, &ws)) return P3D_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  int st = bin_build(kTriangles, face_verts, nullptr, mesh_first, mesh_count, F, N, g, max_faces_per_bin,
+                     sqrtf(blur_radius), ws, s);
+  if (st != P3D_OK) return st;
+  BinCSR csr{ws.offset, ws.total, ws.list};
+  return mesh_fine_from_csr(face_verts, neighbor, csr, N, H, W, g, blur_radius, K, persp, clip, cull, p2f, zbuf, bary,
+                            dists, s);
+}
+
+P3D_API int p3d_rasterize_meshes_coarse(const float* face_verts, const int64_t* mesh_first, const int64_t* mesh_count,
+                                        int64_t F, int N, int H, int W, float blur_radius, int bin_size,
+                                        int max_faces_per_bin, int32_t* bin_faces, void* workspace,
+                                        size_t workspace_bytes, p3d_stream_t stream) {
+  if (N < 0 || H <= 0 || W <= 0 || bin_size <= 0 || max_faces_per_bin < 0) return P3D_ERR_INVALID_ARG;
+  const BinGeom g = make_geom(H, W, bin_size);
+  if (g.BH > P3D_MAX_BINS_PER_SIDE || g.BW > P3D_MAX_BINS_PER_SIDE) return P3D_ERR_TOO_MANY_BINS;
+  if ((int64_t)N * g.nbins * max_faces_per_bin == 0) return P3D_OK;
+  if (!mesh_first || !mesh_count || !bin_faces || (!face_verts && F > 0)) return P3D_ERR_INVALID_ARG;
+  Arena arena(workspace, workspace_bytes);
+  BinWorkspace ws;
+  if (!workspace || !bin_carve(arena, F, N, g, max_faces_per_bin, &ws)) return P3D_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  int st = bin_build(kTriangles, face_verts, nullptr, mesh_first, mesh_count, F, N, g, max_faces_per_bin,
+                     sqrtf(blur_radius), ws, s);
+  if (st != P3D_OK) return st;
+  return bin_expand_padded(ws, N, g, max_faces_per_bin, bin_faces, s);
+}
+
+P3D_API int p3d_rasterize_meshes_fine(const float* face_verts, const int32_t* bin_faces, const int64_t* neighbor,
+                                      int64_t F, int N, int BH, int BW, int M, int H, int W, float blur_radius,
+                                      int bin_size, int K, int persp, int clip, int cull, int64_t* p2f, float* zbuf,
+                                      float* bary, float* dists, void* workspace, size_t workspace_bytes,
+                                      p3d_stream_t stream) {
+  const int rc = check_common(N, H, W, K);
+  if (rc != P3D_OK) return rc;
+  if ((int64_t)N * H * W * K == 0) return P3D_OK;
+  if (bin_size <= 0 || BH <= 0 || BW <= 0 || M < 0) return P3D_ERR_INVALID_ARG;
+  if ((!face_verts && F > 0) || !neighbor || !p2f || !zbuf || !bary || !dists) return P3D_ERR_INVALID_ARG;
+  if (BH > P3D_MAX_BINS_PER_SIDE || BW > P3D_MAX_BINS_PER_SIDE) return P3D_ERR_TOO_MANY_BINS;
+  // the bins handed in must tile the image the way the coarse stage would have
+  if ((int64_t)BH * bin_size < H || (int64_t)BW * bin_size < W) return P3D_ERR_INVALID_ARG;
+  if (workspace_bytes < p3d_rasterize_fine_workspace_bytes(N, BH, BW, M) || !workspace) return P3D_ERR_WORKSPACE;
+  if (M > 0 && !bin_faces) return P3D_ERR_INVALID_ARG;
+  const int64_t rows = (int64_t)N * BH * BW;
+  Arena arena(workspace, workspace_bytes);
+  int* list = arena.take<int>((size_t)rows * M);
+  int* total = arena.take<int>((size_t)rows);
+  int64_t* offset = arena.take<int64_t>((size_t)rows + 1);
+  hipStream_t s = (hipStream_t)stream;
+  int st = bin_compact_padded(bin_faces, rows, M, list, total, offset, s);
+  if (st != P3D_OK) return st;
+  BinGeom g;
+  g.H = H;
+  g.W = W;
+  g.bin_size = bin_size;
+  g.BH = BH;
+  g.BW = BW;
+  g.nbins = BH * BW;
+  BinCSR csr{offset, total, list};
+  return mesh_fine_from_csr(face_verts, neighbor, csr, N, H, W, g, blur_radius, K, persp, clip, cull, p2f, zbuf, bary,
+                            dists, s);
+}
+
+P3D_API int p3d_rasterize_meshes_backward(const float* face_verts, const int64_t* p2f, const float* grad_zbuf,
+                                          const float* grad_bary, const float* grad_dists, int64_t F, int N, int H,
+                                          int W, int K, int persp, int clip, float* grad_face_verts,
+                                          p3d_stream_t stream) {
+  if (F < 0 || N < 0 || H < 0 || W < 0 || K < 0) return P3D_ERR_INVALID_ARG;
+  if (F == 0) return P3D_OK;
+  if (!grad_face_verts || !face_verts) return P3D_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(grad_face_verts, 0, (size_t)F * 9 * sizeof(float), s) != hipSuccess) return P3D_ERR_LAUNCH;
+  const int64_t npix = (int64_t)N * H * W;
+  if (npix * K == 0) return P3D_OK;
+  if (!p2f || !grad_zbuf || !grad_bary || !grad_dists) return P3D_ERR_INVALID_ARG;
+  int64_t blocks = ceil_div(npix, 256);
+  if (blocks > 65536) blocks = 65536;
+  LaunchScope ls("mesh_backward", s);
+  mesh_backward_kernel<<<(unsigned)blocks, 256, 0, s>>>(face_verts, p2f, grad_zbuf, grad_bary, grad_dists, N, H, W, K,
+                                                       persp, clip, grad_face_verts);
+  return launch_status();
+}

@@ -1,0 +1,372 @@
+// raster_points.hip -- point-cloud rasterization for gfx950: fine / naive forward, backward.
+//
+// Replaces RasterizePointsNaiveCudaKernel, RasterizePointsFineCudaKernel and
+// RasterizePointsBackwardCudaKernel (pytorch3d/csrc/rasterize_points/rasterize_points.cu:87-149,
+// 223-298, 366-411).  Same tile / stage / sub-tile-cull structure as raster_mesh.hip: a workgroup
+// owns a 16x16 tile of one bin, streams the bin's points through LDS 256 at a time (dropping
+// z < 0 and points whose x+-r, y+-r box misses the tile), each wave culls against its 8x8
+// sub-tile with one lane per point, and the survivors are tested per pixel:
+// accept iff dist2 = dx*dx + dy*dy < r*r (rasterize_points.cu:55-60).  Queue order is
+// (z, point index) -- the CPU variant's tuple order (rasterize_points_cpu.cpp:55-75); the CUDA
+// variant compares z only and leaves ties to the (unspecified) bin order.
+#include "binning.h"
+#include "p3d_geom.h"
+#include "topk.h"
+
+namespace p3d {
+
+namespace {
+
+constexpr int kTile = 16;
+constexpr int kStage = 256;
+
+struct PointArgs {
+  const float* points;
+  const float* radius;
+  const int64_t* first;
+  const int64_t* count;
+  BinCSR csr;
+  int N, H, W, K;
+  int bin_size, BH, BW, Ty, Tx;
+  long long total_tiles;
+  long long tiles_per_xcd;
+  int32_t* idxs;
+  float* zbuf;
+  float* dists;
+};
+
+template <typename Queue, int KT, bool IN_REGS, bool BINNED>
+__global__ __launch_bounds__(kStage) void point_raster_kernel(PointArgs a) {
+  __shared__ float4 s_box[kStage];  // x-r, x+r, y-r, y+r
+  __shared__ float4 s_pt[kStage];   // x, y, z, r*r
+  __shared__ int s_idx[kStage];
+  __shared__ int s_wcnt[kStage / kWave];
+
+  const long long lt = (long long)(blockIdx.x % 8) * a.tiles_per_xcd + (long long)(blockIdx.x / 8);
+  if (lt >= a.total_tiles) return;
+  long long t = lt;
+  const int tx = (int)(t % a.Tx);
+  t /= a.Tx;
+  const int ty = (int)(t % a.Ty);
+  t /= a.Ty;
+  const int bx = (int)(t % a.BW);
+  t /= a.BW;
+  const int by = (int)(t % a.BH);
+  const int n = (int)(t / a.BH);
+
+  const int H = a.H, W = a.W;
+  const int y_end = min(H, (by + 1) * a.bin_size);
+  const int x_end = min(W, (bx + 1) * a.bin_size);
+  const int ty0 = by * a.bin_size + ty * kTile;
+  const int tx0 = bx * a.bin_size + tx * kTile;
+  if (ty0 >= y_end || tx0 >= x_end) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = tid >> 6;
+  const int sy0 = ty0 + (w >> 1) * 8;
+  const int sx0 = tx0 + (w & 1) * 8;
+  const int yi = sy0 + (lane >> 3);
+  const int xi = sx0 + (lane & 7);
+  const bool pix_ok = yi < y_end && xi < x_end;
+  const bool wave_ok = sy0 < y_end && sx0 < x_end;
+  const float xf = pix_to_ndc(xi, W, H);
+  const float yf = pix_to_ndc(yi, H, W);
+
+  const float tile_x0 = pix_to_ndc(tx0, W, H), tile_x1 = pix_to_ndc(min(tx0 + kTile, x_end) - 1, W, H);
+  const float tile_y0 = pix_to_ndc(ty0, H, W), tile_y1 = pix_to_ndc(min(ty0 + kTile, y_end) - 1, H, W);
+  const float sub_x0 = pix_to_ndc(sx0, W, H), sub_x1 = pix_to_ndc(min(sx0 + 8, x_end) - 1, W, H);
+  const float sub_y0 = pix_to_ndc(sy0, H, W), sub_y1 = pix_to_ndc(min(sy0 + 8, y_end) - 1, H, W);
+
+  int64_t src_base;
+  int count;
+  if (BINNED) {
+    const int64_t row = ((int64_t)n * a.BH + by) * a.BW + bx;
+    src_base = a.csr.offset[row];
+    count = a.csr.total[row];
+  } else {
+    src_base = a.first[n];
+    count = (int)a.count[n];
+  }
+
+  Queue q;
+  q.init();
+  const int K = a.K;
+
+  for (int base = 0; base < count; base += kStage) {
+    const int i = base + tid;
+    bool keep = false;
+    float px = 0.f, py = 0.f, pz = 0.f, r = 0.f;
+    int pid = -1;
+    if (i < count) {
+      pid = BINNED ? a.csr.list[src_base + i] : (int)(src_base + i);
+      const float* g = a.points + (int64_t)pid * 3;
+      px = g[0];
+      py = g[1];
+      pz = g[2];
+      r = a.radius[pid];
+      // a pixel with dist2 < r*r lies inside [x-r, x+r] x [y-r, y+r], so this cull is exact
+      const bool off_tile = tile_x0 > px + r || tile_x1 < px - r || tile_y0 > py + r || tile_y1 < py - r;
+      keep = !(pz < 0.0f) && !off_tile;
+    }
+    const unsigned long long km = __ballot(keep);
+    if (lane == 0) s_wcnt[w] = __popcll(km);
+    __syncthreads();
+    int pos = mask_rank(km);
+    int staged = 0;
+#pragma unroll
+    for (int j = 0; j < kStage / kWave; ++j) {
+      const int c = s_wcnt[j];
+      if (j < w) pos += c;
+      staged += c;
+    }
+    if (keep) {
+      s_box[pos] = make_float4(px - r, px + r, py - r, py + r);
+      s_pt[pos] = make_float4(px, py, pz, r * r);
+      s_idx[pos] = pid;
+    }
+    __syncthreads();
+
+    if (wave_ok) {
+      for (int jb = 0; jb < staged; jb += kWave) {
+        const int j = jb + lane;
+        bool touch = false;
+        if (j < staged) {
+          const float4 b = s_box[j];
+          touch = !(sub_x0 > b.y || sub_x1 < b.x || sub_y0 > b.w || sub_y1 < b.z);
+        }
+        unsigned long long cand = __ballot(touch);
+        while (cand) {
+          const int jj = jb + __builtin_ctzll(cand);
+          cand &= cand - 1;
+          const float4 pt = s_pt[jj];
+          const float dx = xf - pt.x;
+          const float dy = yf - pt.y;
+          const float dist2 = dx * dx + dy * dy;
+          if (pix_ok && dist2 < pt.w) {
+            const int id = s_idx[jj];
+            if (q.admits(K, pt.z, id)) {
+              const float pl[1] = {dist2};
+              q.insert(K, pt.z, id, pl);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (pix_ok) {
+    const int64_t base = (((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi)) * K;
+    if constexpr (IN_REGS) {
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        if (k < K) {
+          const bool ok = q.valid(k);
+          a.idxs[base + k] = ok ? q.idx[k] : -1;
+          a.zbuf[base + k] = ok ? q.z[k] : -1.0f;
+          a.dists[base + k] = ok ? q.pl[0][k] : -1.0f;
+        }
+      }
+    } else {
+      for (int k = 0; k < K; ++k) {
+        const bool ok = q.valid(k);
+        a.idxs[base + k] = ok ? q.idx[k] : -1;
+        a.zbuf[base + k] = ok ? q.z[k] : -1.0f;
+        a.dists[base + k] = ok ? q.pl[0][k] : -1.0f;
+      }
+    }
+  }
+}
+
+template <bool BINNED>
+int launch_point_raster(const PointArgs& a, hipStream_t stream) {
+  const unsigned grid = (unsigned)(a.tiles_per_xcd * 8);
+  LaunchScope ls(BINNED ? "points_fine" : "points_naive", stream);
+  const int K = a.K;
+  if (K == 1)
+    point_raster_kernel<TopKReg<1, 1>, 1, true, BINNED><<<grid, kStage, 0, stream>>>(a);
+  else if (K == 2)
+    point_raster_kernel<TopKReg<2, 1>, 2, true, BINNED><<<grid, kStage, 0, stream>>>(a);
+  else if (K <= 4)
+    point_raster_kernel<TopKReg<4, 1>, 4, true, BINNED><<<grid, kStage, 0, stream>>>(a);
+  else if (K <= 8)
+    point_raster_kernel<TopKReg<8, 1>, 8, true, BINNED><<<grid, kStage, 0, stream>>>(a);
+  else if (K <= 16)
+    point_raster_kernel<TopKReg<16, 1>, 16, true, BINNED><<<grid, kStage, 0, stream>>>(a);
+  else
+    point_raster_kernel<TopKMem<P3D_MAX_K, 1>, P3D_MAX_K, false, BINNED><<<grid, kStage, 0, stream>>>(a);
+  return launch_status();
+}
+
+void set_tiles(PointArgs* a, int bin_size, int BH, int BW) {
+  a->bin_size = bin_size;
+  a->BH = BH;
+  a->BW = BW;
+  const int span_y = bin_size < a->H ? bin_size : a->H;
+  const int span_x = bin_size < a->W ? bin_size : a->W;
+  a->Ty = (int)ceil_div(span_y, kTile);
+  a->Tx = (int)ceil_div(span_x, kTile);
+  a->total_tiles = (long long)a->N * BH * BW * a->Ty * a->Tx;
+  a->tiles_per_xcd = ceil_div(a->total_tiles, 8);
+}
+
+__global__ __launch_bounds__(256) void point_backward_kernel(const float* __restrict__ points,
+                                                             const int32_t* __restrict__ idxs,
+                                                             const float* __restrict__ grad_zbuf,
+                                                             const float* __restrict__ grad_dists, int N, int H, int W,
+                                                             int K, float* __restrict__ grad_points) {
+  const int64_t total = (int64_t)N * H * W * K;
+  const int64_t hwk = (int64_t)H * W * K;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int p = idxs[i];
+    if (p < 0) continue;
+    const int64_t yxk = i % hwk;
+    const int yo = (int)(yxk / ((int64_t)W * K));
+    const int xo = (int)((yxk % ((int64_t)W * K)) / K);
+    const float xf = pix_to_ndc(W - 1 - xo, W, H);  // rasterize_points.cu:389-393
+    const float yf = pix_to_ndc(H - 1 - yo, H, W);
+    const float g = grad_dists[i];
+    const float dx = points[(int64_t)p * 3 + 0] - xf;
+    const float dy = points[(int64_t)p * 3 + 1] - yf;
+    float* o = grad_points + (int64_t)p * 3;
+    unsafeAtomicAdd(o + 0, 2.0f * g * dx);
+    unsafeAtomicAdd(o + 1, 2.0f * g * dy);
+    unsafeAtomicAdd(o + 2, grad_zbuf[i]);
+  }
+}
+
+int check_common(int N, int H, int W, int K) {
+  if (N < 0 || H < 0 || W < 0 || K < 0) return P3D_ERR_INVALID_ARG;
+  if (K > P3D_MAX_K) return P3D_ERR_K_TOO_LARGE;
+  return P3D_OK;
+}
+
+void fill_args(PointArgs* a, const float* points, const float* radius, int N, int H, int W, int K, int32_t* idxs,
+               float* zbuf, float* dists) {
+  a->points = points;
+  a->radius = radius;
+  a->N = N;
+  a->H = H;
+  a->W = W;
+  a->K = K;
+  a->idxs = idxs;
+  a->zbuf = zbuf;
+  a->dists = dists;
+}
+
+}  // namespace
+}  // namespace p3d
+
+using namespace p3d;
+
+P3D_API size_t p3d_rasterize_points_workspace_bytes(int64_t P, int N, int H, int W, int bin_size,
+                                                    int max_points_per_bin) {
+  if (bin_size <= 0 || max_points_per_bin <= 0 || N <= 0 || H <= 0 || W <= 0) return 0;
+  const BinGeom g = make_geom(H, W, bin_size);
+  return bin_workspace_bytes(P, N, g, max_points_per_bin) + 256;
+}
+
+P3D_API int p3d_rasterize_points_naive(const float* points, const int64_t* first, const int64_t* count,
+                                       const float* radius, int64_t P, int N, int H, int W, int K, int32_t* idxs,
+                                       float* zbuf, float* dists, p3d_stream_t stream) {
+  const int rc = check_common(N, H, W, K);
+  if (rc != P3D_OK) return rc;
+  if ((int64_t)N * H * W * K == 0) return P3D_OK;
+  if ((P > 0 && (!points || !radius)) || !first || !count || !idxs || !zbuf || !dists) return P3D_ERR_INVALID_ARG;
+  PointArgs a{};
+  fill_args(&a, points, radius, N, H, W, K, idxs, zbuf, dists);
+  a.first = first;
+  a.count = count;
+  set_tiles(&a, H > W ? H : W, 1, 1);
+  return launch_point_raster<false>(a, (hipStream_t)stream);
+}
+
+P3D_API int p3d_rasterize_points(const float* points, const int64_t* first, const int64_t* count, const float* radius,
+                                 int64_t P, int N, int H, int W, int K, int bin_size, int max_points_per_bin,
+                                 int32_t* idxs, float* zbuf, float* dists, void* workspace, size_t workspace_bytes,
+                                 p3d_stream_t stream) {
+  if (bin_size <= 0 || max_points_per_bin <= 0)
+    return p3d_rasterize_points_naive(points, first, count, radius, P, N, H, W, K, idxs, zbuf, dists, stream);
+  const int rc = check_common(N, H, W, K);
+  if (rc != P3D_OK) return rc;
+  if ((int64_t)N * H * W * K == 0) return P3D_OK;
+  if ((P > 0 && (!points || !radius)) || !first || !count || !idxs || !zbuf || !dists) return P3D_ERR_INVALID_ARG;
+  const BinGeom g = make_geom(H, W, bin_size);
+  if (g.BH > P3D_MAX_BINS_PER_SIDE || g.BW > P3D_MAX_BINS_PER_SIDE) return P3D_ERR_TOO_MANY_BINS;
+  Arena arena(workspace, workspace_bytes);
+  BinWorkspace ws;
+  if (!workspace || !bin_carve(arena, P, N, g, max_points_per_bin, &ws)) return P3D_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  int st = bin_build(kPoints, points, radius, first, count, P, N, g, max_points_per_bin, 0.0f, ws, s);
+  if (st != P3D_OK) return st;
+  PointArgs a{};
+  fill_args(&a, points, radius, N, H, W, K, idxs, zbuf, dists);
+  a.csr = BinCSR{ws.offset, ws.total, ws.list};
+  set_tiles(&a, g.bin_size, g.BH, g.BW);
+  return launch_point_raster<true>(a, s);
+}
+
+P3D_API int p3d_rasterize_points_coarse(const float* points, const int64_t* first, const int64_t* count,
+                                        const float* radius, int64_t P, int N, int H, int W, int bin_size,
+                                        int max_points_per_bin, int32_t* bin_points, void* workspace,
+                                        size_t workspace_bytes, p3d_stream_t stream) {
+  if (N < 0 || H <= 0 || W <= 0 || bin_size <= 0 || max_points_per_bin < 0) return P3D_ERR_INVALID_ARG;
+  const BinGeom g = make_geom(H, W, bin_size);
+  if (g.BH > P3D_MAX_BINS_PER_SIDE || g.BW > P3D_MAX_BINS_PER_SIDE) return P3D_ERR_TOO_MANY_BINS;
+  if ((int64_t)N * g.nbins * max_points_per_bin == 0) return P3D_OK;
+  if ((P > 0 && (!points || !radius)) || !first || !count || !bin_points) return P3D_ERR_INVALID_ARG;
+  Arena arena(workspace, workspace_bytes);
+  BinWorkspace ws;
+  if (!workspace || !bin_carve(arena, P, N, g, max_points_per_bin, &ws)) return P3D_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  int st = bin_build(kPoints, points, radius, first, count, P, N, g, max_points_per_bin, 0.0f, ws, s);
+  if (st != P3D_OK) return st;
+  return bin_expand_padded(ws, N, g, max_points_per_bin, bin_points, s);
+}
+
+P3D_API int p3d_rasterize_points_fine(const float* points, const int32_t* bin_points, const float* radius, int64_t P,
+                                      int N, int BH, int BW, int M, int H, int W, int bin_size, int K, int32_t* idxs,
+                                      float* zbuf, float* dists, void* workspace, size_t workspace_bytes,
+                                      p3d_stream_t stream) {
+  const int rc = check_common(N, H, W, K);
+  if (rc != P3D_OK) return rc;
+  if ((int64_t)N * H * W * K == 0) return P3D_OK;
+  if (bin_size <= 0 || BH <= 0 || BW <= 0 || M < 0) return P3D_ERR_INVALID_ARG;
+  if ((P > 0 && (!points || !radius)) || !idxs || !zbuf || !dists) return P3D_ERR_INVALID_ARG;
+  if (BH > P3D_MAX_BINS_PER_SIDE || BW > P3D_MAX_BINS_PER_SIDE) return P3D_ERR_TOO_MANY_BINS;
+  if ((int64_t)BH * bin_size < H || (int64_t)BW * bin_size < W) return P3D_ERR_INVALID_ARG;
+  if (workspace_bytes < p3d_rasterize_fine_workspace_bytes(N, BH, BW, M) || !workspace) return P3D_ERR_WORKSPACE;
+  if (M > 0 && !bin_points) return P3D_ERR_INVALID_ARG;
+  const int64_t rows = (int64_t)N * BH * BW;
+  Arena arena(workspace, workspace_bytes);
+  int* list = arena.take<int>((size_t)rows * M);
+  int* total = arena.take<int>((size_t)rows);
+  int64_t* offset = arena.take<int64_t>((size_t)rows + 1);
+  hipStream_t s = (hipStream_t)stream;
+  int st = bin_compact_padded(bin_points, rows, M, list, total, offset, s);
+  if (st != P3D_OK) return st;
+  PointArgs a{};
+  fill_args(&a, points, radius, N, H, W, K, idxs, zbuf, dists);
+  a.csr = BinCSR{offset, total, list};
+  set_tiles(&a, bin_size, BH, BW);
+  return launch_point_raster<true>(a, s);
+}
+
+P3D_API int p3d_rasterize_points_backward(const float* points, const int32_t* idxs, const float* grad_zbuf,
+                                          const float* grad_dists, int64_t P, int N, int H, int W, int K,
+                                          float* grad_points, p3d_stream_t stream) {
+  if (P < 0 || N < 0 || H < 0 || W < 0 || K < 0) return P3D_ERR_INVALID_ARG;
+  if (P == 0) return P3D_OK;
+  if (!grad_points || !points) return P3D_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(grad_points, 0, (size_t)P * 3 * sizeof(float), s) != hipSuccess) return P3D_ERR_LAUNCH;
+  const int64_t total = (int64_t)N * H * W * K;
+  if (total == 0) return P3D_OK;
+  if (!idxs || !grad_zbuf || !grad_dists) return P3D_ERR_INVALID_ARG;
+  int64_t blocks = ceil_div(total, 256);
+  if (blocks > 65536) blocks = 65536;
+  LaunchScope ls("points_backward", s);
+  point_backward_kernel<<<(unsigned)blocks, 256, 0, s>>>(points, idxs, grad_zbuf, grad_dists, N, H, W, K, grad_points);
+  return launch_status();
+}

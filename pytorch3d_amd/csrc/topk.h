@@ -1,0 +1,177 @@
+// topk.h -- per-pixel "K nearest" queues for the fine / naive rasterizers.
+//
+// Target semantics ("Top-K"): the K smallest candidates under the total
+// order (z ascending, primitive index ascending), emitted in that order -- what the reference's
+// CPU queue (rasterize_meshes_cpu.cpp:281-285) and Python implementation do and what
+// test_order_of_ties pins.  The reference's CUDA queue (rasterize_meshes.cu:216-237, an unsorted
+// array with a tracked maximum + final BubbleSort) yields the same set except when several queued
+// entries tie exactly at the maximum z while the queue overflows.
+//
+// TopKReg keeps the queue sorted in VGPRs (compile-time capacity KT, fully unrolled
+// compare-exchange insertion: no scratch, no divergence inside an insertion).  TopKMem is the
+// K <= 150 fallback in private memory.  NP = number of float payload words per entry.
+// Host-compilable like p3d_geom.h, so tests/ can exercise the queue logic without a GPU.
+#pragma once
+
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "p3d_geom.h"  // P3D_HDM
+
+namespace p3d {
+
+constexpr int kEmptyIdx = 0x7fffffff;
+
+template <int KT, int NP>
+struct TopKReg {
+  float z[KT];
+  int idx[KT];
+  float pl[NP][KT];
+
+  P3D_HDM void init() {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      z[k] = INFINITY;
+      idx[k] = kEmptyIdx;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) pl[p][k] = -1.0f;
+    }
+  }
+
+  // Sorted insertion; the largest entry falls off the end.  `K` <= KT is the live capacity.
+  P3D_HDM void insert(int K, float cz, int cidx, const float (&cpl)[NP]) {
+    float vz = cz;
+    int vi = cidx;
+    float vp[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) vp[p] = cpl[p];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const bool lt = (vz < z[k]) || (vz == z[k] && vi < idx[k]);
+      const float tz = z[k];
+      const int ti = idx[k];
+      z[k] = lt ? vz : tz;
+      idx[k] = lt ? vi : ti;
+      vz = lt ? tz : vz;
+      vi = lt ? ti : vi;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const float tp = pl[p][k];
+        pl[p][k] = lt ? vp[p] : tp;
+        vp[p] = lt ? tp : vp[p];
+      }
+    }
+    if (K < KT) {
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        if (k >= K) {
+          z[k] = INFINITY;
+          idx[k] = kEmptyIdx;
+        }
+      }
+    }
+  }
+
+  // Cheap pre-test: can (cz, cidx) enter a queue of live capacity K at all?
+  P3D_HDM bool admits(int K, float cz, int cidx) const {
+    float lz = z[0];
+    int li = idx[0];
+#pragma unroll
+    for (int k = 1; k < KT; ++k) {
+      if (k < K) {
+        lz = z[k];
+        li = idx[k];
+      }
+    }
+    return (cz < lz) || (cz == lz && cidx < li);
+  }
+
+  // Position of primitive `want` in the queue, or -1.
+  P3D_HDM int find(int want) const {
+    int at = -1;
+#pragma unroll
+    for (int k = KT - 1; k >= 0; --k) {
+      if (idx[k] == want) at = k;
+    }
+    return at;
+  }
+
+  P3D_HDM float payload_at(int p, int at) const {
+    float v = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      if (k == at) v = pl[p][k];
+    }
+    return v;
+  }
+
+  // Remove entry `at` (keeps order).
+  P3D_HDM void erase(int at) {
+#pragma unroll
+    for (int k = 0; k < KT - 1; ++k) {
+      if (k >= at) {
+        z[k] = z[k + 1];
+        idx[k] = idx[k + 1];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) pl[p][k] = pl[p][k + 1];
+      }
+    }
+    z[KT - 1] = INFINITY;
+    idx[KT - 1] = kEmptyIdx;
+  }
+
+  P3D_HDM bool valid(int k) const { return idx[k] != kEmptyIdx; }
+};
+
+template <int KMAX, int NP>
+struct TopKMem {
+  float z[KMAX];
+  int idx[KMAX];
+  float pl[NP][KMAX];
+  int n;
+
+  P3D_HDM void init() { n = 0; }
+
+  P3D_HDM void insert(int K, float cz, int cidx, const float (&cpl)[NP]) {
+    int j = n;
+    while (j > 0 && ((cz < z[j - 1]) || (cz == z[j - 1] && cidx < idx[j - 1]))) --j;
+    if (j >= K) return;
+    const int last = n < K ? n : K - 1;
+    for (int m = last; m > j; --m) {
+      z[m] = z[m - 1];
+      idx[m] = idx[m - 1];
+      for (int p = 0; p < NP; ++p) pl[p][m] = pl[p][m - 1];
+    }
+    z[j] = cz;
+    idx[j] = cidx;
+    for (int p = 0; p < NP; ++p) pl[p][j] = cpl[p];
+    if (n < K) ++n;
+  }
+
+  P3D_HDM bool admits(int K, float cz, int cidx) const {
+    if (n < K) return true;
+    return (cz < z[K - 1]) || (cz == z[K - 1] && cidx < idx[K - 1]);
+  }
+
+  P3D_HDM int find(int want) const {
+    for (int k = 0; k < n; ++k)
+      if (idx[k] == want) return k;
+    return -1;
+  }
+
+  P3D_HDM float payload_at(int p, int at) const { return pl[p][at]; }
+
+  P3D_HDM void erase(int at) {
+    for (int k = at; k < n - 1; ++k) {
+      z[k] = z[k + 1];
+      idx[k] = idx[k + 1];
+      for (int p = 0; p < NP; ++p) pl[p][k] = pl[p][k + 1];
+    }
+    --n;
+  }
+
+  P3D_HDM bool valid(int k) const { return k < n; }
+};
+
+}  // namespace p3d

@@ -1,0 +1,106 @@
+"""Host-side mirror of pytorch3d/renderer/mesh/rasterize_meshes.py:32-357 over pytorch3d_amd._C.
+
+Same function name, arguments, defaults, heuristics and error messages as the reference's L2
+entry point, so the parity tests read like the reference's own tests.  Frustum clipping
+(`z_clip_value` / `cull_to_frustum`, pure-torch pytorch3d/renderer/mesh/clip.py) is SURVEY §8f
+"next" #1 and not part of this path: with the reference installed, use its own
+`rasterize_meshes` through pytorch3d_amd.shim (clip.py then runs unmodified on top of our `_C`).
+"""
+from typing import List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _C
+
+kMaxFacesPerBin = 22  # rasterize_meshes.py:29
+
+
+def parse_image_size(image_size):
+    """pytorch3d/renderer/utils.py parse_image_size: int or (H, W) -> (H, W)."""
+    if not isinstance(image_size, (tuple, list)):
+        return (int(image_size), int(image_size))
+    if len(image_size) != 2:
+        raise ValueError("Image size can only be a tuple/list of (H, W)")
+    if not all(i > 0 for i in image_size):
+        raise ValueError("Image sizes must be greater than 0; got %d, %d" % tuple(image_size))
+    if not all(isinstance(i, int) for i in image_size):
+        raise ValueError("Image sizes must be integers; got %r, %r" % tuple(image_size))
+    return tuple(image_size)
+
+
+def default_bin_size(max_image_size: int) -> int:
+    """rasterize_meshes.py:195-210 (GPU branch)."""
+    if max_image_size <= 64:
+        return 8
+    return int(2 ** max(np.ceil(np.log2(max_image_size)) - 4, 4))
+
+
+def rasterize_meshes(
+    meshes,
+    image_size: Union[int, List[int], Tuple[int, int]] = 256,
+    blur_radius: float = 0.0,
+    faces_per_pixel: int = 8,
+    bin_size: Optional[int] = None,
+    max_faces_per_bin: Optional[int] = None,
+    perspective_correct: bool = False,
+    clip_barycentric_coords: bool = False,
+    cull_backfaces: bool = False,
+    z_clip_value: Optional[float] = None,
+    cull_to_frustum: bool = False,
+):
+    """Returns (pix_to_face, zbuf, barycentric_coords, dists), each (N, H, W, faces_per_pixel[, 3])."""
+    if z_clip_value is not None or cull_to_frustum:
+        raise NotImplementedError(
+            "clip_faces (z_clip_value / cull_to_frustum) is outside the hot path (SURVEY §8f next #1); "
+            "use the reference's rasterize_meshes over pytorch3d_amd.shim.install()")
+    verts_packed = meshes.verts_packed()
+    faces_packed = meshes.faces_packed()
+    face_verts = verts_packed[faces_packed]
+    mesh_to_face_first_idx = meshes.mesh_to_faces_packed_first_idx()
+    num_faces_per_mesh = meshes.num_faces_per_mesh()
+    im_size = parse_image_size(image_size)
+    max_image_size = max(*im_size)
+
+    clipped_faces_neighbor_idx = torch.full(
+        size=(face_verts.shape[0],), fill_value=-1, device=face_verts.device, dtype=torch.int64)
+
+    if bin_size is None:
+        bin_size = default_bin_size(max_image_size)
+    if bin_size != 0:
+        faces_per_bin = 1 + (max_image_size - 1) // bin_size
+        if faces_per_bin >= kMaxFacesPerBin:
+            raise ValueError("bin_size too small, number of faces per bin must be less than %d; got %d" %
+                             (kMaxFacesPerBin, faces_per_bin))
+    if max_faces_per_bin is None:
+        max_faces_per_bin = int(max(10000, meshes._F / 5))
+
+    return _RasterizeFaceVerts.apply(face_verts, mesh_to_face_first_idx, num_faces_per_mesh,
+                                     clipped_faces_neighbor_idx, im_size, blur_radius, faces_per_pixel, bin_size,
+                                     max_faces_per_bin, perspective_correct, clip_barycentric_coords, cull_backfaces)
+
+
+class _RasterizeFaceVerts(torch.autograd.Function):
+    """Autograd wrapper, as rasterize_meshes.py:252-357."""
+
+    @staticmethod
+    def forward(ctx, face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx,
+                image_size=(256, 256), blur_radius=0.01, faces_per_pixel=0, bin_size=0, max_faces_per_bin=0,
+                perspective_correct=False, clip_barycentric_coords=False, cull_backfaces=False):
+        pix_to_face, zbuf, barycentric_coords, dists = _C.rasterize_meshes(
+            face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, image_size,
+            blur_radius, faces_per_pixel, bin_size, max_faces_per_bin, perspective_correct, clip_barycentric_coords,
+            cull_backfaces)
+        ctx.save_for_backward(face_verts, pix_to_face)
+        ctx.mark_non_differentiable(pix_to_face)
+        ctx.perspective_correct = perspective_correct
+        ctx.clip_barycentric_coords = clip_barycentric_coords
+        return pix_to_face, zbuf, barycentric_coords, dists
+
+    @staticmethod
+    def backward(ctx, grad_pix_to_face, grad_zbuf, grad_barycentric_coords, grad_dists):
+        face_verts, pix_to_face = ctx.saved_tensors
+        grad_face_verts = _C.rasterize_meshes_backward(face_verts, pix_to_face, grad_zbuf, grad_barycentric_coords,
+                                                       grad_dists, ctx.perspective_correct,
+                                                       ctx.clip_barycentric_coords)
+        return (grad_face_verts,) + (None,) * 11

@@ -1,0 +1,188 @@
+"""Shared helpers for the test-suite: synthetic geometry, camera transform, harness loaders."""
+import ctypes
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+# ---------------------------------------------------------------------------------------------
+# geometry generators (own code; the reference's ico_sphere/torus are not available on the GPU box)
+# ---------------------------------------------------------------------------------------------
+def ico_sphere(level=0):
+    """Unit icosphere: (verts (V,3) f32, faces (F,3) i64), 20 * 4**level faces, CCW seen from outside."""
+    t = (1.0 + math.sqrt(5.0)) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
+         (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10),
+         (8, 6, 7), (9, 8, 1)]
+    verts = [np.array(p, dtype=np.float64) / np.linalg.norm(p) for p in v]
+    faces = list(f)
+    for _ in range(level):
+        cache = {}
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = verts[a] + verts[b]
+                verts.append(m / np.linalg.norm(m))
+                cache[key] = len(verts) - 1
+            return cache[key]
+
+        nf = []
+        for a, b, c in faces:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        faces = nf
+    return (torch.tensor(np.stack(verts), dtype=torch.float32), torch.tensor(faces, dtype=torch.int64))
+
+
+def torus(r, R, sides, rings):
+    """Torus with tube radius r, ring radius R: 2*sides*rings faces."""
+    i = torch.arange(rings, dtype=torch.float64)
+    j = torch.arange(sides, dtype=torch.float64)
+    phi = (2 * math.pi * i / rings)[:, None]
+    th = (2 * math.pi * j / sides)[None, :]
+    x = (R + r * torch.cos(th)) * torch.cos(phi)
+    y = (R + r * torch.cos(th)) * torch.sin(phi)
+    z = (r * torch.sin(th)).expand(rings, sides)
+    verts = torch.stack([x, y, z], -1).reshape(-1, 3).float()
+    ii = torch.arange(rings)[:, None]
+    jj = torch.arange(sides)[None, :]
+    a = (ii * sides + jj)
+    b = (((ii + 1) % rings) * sides + jj)
+    c = (((ii + 1) % rings) * sides + (jj + 1) % sides)
+    d = (ii * sides + (jj + 1) % sides)
+    f1 = torch.stack([a, b, c], -1).reshape(-1, 3)
+    f2 = torch.stack([a, c, d], -1).reshape(-1, 3)
+    return verts, torch.cat([f1, f2], 0).long()
+
+
+def random_rotation(gen):
+    q = torch.randn(4, generator=gen, dtype=torch.float64)
+    q = q / q.norm()
+    w, x, y, z = q.tolist()
+    return torch.tensor([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], dtype=torch.float32)
+
+
+def to_ndc(verts, dist=2.7, fov_deg=60.0, scale=1.0):
+    """A pinhole view from distance `dist` down -z: x,y -> NDC, z -> view-space depth (kept, as
+    MeshRasterizer.transform does, pytorch3d/renderer/mesh/rasterizer.py:195-216)."""
+    f = 1.0 / math.tan(math.radians(fov_deg) / 2.0)
+    v = verts * scale
+    z = v[:, 2] + dist
+    return torch.stack([f * v[:, 0] / z, f * v[:, 1] / z, z], -1)
+
+
+def triangle_soup(F, gen, size=0.5, zlo=0.3, zhi=2.3, behind_every=0):
+    """F random triangles in NDC with per-vertex depths; every `behind_every`-th is (partly) behind the camera."""
+    c = torch.rand(F, 1, 2, generator=gen) * 2.4 - 1.2
+    xy = c + (torch.rand(F, 3, 2, generator=gen) - 0.5) * size
+    z = torch.rand(F, 3, 1, generator=gen) * (zhi - zlo) + zlo
+    fv = torch.cat([xy, z], -1).float()
+    if behind_every:
+        fv[::behind_every, :, 2] -= 1.0
+    return fv
+
+
+def smooth_soup(F, gen, size=0.5):
+    """Triangles whose three depths are close (like real meshes): well-conditioned gradients."""
+    c = torch.rand(F, 1, 2, generator=gen) * 2.2 - 1.1
+    xy = c + (torch.rand(F, 3, 2, generator=gen) - 0.5) * size
+    z0 = torch.rand(F, 1, 1, generator=gen) * 2.0 + 0.8
+    z = z0 + (torch.rand(F, 3, 1, generator=gen) - 0.5) * 0.1
+    return torch.cat([xy, z], -1).float()
+
+
+def split_counts(F, N):
+    per = F // N
+    first = torch.arange(N, dtype=torch.int64) * per
+    count = torch.full((N,), per, dtype=torch.int64)
+    count[-1] = F - int(first[-1])
+    return first, count
+
+
+def hetero_batch(n_meshes, seed=0, fmin=1000, fmax=20000):
+    """BASELINE config 3 generator: tori / icospheres with log-uniform face counts, random rotation,
+    seen from distance 2.7.  Returns (list of NDC verts, list of faces)."""
+    gen = torch.Generator().manual_seed(seed)
+    verts, faces = [], []
+    for _ in range(n_meshes):
+        u = torch.rand(3, generator=gen).tolist()
+        target = int(round(math.exp(math.log(fmin) + u[0] * (math.log(fmax) - math.log(fmin)))))
+        if u[1] < 0.25:
+            level = min(range(2, 6), key=lambda l: abs(20 * 4 ** l - target))
+            v, f = ico_sphere(level)
+        else:
+            sides = max(8, int(round(math.sqrt(target / 2.0 / 2.5))))
+            rings = max(8, int(round(target / 2.0 / sides)))
+            v, f = torus(0.4 + 0.2 * u[2], 1.0, sides, rings)
+            v = v / 1.5
+        R = random_rotation(gen)
+        verts.append(to_ndc(v @ R.T))
+        faces.append(f)
+    return verts, faces
+
+
+# ---------------------------------------------------------------------------------------------
+# harness loaders
+# ---------------------------------------------------------------------------------------------
+_hostgeom = None
+
+
+def hostgeom():
+    """g++ build of the device headers (tests/hostgeom/hostgeom.cpp)."""
+    global _hostgeom
+    if _hostgeom is None:
+        d = os.path.join(ROOT, "tests", "hostgeom")
+        so = os.path.join(d, "libhostgeom.so")
+        srcs = [os.path.join(d, "hostgeom.cpp"), os.path.join(ROOT, "pytorch3d_amd", "csrc", "p3d_geom.h"),
+                os.path.join(ROOT, "pytorch3d_amd", "csrc", "topk.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
+                                   "-Wno-unknown-pragmas", srcs[0], "-o", so])
+        _hostgeom = ctypes.CDLL(so)
+    return _hostgeom
+
+
+def p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def hg_rasterize_meshes(fv, first, count, nbr, image_size, blur, K, persp, clip, cull, use_mem=False):
+    H, W = image_size
+    N = first.shape[0]
+    fv, first, count, nbr = fv.contiguous(), first.contiguous(), count.contiguous(), nbr.contiguous()
+    p2f = torch.empty((N, H, W, K), dtype=torch.int64)
+    zbuf = torch.empty((N, H, W, K), dtype=torch.float32)
+    bary = torch.empty((N, H, W, K, 3), dtype=torch.float32)
+    dists = torch.empty((N, H, W, K), dtype=torch.float32)
+    hostgeom().hg_rasterize_meshes(p(fv), p(first), p(count), p(nbr), N, H, W, ctypes.c_float(blur), K, int(persp),
+                                   int(clip), int(cull), int(use_mem), p(p2f), p(zbuf), p(bary), p(dists))
+    return p2f, zbuf, bary, dists
+
+
+def hg_rasterize_meshes_backward(fv, p2f, gz, gb, gd, persp, clip, clip_on_corrected=False):
+    N, H, W, K = p2f.shape
+    F = fv.shape[0]
+    acc = torch.zeros((F, 3, 3), dtype=torch.float64)
+    hostgeom().hg_rasterize_meshes_backward(p(fv.contiguous()), p(p2f.contiguous()), p(gz.contiguous()),
+                                            p(gb.contiguous()), p(gd.contiguous()), ctypes.c_int64(F), N, H, W, K,
+                                            int(persp), int(clip), int(clip_on_corrected), p(acc))
+    return acc.float()
+
+
+def gpu_available():
+    return torch.cuda.is_available()
