@@ -26,6 +26,7 @@ class PackedMeshes:
         f_first = torch.cumsum(nf, 0) - nf
         self._verts_list = list(verts)
         self._faces_list = list(faces)
+        self._nv_host = [int(x) for x in nv.tolist()]  # host copies: no device sync when re-splitting
         self._verts_packed = torch.cat(list(verts), 0) if self._N else torch.zeros((0, 3))
         self._faces_packed = (torch.cat([f + int(o) for f, o in zip(faces, v_first)], 0)
                               if self._N else torch.zeros((0, 3), dtype=torch.int64))
@@ -46,6 +47,8 @@ class PackedMeshes:
         return self._faces_packed
 
     def verts_list(self) -> List[torch.Tensor]:
+        if self._verts_list is None:
+            self._verts_list = list(torch.split(self._verts_packed, self._nv_host, 0))
         return self._verts_list
 
     def faces_list(self) -> List[torch.Tensor]:
@@ -68,13 +71,12 @@ class PackedMeshes:
         out = object.__new__(PackedMeshes)
         out.__dict__.update(self.__dict__)
         out._verts_packed = new_verts_packed
-        sizes = [int(n) for n in self._num_verts.tolist()]
-        out._verts_list = list(torch.split(new_verts_packed, sizes, 0))
+        out._verts_list = None  # split lazily in verts_list()
         return out
 
     def slice(self, start: int, stop: int) -> "PackedMeshes":
         """Meshes start..stop-1 as their own batch (the unit of multi-GPU sharding)."""
-        return PackedMeshes(self._verts_list[start:stop], self._faces_list[start:stop])
+        return PackedMeshes(self.verts_list()[start:stop], self._faces_list[start:stop])
 
 
 class PackedPointclouds:

@@ -1,0 +1,199 @@
+"""GPU parity: point rasterization, the three compositors and interpolate_face_attributes vs the
+oracle (and the reference CPU build when present), through the C ABI."""
+import pytest
+import torch
+
+import _util as U
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _cloud(P, gen, zlo=-0.2, zhi=2.0):
+    return torch.cat([torch.rand(P, 2, generator=gen) * 2.4 - 1.2, torch.rand(P, 1, generator=gen) * (zhi - zlo) + zlo],
+                     1)
+
+
+@pytest.mark.parametrize("size", [(32, 32), (20, 48), (45, 31)])
+@pytest.mark.parametrize("K", [1, 3, 8, 10, 16, 40])
+def test_points_naive_and_binned_vs_oracle(size, K):
+    from pytorch3d_amd import _C
+
+    d = _dev()
+    gen = torch.Generator().manual_seed(K * 100 + size[0])
+    P = 800
+    pts = _cloud(P, gen)
+    first = torch.tensor([0, 300, 300])
+    count = torch.tensor([300, 0, 500])
+    radius = torch.rand(P, generator=gen) * 0.12 + 0.02
+    ref = orc.rasterize_points_naive(pts, first, count, size, radius, K)
+    for bin_size in (0, 8, 16):
+        ours = _C.rasterize_points(pts.to(d), first.to(d), count.to(d), size, radius.to(d), K, bin_size, 500)
+        ours = [o.cpu() for o in ours]
+        assert torch.equal(ours[0], ref[0]), f"idx differs bin={bin_size}: {(ours[0] != ref[0]).sum().item()}"
+        assert torch.equal(ours[1], ref[1]) and torch.equal(ours[2], ref[2])
+    ref_mod = orc.ref_module()
+    if ref_mod is not None:
+        r = ref_mod._rasterize_points_naive(pts, first, count, size, radius, K)
+        assert all(torch.equal(a, b) for a, b in zip(ours, r))
+
+
+def test_points_coarse_and_fine_ops():
+    from pytorch3d_amd import _C
+
+    d = _dev()
+    gen = torch.Generator().manual_seed(3)
+    P = 3000
+    pts = _cloud(P, gen)
+    first = torch.tensor([0, 1500])
+    count = torch.tensor([1500, 1500])
+    radius = torch.rand(P, generator=gen) * 0.05 + 0.01
+    for (H, W), bs in [((32, 32), 8), ((64, 40), 8), ((30, 50), 5)]:
+        ref, _ = orc.rasterize_points_coarse(pts, first, count, (H, W), radius, bs, 600)
+        ours = _C._rasterize_points_coarse(pts.to(d), first.to(d), count.to(d), (H, W), radius.to(d), bs, 600).cpu()
+        assert torch.equal(ours, ref)
+        fine = _C._rasterize_points_fine(pts.to(d), ours.to(d), (H, W), radius.to(d), bs, 6)
+        naive = orc.rasterize_points_naive(pts, first, count, (H, W), radius, 6)
+        assert all(torch.equal(a.cpu(), b) for a, b in zip(fine, naive))
+
+
+def test_points_backward_and_autograd():
+    import pytorch3d_amd as p3d
+    from pytorch3d_amd import _C
+
+    d = _dev()
+    gen = torch.Generator().manual_seed(8)
+    P = 2000
+    pts = _cloud(P, gen, zlo=0.1)
+    clouds = p3d.PackedPointclouds([pts[:900].to(d).requires_grad_(True), pts[900:].to(d).requires_grad_(True)])
+    idx, zbuf, dists = p3d.rasterize_points(clouds, image_size=(40, 56), radius=0.05, points_per_pixel=5)
+    gz = torch.randn(zbuf.shape, generator=gen)
+    gd = torch.randn(dists.shape, generator=gen)
+    ref = orc.rasterize_points_backward(pts, idx.cpu(), gz, gd, acc64=True)
+    direct = _C.rasterize_points_backward(pts.to(d), idx, gz.to(d), gd.to(d)).cpu()
+    scale = ref.abs().max().item()
+    assert torch.allclose(direct, ref, rtol=1e-4, atol=5e-6 * max(scale, 1.0))
+    # and through autograd, including the concatenation of the two clouds
+    p1 = pts[:900].to(d).requires_grad_(True)
+    p2 = pts[900:].to(d).requires_grad_(True)
+
+    class _C2:  # packed container over a differentiable concat
+        _N, _P, device = 2, 1100, d
+
+        def points_packed(self):
+            return torch.cat([p1, p2], 0)
+
+        def cloud_to_packed_first_idx(self):
+            return torch.tensor([0, 900], device=d)
+
+        def num_points_per_cloud(self):
+            return torch.tensor([900, 1100], device=d)
+
+    out = p3d.rasterize_points(_C2(), image_size=(40, 56), radius=0.05, points_per_pixel=5)
+    torch.autograd.backward([out[1], out[2]], [gz.to(d), gd.to(d)])
+    got = torch.cat([p1.grad, p2.grad], 0).cpu()
+    assert torch.allclose(got, ref, rtol=1e-4, atol=5e-6 * max(scale, 1.0))
+
+
+@pytest.mark.parametrize("mode", ["alphacomposite", "weightedsumnorm", "weightedsum"])
+@pytest.mark.parametrize("K", [4, 10, 24])
+@pytest.mark.parametrize("permuted", [False, True])
+def test_compositors(mode, K, permuted):
+    from pytorch3d_amd import _C
+
+    d = _dev()
+    gen = torch.Generator().manual_seed(K)
+    N, C, P, H, W = 2, 5, 300, 13, 17
+    feat = torch.rand(C, P, generator=gen)
+    if permuted:  # what the renderers pass: permuted views of (N,H,W,K) tensors
+        alphas = torch.rand(N, H, W, K, generator=gen).permute(0, 3, 1, 2)
+        idx = torch.randint(-1, P, (N, H, W, K), generator=gen).permute(0, 3, 1, 2)
+    else:
+        alphas = torch.rand(N, K, H, W, generator=gen)
+        idx = torch.randint(-1, P, (N, K, H, W), generator=gen)
+    go = torch.randn(N, C, H, W, generator=gen)
+    ref = orc.composite_forward(mode, feat, alphas, idx)
+    fwd = getattr(_C, "accum_" + mode)(feat.to(d), alphas.to(d), idx.to(d)).cpu()
+    assert torch.equal(fwd, ref), f"forward not bit-exact: {(fwd - ref).abs().max().item()}"
+    rgf, rga = orc.composite_backward(mode, go, feat, alphas, idx)
+    gf, ga = getattr(_C, "accum_" + mode + "_backward")(go.to(d), feat.to(d), alphas.to(d), idx.to(d))
+    assert torch.allclose(gf.cpu(), rgf, atol=2e-5, rtol=1e-4)
+    assert torch.allclose(ga.cpu(), rga, atol=2e-5 * max(1.0, rga.abs().max().item()), rtol=1e-4)
+    ref_mod = orc.ref_module()
+    if ref_mod is not None:
+        r = getattr(ref_mod, "accum_" + mode)(feat, alphas.contiguous(), idx.contiguous())
+        assert torch.allclose(fwd, r, atol=1e-6)
+
+
+def test_compositor_autograd_mirror():
+    import pytorch3d_amd as p3d
+
+    d = _dev()
+    gen = torch.Generator().manual_seed(1)
+    N, C, P, K, H, W = 1, 3, 100, 6, 9, 11
+    feat = torch.rand(C, P, generator=gen).to(d).requires_grad_(True)
+    alphas = torch.rand(N, K, H, W, generator=gen).to(d).requires_grad_(True)
+    idx = torch.randint(-1, P, (N, K, H, W), generator=gen).to(d)
+    for fn, mode in ((p3d.alpha_composite, "alphacomposite"), (p3d.norm_weighted_sum, "weightedsumnorm"),
+                     (p3d.weighted_sum, "weightedsum")):
+        feat.grad = alphas.grad = None
+        img = fn(idx, alphas, feat)
+        go = torch.randn(img.shape, generator=gen)
+        img.backward(go.to(d))
+        rgf, rga = orc.composite_backward(mode, go, feat.detach().cpu(), alphas.detach().cpu(), idx.cpu())
+        assert torch.allclose(feat.grad.cpu(), rgf, atol=2e-5, rtol=1e-4)
+        assert torch.allclose(alphas.grad.cpu(), rga, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("D", [1, 3, 4, 7, 32])
+def test_interp_face_attrs(D):
+    from pytorch3d_amd import _C
+
+    d = _dev()
+    gen = torch.Generator().manual_seed(D)
+    P, F = 5000, 60
+    p2f = torch.randint(-1, F, (P,), generator=gen)
+    bary = torch.rand(P, 3, generator=gen)
+    attrs = torch.randn(F, 3, D, generator=gen)
+    ref = orc.interp_forward(p2f, bary, attrs)
+    out = _C.interp_face_attrs_forward(p2f.to(d), bary.to(d), attrs.to(d)).cpu()
+    assert torch.equal(out, ref)
+    g = torch.randn(P, D, generator=gen)
+    rgb, rgf = orc.interp_backward(p2f, bary, attrs, g)
+    gb, gf = _C.interp_face_attrs_backward(p2f.to(d), bary.to(d), attrs.to(d), g.to(d))
+    assert torch.allclose(gb.cpu(), rgb, atol=1e-5, rtol=1e-5)
+    assert torch.allclose(gf.cpu(), rgf, atol=1e-4, rtol=1e-4)
+    # float64 is dispatched too (AT_DISPATCH_FLOATING_TYPES, interp_face_attrs.cu:72)
+    out64 = _C.interp_face_attrs_forward(p2f.to(d), bary.double().to(d), attrs.double().to(d)).cpu()
+    assert torch.allclose(out64.float(), ref, atol=1e-6)
+
+
+def test_interp_mirror_shapes_and_grads():
+    import pytorch3d_amd as p3d
+
+    d = _dev()
+    gen = torch.Generator().manual_seed(2)
+    N, H, W, K, F, D = 2, 6, 7, 3, 20, 4
+    p2f = torch.randint(-1, F, (N, H, W, K), generator=gen).to(d)
+    bary = torch.rand(N, H, W, K, 3, generator=gen).to(d).requires_grad_(True)
+    attrs = torch.randn(F, 3, D, generator=gen).to(d).requires_grad_(True)
+    out = p3d.interpolate_face_attributes(p2f, bary, attrs)
+    assert out.shape == (N, H, W, K, D)
+    # python reference (pytorch3d/ops/interp_face_attrs.py:86-102 semantics) for values and grads
+    mask = (p2f < 0)
+    idx = p2f.clone()
+    idx[mask] = 0
+    pf = attrs[idx]  # (N,H,W,K,3,D)
+    ref = (bary[..., None] * pf).sum(-2)
+    ref = torch.where(mask[..., None], torch.zeros_like(ref), ref)
+    assert torch.allclose(out, ref, atol=1e-6)
+    g = torch.randn(out.shape, generator=gen).to(d)
+    ga, gb = torch.autograd.grad(ref, [attrs, bary], g, retain_graph=True)
+    oa, ob = torch.autograd.grad(out, [attrs, bary], g)
+    assert torch.allclose(oa, ga, atol=1e-4) and torch.allclose(ob, gb, atol=1e-5)
+    with pytest.raises(ValueError):
+        p3d.interpolate_face_attributes(p2f[0], bary, attrs)
