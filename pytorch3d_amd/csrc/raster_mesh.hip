@@ -30,6 +30,10 @@ constexpr int kTile = 16;       // pixels per tile side (4 waves x 8x8)
 constexpr int kStage = 256;     // faces staged per round = threads per workgroup
 constexpr int kMeshPayload = 4; // dist, bary.x, bary.y, bary.z
 
+#ifndef P3D_FINE_WAVES_PER_SIMD
+#define P3D_FINE_WAVES_PER_SIMD 4  // caps the fine kernel at 128 VGPRs: 4 waves/SIMD instead of 2
+#endif
+
 struct MeshArgs {
   const float* face_verts;
   const int64_t* neighbor;
@@ -148,7 +152,7 @@ __device__ __forceinline__ void write_pixel(const MeshArgs& a, const Queue& q, i
 }
 
 template <typename Queue, int KT, bool IN_REGS, bool BINNED>
-__global__ __launch_bounds__(kStage) void mesh_raster_kernel(MeshArgs a) {
+__global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_kernel(MeshArgs a) {
   __shared__ float4 s_box[kStage];       // xlo, xhi, ylo, yhi (blur-expanded)
   __shared__ float4 s_vert[kStage][3];   // v0x v0y v0z v1x | v1y v1z v2x v2y | v2z idx nb -
   __shared__ int s_wcnt[kStage / kWave];
@@ -269,22 +273,22 @@ __global__ __launch_bounds__(kStage) void mesh_raster_kernel(MeshArgs a) {
               const int f = __float_as_int(r2.y);
               const int nb = __float_as_int(r2.z);
               const float pl[kMeshPayload] = {h.dist, h.bary.x, h.bary.y, h.bary.z};
+              bool ins = true;
               if (nb != -1) {
                 // clipped-face neighbour rule (rasterize_meshes.cu:186-215,
                 // rasterize_meshes_cpu.cpp:249-277): at most one of the two halves of a split
                 // face stays in the queue -- the one closer to the pixel.
                 const int at = q.find(nb);
                 if (at >= 0) {
-                  if (fabsf(h.dist) < fabsf(q.payload_at(0, at))) {
+                  if (fabsf(h.dist) < fabsf(q.payload_at(0, at)))
                     q.erase(at);
-                    q.insert(K, h.z, f, pl);
-                  }
-                } else {
-                  q.insert(K, h.z, f, pl);
+                  else
+                    ins = false;
                 }
-              } else {
-                q.insert(K, h.z, f, pl);
               }
+              // a candidate that sorts after the K-th entry of a full queue would fall straight
+              // off the end of the insertion network: skip the network for it
+              if (ins && q.admits(K, h.z, f)) q.insert(K, h.z, f, pl);
             }
           }
         }

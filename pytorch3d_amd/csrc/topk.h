@@ -73,18 +73,10 @@ struct TopKReg {
     }
   }
 
-  // Cheap pre-test: can (cz, cidx) enter a queue of live capacity K at all?
-  P3D_HDM bool admits(int K, float cz, int cidx) const {
-    float lz = z[0];
-    int li = idx[0];
-#pragma unroll
-    for (int k = 1; k < KT; ++k) {
-      if (k < K) {
-        lz = z[k];
-        li = idx[k];
-      }
-    }
-    return (cz < lz) || (cz == lz && cidx < li);
+  // Cheap pre-test: can (cz, cidx) enter the queue at all?  Exact when K == KT (slot KT-1 is the
+  // K-th entry); when K < KT that slot is always empty and the test passes (insert() sorts it out).
+  P3D_HDM bool admits(int /*K*/, float cz, int cidx) const {
+    return (cz < z[KT - 1]) || (cz == z[KT - 1] && cidx < idx[KT - 1]);
   }
 
   // Position of primitive `want` in the queue, or -1.
