@@ -186,3 +186,32 @@ def hg_rasterize_meshes_backward(fv, p2f, gz, gb, gd, persp, clip, clip_on_corre
 
 def gpu_available():
     return torch.cuda.is_available()
+
+
+# ---------------------------------------------------------------------------------------------
+# replay of the reference test-suite's own operator calls (tests/golden/ref_suite_calls.*)
+# ---------------------------------------------------------------------------------------------
+def ref_suite_calls():
+    """[(op, test id, [inputs], [outputs])] recorded by tests/golden/record_reference_suite.py from the
+    reference's unittest modules running on the reference's CPU kernels."""
+    import json
+
+    with open(os.path.join(GOLDEN, "ref_suite_calls.json")) as f:
+        manifest = json.load(f)["calls"]
+    arrays = np.load(os.path.join(GOLDEN, "ref_suite_calls.npz"))
+
+    def dec(e):
+        if e["t"] == "tensor":
+            return torch.from_numpy(arrays[e["key"]])
+        if e["t"] == "tuple":
+            return tuple(e["v"])
+        return e["v"]
+
+    return [(c["op"], c["test"], [dec(e) for e in c["in"]], [dec(e) for e in c["out"]]) for c in manifest]
+
+
+def sort_bins(b):
+    """Order-free view of a (N,BH,BW,M) bin tensor: entries ascending, -1 padding last."""
+    big = torch.where(b < 0, torch.full_like(b, 2 ** 30), b)
+    s = big.sort(-1).values
+    return torch.where(s == 2 ** 30, torch.full_like(s, -1), s)

@@ -1,0 +1,177 @@
+"""CPU suite, part 3: the C-ABI library and the host logic (no GPU, no compute calls).
+
+* libp3d_amd.so loads and exports every function include/p3d_amd.h declares (and nothing in the
+  header is missing from the ctypes table);
+* entry points that can answer without a device (version, error strings, workspace sizing, argument
+  validation that precedes any launch) behave;
+* the `pytorch3d._C` surface mirrors the reference's pybind names / error behaviour and REFUSES CPU
+  tensors (no fallback);
+* host-side heuristics of the L2 mirror (bin size, max bins) follow the reference.
+"""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+import _util as U
+
+HEADER = os.path.join(U.ROOT, "include", "p3d_amd.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(p3d_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_operator_surface():
+    names = _declared()
+    for want in ("p3d_rasterize_meshes", "p3d_rasterize_meshes_naive", "p3d_rasterize_meshes_coarse",
+                 "p3d_rasterize_meshes_fine", "p3d_rasterize_meshes_backward", "p3d_rasterize_points",
+                 "p3d_rasterize_points_naive", "p3d_rasterize_points_coarse", "p3d_rasterize_points_fine",
+                 "p3d_rasterize_points_backward", "p3d_composite_forward", "p3d_composite_backward",
+                 "p3d_interp_face_attrs_forward", "p3d_interp_face_attrs_backward"):
+        assert want in names
+
+
+def test_library_exports_every_declared_symbol():
+    from pytorch3d_amd import _lib
+
+    assert os.path.exists(_lib.LIB_PATH), "run `python -m pytorch3d_amd.build` (hipcc --offload-arch=gfx950)"
+    dyn = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT (p3d_[a-z0-9_]+)", dyn))
+    declared = set(_declared())
+    assert declared <= exported, f"declared but not exported: {sorted(declared - exported)}"
+    assert exported <= declared, f"exported but not declared in include/p3d_amd.h: {sorted(exported - declared)}"
+    assert set(_lib.EXPORTED_SYMBOLS) == declared, "ctypes table out of sync with the header"
+
+
+def test_library_contains_gfx950_code_object():
+    from pytorch3d_amd import _lib
+
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"mesh_raster_kernel" in blob
+
+
+def test_library_loads_and_answers_without_a_device():
+    from pytorch3d_amd import _lib
+
+    lib = _lib.load()
+    assert lib.p3d_abi_version() == 1
+    assert b"150" in lib.p3d_error_string(-2) or b"K" in lib.p3d_error_string(-2)
+    assert lib.p3d_error_string(0)
+    # workspace sizing is pure host arithmetic
+    a = lib.p3d_rasterize_meshes_workspace_bytes(10000, 4, 128, 128, 16, 1000)
+    b = lib.p3d_rasterize_meshes_workspace_bytes(20000, 4, 128, 128, 16, 1000)
+    assert 0 < a <= b
+    assert lib.p3d_rasterize_meshes_workspace_bytes(10000, 4, 128, 128, 0, 0) == 0
+    assert lib.p3d_rasterize_points_workspace_bytes(10000, 2, 64, 64, 8, 100) > 0
+    assert lib.p3d_rasterize_fine_workspace_bytes(2, 4, 4, 10) >= 2 * 16 * 10 * 4
+    # validation that precedes any launch: K > 150, too many bins, null outputs
+    null = ctypes.c_void_p(None)
+    rc = lib.p3d_rasterize_meshes_naive(null, null, null, null, 0, 1, 8, 8, 0.0, 151, 0, 0, 0, null, null, null, null, null)
+    assert rc == -2
+    rc = lib.p3d_rasterize_meshes(null, null, null, null, 0, 1, 64, 64, 0.0, 4, 2, 10, 0, 0, 0, null, null, null, null,
+                                  null, 0, null)
+    assert rc in (-1, -3)
+    rc = lib.p3d_rasterize_meshes_coarse(null, null, null, 0, 1, 64, 64, 0.0, 2, 10, null, null, 0, null)
+    assert rc == -3
+    # empty problems return OK before touching the device
+    rc = lib.p3d_rasterize_meshes_naive(null, null, null, null, 0, 0, 8, 8, 0.0, 4, 0, 0, 0, null, null, null, null, null)
+    assert rc == 0
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    from pytorch3d_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libp3d_amd.so"))
+    with pytest.raises(_lib.ExtensionMissing, match="no CPU/eager fallback"):
+        _lib.load()
+
+
+def test_operator_surface_names_match_the_reference_pybind_module():
+    """pytorch3d/csrc/ext.cpp:38-73 (hot-path subset) + the constants read at import (ext.cpp:180-185)."""
+    from pytorch3d_amd import _C, shim
+
+    ref_names = ["rasterize_meshes", "rasterize_meshes_backward", "_rasterize_meshes_naive", "_rasterize_meshes_coarse",
+                 "_rasterize_meshes_fine", "rasterize_points", "rasterize_points_backward", "_rasterize_points_naive",
+                 "_rasterize_points_coarse", "_rasterize_points_fine", "accum_alphacomposite",
+                 "accum_alphacomposite_backward", "accum_weightedsumnorm", "accum_weightedsumnorm_backward",
+                 "accum_weightedsum", "accum_weightedsum_backward", "interp_face_attrs_forward",
+                 "interp_face_attrs_backward"]
+    mod = shim.make_module()
+    for n in ref_names:
+        assert callable(getattr(_C, n)) and callable(getattr(mod, n))
+    assert (mod.EPS, mod.MAX_INT, mod.MAX_UINT, mod.MAX_USHORT, mod.PULSAR_MAX_GRAD_SPHERES) == (
+        1e-6, 2147483647, 4294967295, 65535, 128)
+    with pytest.raises(NotImplementedError):
+        mod.knn_points_idx(None)
+
+
+def test_cpu_tensors_are_refused_not_emulated():
+    from pytorch3d_amd import _C
+
+    fv = torch.rand(4, 3, 3)
+    z = torch.zeros(1, dtype=torch.int64)
+    with pytest.raises(RuntimeError, match="GPU path only"):
+        _C.rasterize_meshes(fv, z, z + 4, torch.full((4,), -1, dtype=torch.int64), (8, 8), 0.0, 2, 0, 0, False, False,
+                            False)
+    with pytest.raises(RuntimeError, match="GPU path only"):
+        _C.accum_alphacomposite(torch.rand(3, 5), torch.rand(1, 2, 4, 4), torch.zeros(1, 2, 4, 4, dtype=torch.int64))
+    with pytest.raises(RuntimeError, match="GPU path only"):
+        _C.interp_face_attrs_forward(torch.zeros(5, dtype=torch.int64), torch.rand(5, 3), torch.rand(2, 3, 4))
+
+
+def test_l2_mirror_heuristics_follow_the_reference():
+    """rasterize_meshes.py:195-222 / rasterize_points.py:104-126."""
+    import importlib
+
+    rm = importlib.import_module("pytorch3d_amd.rasterize_meshes")
+
+    assert rm.default_bin_size(64) == 8
+    assert rm.default_bin_size(65) == 16
+    assert rm.default_bin_size(256) == 16
+    assert rm.default_bin_size(512) == 32
+    assert rm.default_bin_size(1024) == 64
+    assert rm.parse_image_size(32) == (32, 32)
+    assert rm.parse_image_size((20, 48)) == (20, 48)
+    with pytest.raises(ValueError):
+        rm.parse_image_size((0, 4))
+
+    class M:
+        _F = 10
+
+        def verts_packed(self):
+            return torch.rand(6, 3)
+
+        def faces_packed(self):
+            return torch.tensor([[0, 1, 2], [3, 4, 5]])
+
+        def mesh_to_faces_packed_first_idx(self):
+            return torch.tensor([0])
+
+        def num_faces_per_mesh(self):
+            return torch.tensor([2])
+
+    with pytest.raises(ValueError, match="bin_size too small"):
+        rm.rasterize_meshes(M(), image_size=512, bin_size=8)  # tests/test_rasterize_meshes.py:461-466
+    with pytest.raises(NotImplementedError):
+        rm.rasterize_meshes(M(), image_size=32, z_clip_value=0.1)
+
+
+def test_packed_containers_match_reference_accessors():
+    import pytorch3d_amd as p3d
+
+    v = [torch.rand(5, 3), torch.rand(7, 3)]
+    f = [torch.tensor([[0, 1, 2], [2, 3, 4]]), torch.tensor([[0, 5, 6]])]
+    m = p3d.PackedMeshes(v, f)
+    assert len(m) == 2
+    assert m.verts_packed().shape == (12, 3)
+    assert m.faces_packed().tolist() == [[0, 1, 2], [2, 3, 4], [5, 10, 11]]
+    assert m.mesh_to_faces_packed_first_idx().tolist() == [0, 2]
+    assert m.num_faces_per_mesh().tolist() == [2, 1]
+    assert m._F == 2
