@@ -1,0 +1,101 @@
+#!/usr/bin/env python
+"""Fold the rocprofv3 CSVs written by profiles/run_rocprof.sh into a committed summary.
+
+    python profiles/summarize.py gpurun_out/prof profiles/r01_v3   ->  profiles/r01_v3_rocprof.md
+                                                                        profiles/traffic.json (read by bench.py)
+
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are collected in
+separate --pmc passes, are in KiB-units of 1024 B, and on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, i.e.
+reads up to 2x low for wide coalesced streams: both the raw and the x2-corrected figure are reported; WRITE_SIZE is
+calibrated here against the fine kernel, whose only HBM writes are its outputs (an exactly known byte count).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+OURS = {"mesh_raster_kernel": "mesh_fine", "mesh_backward": "mesh_backward", "points_raster": "points_fine",
+        "bin_count": "bin_count", "bin_fill": "bin_fill", "bin_scan_offsets": "bin_scan_offsets",
+        "bin_scan_rows": "bin_scan_rows", "bin_plan": "bin_plan", "gather_faces": "gather_face_verts",
+        "scatter_face": "scatter_face_grads"}
+
+
+def short(name):
+    for k, v in OURS.items():
+        if k in name:
+            return v
+    return None
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    lines = ["# rocprofv3 summary (" + os.path.basename(dst) + ")", "",
+             "Command: `python bench.py --steps 5 --warmup 2 --no-cpu-baseline` under `rocprofv3` "
+             "(profiles/run_rocprof.sh), MI355X / gfx950.", ""]
+    f = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
+    if f:
+        rows = list(csv.DictReader(open(f[0])))
+        tot = sum(float(r["TotalDurationNs"]) for r in rows)
+        lines += ["## `--kernel-trace --stats`: per-kernel time (all launches incl. warm-up)", "",
+                  "| kernel | calls | avg us | min us | max us | % of GPU time |", "|---|---|---|---|---|---|"]
+        for r in rows[:16]:
+            nm = short(r["Name"]) or r["Name"].split("(")[0][-70:]
+            lines.append(f"| {nm} | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | "
+                         f"{float(r['MaxNs'])/1e3:.1f} | {100*float(r['TotalDurationNs'])/tot:.2f} |")
+        lines.append("")
+    traffic = {}
+    pmc = collections.defaultdict(dict)
+    meta = {}
+    for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+        if not os.path.isdir(d):
+            continue
+        f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+        if not f:
+            continue
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f[0])):
+            k = short(r["Kernel_Name"])
+            if k is None:
+                continue
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            meta[k] = dict(vgpr=r["VGPR_Count"], agpr=r.get("Accum_VGPR_Count", "0"), sgpr=r["SGPR_Count"],
+                           lds=r["LDS_Block_Size"], scratch=r["Scratch_Size"], grid=r["Grid_Size"], wg=r["Workgroup_Size"])
+        for k, cs in acc.items():
+            for c, v in cs.items():
+                pmc[k][c] = sum(v) / len(v)
+    if pmc:
+        lines += ["## PMC passes (per-launch averages; each `--pmc` set collected in its own run)", ""]
+        for k in sorted(pmc, key=lambda k: -pmc[k].get("SQ_WAVE_CYCLES", 0)):
+            m = meta[k]
+            lines += [f"### {k}", "",
+                      f"grid {m['grid']} threads, workgroup {m['wg']}, VGPR {m['vgpr']} (+{m['agpr']} acc), SGPR {m['sgpr']}, "
+                      f"LDS {m['lds']} B, scratch {m['scratch']} B/lane", "", "| counter | per launch |", "|---|---|"]
+            for c in sorted(pmc[k]):
+                lines.append(f"| {c} | {pmc[k][c]:.4g} |")
+            c = pmc[k]
+            if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
+                fetch = c.get("FETCH_SIZE", 0.0) * 1024
+                write = c.get("WRITE_SIZE", 0.0) * 1024
+                traffic[k] = {"fetch_bytes_raw": fetch, "fetch_bytes_x2": 2 * fetch, "write_bytes": write,
+                              "hbm_bytes": 2 * fetch + write}
+                lines += ["", f"HBM traffic per launch: FETCH_SIZE {fetch/1e6:.1f} MB raw (x2 gfx950 correction: "
+                          f"{2*fetch/1e6:.1f} MB), WRITE_SIZE {write/1e6:.1f} MB -> {(2*fetch+write)/1e6:.1f} MB"]
+            if "SQ_WAVE_CYCLES" in c and "SQ_INSTS_VALU" in c:
+                lines += ["", f"VALU wave-instructions per wave: {c['SQ_INSTS_VALU']/max(c.get('SQ_WAVES',1),1):.0f}; "
+                          f"busy {100*c.get('SQ_ACTIVE_INST_VALU',0)/c['SQ_WAVE_CYCLES']:.1f}% / waiting "
+                          f"{100*c.get('SQ_WAIT_ANY',0)/c['SQ_WAVE_CYCLES']:.1f}% / issue-stalled "
+                          f"{100*c.get('SQ_WAIT_INST_ANY',0)/c['SQ_WAVE_CYCLES']:.1f}% of wave cycles"]
+            lines.append("")
+    with open(dst + "_rocprof.md", "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "traffic.json"), "w") as fh:
+        json.dump({k: v["hbm_bytes"] for k, v in traffic.items()} | {"_detail": traffic, "_source": os.path.basename(dst)},
+                  fh, indent=1)
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
