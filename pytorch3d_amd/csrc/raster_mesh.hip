@@ -16,8 +16,7 @@
 // The naive operator is the same kernel with "the bin" being the whole image and "the list"
 // being the mesh's face range, so naive and binned results are identical by construction.
 //
-// Backward (replaces RasterizeMeshesBackwardCudaKernel, rasterize_meshes.cu:433-564): one
-// thread per pixel, per-sample recompute through p3d_geom.h, hardware f32 atomics.
+// The SoftRas backward lives in raster_mesh_bwd.hip.
 #include "binning.h"
 #include "p3d_geom.h"
 #include "topk.h"
@@ -334,93 +333,6 @@ void set_tiles(MeshArgs* a, int bin_size, int BH, int BW) {
   a->tiles_per_xcd = ceil_div(a->total_tiles, 8);
 }
 
-// ---------------------------------------------------------------------------------------
-// Backward.
-// ---------------------------------------------------------------------------------------
-// Sum of v over the 64 lanes of the wave, returned in every lane.  Four DPP steps reduce each
-// row of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror -- each folds into one
-// v_add_f32_dpp), then the four row totals are read with v_readlane.  Must be called with all
-// lanes active.
-#define P3D_DPP_ADD(v, ctrl) \
-  ((v) + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xf, 0xf, true)))
-
-__device__ __forceinline__ float wave_sum(float v) {
-  v = P3D_DPP_ADD(v, 0xB1);   // quad_perm [1,0,3,2]
-  v = P3D_DPP_ADD(v, 0x4E);   // quad_perm [2,3,0,1]
-  v = P3D_DPP_ADD(v, 0x141);  // row_half_mirror
-  v = P3D_DPP_ADD(v, 0x140);  // row_mirror
-  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-  return (r0 + r1) + (r2 + r3);
-}
-
-// One wave owns an 8x8 pixel tile (one pixel per lane), walks the K slots, and for every slot
-// reduces the nine partials of all lanes that hit the SAME face inside the wave before touching
-// memory: neighbouring pixels overwhelmingly share faces (SoftRas blur makes every face cover
-// tens of pixels), so the 9 atomics per (pixel, k) sample of the reference become 9 per
-// (wave, distinct face).
-__global__ __launch_bounds__(256) void mesh_backward_kernel(const float* __restrict__ face_verts,
-                                                            const int64_t* __restrict__ p2f,
-                                                            const float* __restrict__ grad_zbuf,
-                                                            const float* __restrict__ grad_bary,
-                                                            const float* __restrict__ grad_dists, int N, int H, int W,
-                                                            int K, int persp, int clip, float* __restrict__ grad_fv) {
-  const int lane = threadIdx.x & 63;
-  const int tiles_x = (W + 7) >> 3, tiles_y = (H + 7) >> 3;
-  const long long ntiles = (long long)N * tiles_y * tiles_x;
-  const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
-  for (long long t = wave0; t < ntiles; t += nwaves) {
-    const int tx = (int)(t % tiles_x);
-    const int ty = (int)((t / tiles_x) % tiles_y);
-    const int n = (int)(t / ((long long)tiles_x * tiles_y));
-    const int yo = ty * 8 + (lane >> 3), xo = tx * 8 + (lane & 7);
-    const bool ok = yo < H && xo < W;
-    const int yi = H - 1 - yo, xi = W - 1 - xo;  // rasterize_meshes.cu:458-462
-    const f2 p = mk2(pix_to_ndc(xi, W, H), pix_to_ndc(yi, H, W));
-    const int64_t base = (((int64_t)n * H + yo) * W + xo) * K;
-    for (int k = 0; k < K; ++k) {
-      const int64_t i = base + k;
-      const int f = ok ? (int)p2f[i] : -1;
-      unsigned long long remaining = __ballot(f >= 0);
-      if (remaining == 0) continue;  // wave-uniform
-      FaceGrad r;
-#pragma unroll
-      for (int j = 0; j < 9; ++j) r.g[j] = 0.0f;
-      if (f >= 0) {
-        const float* g = face_verts + (int64_t)f * 9;
-        const f3 v0 = mk3(g[0], g[1], g[2]);
-        const f3 v1 = mk3(g[3], g[4], g[5]);
-        const f3 v2 = mk3(g[6], g[7], g[8]);
-        const f3 gb = mk3(grad_bary[i * 3 + 0], grad_bary[i * 3 + 1], grad_bary[i * 3 + 2]);
-        r = face_sample_bwd(v0, v1, v2, p, grad_zbuf[i], gb, grad_dists[i], persp != 0, clip != 0, false);
-      }
-      while (remaining) {
-        const int leader = __builtin_ctzll(remaining);
-        const int f0 = __builtin_amdgcn_readlane(f, leader);
-        const bool mem = f == f0;
-        const unsigned long long m = __ballot(mem);
-        remaining &= ~m;
-        float* o = grad_fv + (int64_t)f0 * 9;
-        if (__popcll(m) == 1) {
-          if (mem) {
-#pragma unroll
-            for (int j = 0; j < 9; ++j) unsafeAtomicAdd(o + j, r.g[j]);
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 9; ++j) {
-            const float s = wave_sum(mem ? r.g[j] : 0.0f);
-            if (lane == leader) unsafeAtomicAdd(o + j, s);
-          }
-        }
-      }
-    }
-  }
-}
-
 int check_common(int N, int H, int W, int K) {
   if (N < 0 || H < 0 || W < 0 || K < 0) return P3D_ERR_INVALID_ARG;
   if (K > P3D_MAX_K) return P3D_ERR_K_TOO_LARGE;
@@ -582,25 +494,4 @@ P3D_API int p3d_rasterize_meshes_fine(const float* face_verts, const int32_t* bi
   BinCSR csr{offset, total, list};
   return mesh_fine_from_csr(face_verts, neighbor, csr, N, H, W, g, blur_radius, K, persp, clip, cull, p2f, zbuf, bary,
                             dists, s);
-}
-
-P3D_API int p3d_rasterize_meshes_backward(const float* face_verts, const int64_t* p2f, const float* grad_zbuf,
-                                          const float* grad_bary, const float* grad_dists, int64_t F, int N, int H,
-                                          int W, int K, int persp, int clip, float* grad_face_verts,
-                                          p3d_stream_t stream) {
-  if (F < 0 || N < 0 || H < 0 || W < 0 || K < 0) return P3D_ERR_INVALID_ARG;
-  if (F == 0) return P3D_OK;
-  if (!grad_face_verts || !face_verts) return P3D_ERR_INVALID_ARG;
-  hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(grad_face_verts, 0, (size_t)F * 9 * sizeof(float), s) != hipSuccess) return P3D_ERR_LAUNCH;
-  const int64_t npix = (int64_t)N * H * W;
-  if (npix * K == 0) return P3D_OK;
-  if (!p2f || !grad_zbuf || !grad_bary || !grad_dists) return P3D_ERR_INVALID_ARG;
-  const int64_t ntiles = (int64_t)N * ceil_div(H, 8) * ceil_div(W, 8);
-  int64_t blocks = ceil_div(ntiles, 4);
-  if (blocks > 256 * 64) blocks = 256 * 64;
-  LaunchScope ls("mesh_backward", s);
-  mesh_backward_kernel<<<(unsigned)blocks, 256, 0, s>>>(face_verts, p2f, grad_zbuf, grad_bary, grad_dists, N, H, W, K,
-                                                       persp, clip, grad_face_verts);
-  return launch_status();
 }

@@ -1,0 +1,335 @@
+// raster_mesh_bwd.hip -- SoftRas backward of mesh rasterization for gfx950.
+//
+// Replaces RasterizeMeshesBackwardCudaKernel (pytorch3d/csrc/rasterize_meshes/rasterize_meshes.cu:433-625):
+// per (pixel, k) sample with a face, recompute the forward through p3d_geom.h and scatter nine
+// partials to grad_face_verts[f].  The reference issues nine global float atomics per sample; on
+// MI355X device-scope atomics resolve beyond the per-XCD L2, so that design is atomic-bound (the
+// first version of this kernel, with a wave-level segmented reduction, still spent 1.4 GB of HBM
+// write traffic per launch on 11.5 MB of output).
+//
+// Design (numbers from profiles/microbench/lds_atomic.hip and profiles/ablate.py on MI355X):
+//   * gfx950 executes ds_add_f32 one lane at a time (~190-260 CU-cycles per wave instruction whatever
+//     the conflict pattern; ds_add_u32 / ds_wrxchg take ~4), so accumulating partials with LDS float
+//     atomics costs twice the whole rest of the kernel.  This kernel uses NO float atomics in LDS.
+//   * one wave owns a 16x16-pixel area of one image (a 256-thread workgroup = a 32x32 region), walked
+//     as four 8x8 tiles, one pixel per lane; a lane reads its pixel's K-row of pix_to_face /
+//     grad_zbuf / grad_dists / grad_bary with 16-byte loads, once, and only if the pixel has a face
+//     (background rows are never fetched);
+//   * per K slot, lanes that hit the same face are linked into a list with ONE integer LDS exchange
+//     per lane on the face's hash-table slot (ds_wrxchg_rtn returns the previous visitor), the nine
+//     partials are summed along the lists by pointer jumping (ds_bpermute, log2(group) steps), and
+//     each list head adds its group's total to the wave-private table with plain LDS loads/stores
+//     (no two heads of one wave instruction share a slot);
+//   * a face's contributions from all pixels and all K slots of the 16x16 area meet in that table;
+//     it is flushed with nine global atomics per (area, face) -- instead of nine per sample -- when
+//     the area is done or the table runs full.
+// Accumulation order is not deterministic (float atomics on the final flush), as in the reference
+// (rasterize_meshes.cu:587 alertNotDeterministic).
+#include "p3d_common.h"
+#include "p3d_geom.h"
+
+#include <stdlib.h>
+
+namespace p3d {
+
+namespace {
+
+constexpr int kRegion = 32;   // pixels per workgroup-region side (four 16x16 wave areas)
+constexpr int kSlots = 232;   // hash-table slots per wave: 4 waves x 232 x 44 B = 40832 B -> 4 workgroups per CU
+constexpr int kFlushAt = kSlots - 64;  // a step adds at most 64 faces: the table can never overflow
+constexpr int kEmptyKey = -1;
+
+struct BwdArgs {
+  const float* face_verts;
+  const int64_t* p2f;
+  const float* grad_zbuf;
+  const float* grad_bary;
+  const float* grad_dists;
+  float* grad_fv;
+  int N, H, W, K;
+  int RY, RX;  // regions per image
+  int persp, clip;
+  int debug;  // P3D_DEBUG_BWD ablation bits (profiles/ablate.py): 1 no compute, 2 no accumulate, 4 no vertex gathers
+};
+
+__device__ __forceinline__ int hash_face(int f) {
+  return (int)(((unsigned long long)((unsigned)f * 2654435761u) * (unsigned)kSlots) >> 32);
+}
+
+// Row loaders: KT contiguous elements starting at a (KT * elemsize)-aligned address.
+template <int KT>
+__device__ __forceinline__ void load_idx_row(const int64_t* p, int (&out)[KT]) {
+  if constexpr (KT % 2 == 0) {
+#pragma unroll
+    for (int k = 0; k < KT; k += 2) {
+      const longlong2 t = *reinterpret_cast<const longlong2*>(p + k);
+      out[k] = (int)t.x;
+      out[k + 1] = (int)t.y;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) out[k] = (int)p[k];
+  }
+}
+
+template <int M>
+__device__ __forceinline__ void load_f32_row(const float* p, float (&out)[M]) {
+  if constexpr (M % 4 == 0) {
+#pragma unroll
+    for (int k = 0; k < M; k += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(p + k);
+      out[k] = t.x;
+      out[k + 1] = t.y;
+      out[k + 2] = t.z;
+      out[k + 3] = t.w;
+    }
+  } else if constexpr (M % 2 == 0) {
+#pragma unroll
+    for (int k = 0; k < M; k += 2) {
+      const float2 t = *reinterpret_cast<const float2*>(p + k);
+      out[k] = t.x;
+      out[k + 1] = t.y;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < M; ++k) out[k] = p[k];
+  }
+}
+
+// Wave-private accumulation table (LDS).
+struct Table {
+  volatile int* keys;   // [kSlots] face id or kEmptyKey (volatile: other lanes of the wave write it between my store and my re-load)
+  volatile int* owner;  // [kSlots] scratch for the per-step visitor lists, -1 between steps
+  float* vals;          // [9][kSlots]
+};
+
+__device__ __forceinline__ float lane_read(float v, int src_lane) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+
+// Flush every occupied slot with global atomics and empty the table.  All 64 lanes.
+__device__ __forceinline__ void flush_table(const Table& t, float* __restrict__ grad_fv, int lane) {
+  for (int s = lane; s < kSlots; s += 64) {
+    const int f = t.keys[s];
+    if (f != kEmptyKey) {
+      float* o = grad_fv + (int64_t)f * 9;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) unsafeAtomicAdd(o + j, t.vals[j * kSlots + s]);
+      t.keys[s] = kEmptyKey;
+    }
+  }
+}
+
+// One K slot of one 8x8 tile: every lane with f >= 0 contributes r to face f.  Must be called by
+// all 64 lanes (wave-uniform control flow).  Returns the number of table slots newly occupied.
+__device__ __forceinline__ int accumulate_step(const Table& t, int lane, int f, FaceGrad& r) {
+  const bool active = f >= 0;
+  // ---- locate / claim the face's slot.  All lanes of one face probe in lockstep (same hash,
+  // same sequence), so they see the same thing at every probe.
+  int slot = -1;
+  bool fresh = false;
+  if (active) {
+    int h = hash_face(f);
+    for (;;) {
+      const int cur = t.keys[h];
+      if (cur == f) {
+        slot = h;
+        break;
+      }
+      if (cur == kEmptyKey) {
+        t.keys[h] = f;  // several faces may race for one empty slot: the last store wins
+        if (t.keys[h] == f) {
+          slot = h;
+          fresh = true;
+          break;
+        }
+      }
+      h = (h + 1 == kSlots) ? 0 : h + 1;
+    }
+  }
+  // ---- link the visitors of each slot: prev = the lane that visited before me (or -1).
+  int prev = -1;
+  if (active) prev = atomicExch(const_cast<int*>(&t.owner[slot]), lane);
+  const bool head = active && t.owner[slot] == lane;  // the last visitor heads the list
+  // ---- sum along the lists by pointer jumping: after step s every lane holds the sum of the
+  // 2^s list entries starting at itself, so the head ends with the group total.
+  while (__ballot(prev >= 0)) {
+    const int src = prev >= 0 ? prev : lane;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const float o = lane_read(r.g[j], src);
+      if (prev >= 0) r.g[j] += o;
+    }
+    const int pp = __builtin_amdgcn_ds_bpermute(src << 2, prev);
+    prev = prev >= 0 ? pp : -1;
+  }
+  // ---- heads fold their total into the table (distinct faces -> distinct slots: plain ld/st)
+  if (head) {
+    t.owner[slot] = -1;
+    if (fresh) {
+#pragma unroll
+      for (int j = 0; j < 9; ++j) t.vals[j * kSlots + slot] = r.g[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 9; ++j) t.vals[j * kSlots + slot] += r.g[j];
+    }
+  }
+  return __popcll(__ballot(head && fresh));
+}
+
+// KT > 0: K == KT, rows read with vector loads.  KT == 0: any K, per-slot scalar loads.
+template <int KT>
+__global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
+  __shared__ int s_keys[4][kSlots];
+  __shared__ int s_owner[4][kSlots];
+  __shared__ float s_vals[4][9 * kSlots];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = tid >> 6;
+  const Table tab{s_keys[w], s_owner[w], s_vals[w]};
+  // region of this workgroup, 16x16 area of this wave
+  long long t = blockIdx.x;
+  const int rx = (int)(t % a.RX);
+  t /= a.RX;
+  const int ry = (int)(t % a.RY);
+  const int n = (int)(t / a.RY);
+  const int ay = ry * kRegion + (w >> 1) * 16;
+  const int ax = rx * kRegion + (w & 1) * 16;
+  const int H = a.H, W = a.W, K = a.K;
+  if (ay >= H || ax >= W) return;  // wave-uniform; no workgroup barriers in this kernel
+
+  for (int i = lane; i < kSlots; i += 64) {
+    tab.keys[i] = kEmptyKey;
+    tab.owner[i] = -1;
+  }
+  const bool persp = a.persp != 0, clip = a.clip != 0;
+  int used = 0;  // occupied slots (wave-uniform)
+
+#pragma unroll 1
+  for (int tile = 0; tile < 4; ++tile) {
+    const int yo = ay + (tile >> 1) * 8 + (lane >> 3);
+    const int xo = ax + (tile & 1) * 8 + (lane & 7);
+    const bool ok = yo < H && xo < W;
+    const int yi = H - 1 - yo, xi = W - 1 - xo;  // rasterize_meshes.cu:458-462
+    const f2 p = mk2(pix_to_ndc(xi, W, H), pix_to_ndc(yi, H, W));
+    const int64_t base = (((int64_t)n * H + yo) * W + xo) * K;
+
+    if constexpr (KT > 0) {
+      int f[KT];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) f[k] = -1;
+      if (ok) load_idx_row<KT>(a.p2f + base, f);
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) any |= f[k] >= 0;
+      if (__ballot(any) == 0) continue;  // wave-uniform: nothing rendered in this 8x8 tile
+      float gz[KT], gd[KT], gb[3 * KT];
+      if (any) {
+        load_f32_row<KT>(a.grad_zbuf + base, gz);
+        load_f32_row<KT>(a.grad_dists + base, gd);
+        load_f32_row<3 * KT>(a.grad_bary + base * 3, gb);
+      }
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        if (__ballot(f[k] >= 0) == 0) continue;  // wave-uniform
+        FaceGrad r;
+        if (f[k] >= 0) {
+          const float* g = a.face_verts + (int64_t)((a.debug & 4) ? 0 : f[k]) * 9;
+          const f3 v0 = mk3(g[0], g[1], g[2]);
+          const f3 v1 = mk3(g[3], g[4], g[5]);
+          const f3 v2 = mk3(g[6], g[7], g[8]);
+          if (a.debug & 1) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) r.g[j] = v0.x + gz[k] + gd[k] + gb[3 * k];
+          } else {
+            r = face_sample_bwd(v0, v1, v2, p, gz[k], mk3(gb[3 * k], gb[3 * k + 1], gb[3 * k + 2]), gd[k], persp, clip,
+                                false);
+          }
+        }
+        if (a.debug & 2) {
+          if (f[k] >= 0 && r.g[0] == 1234.5f) a.grad_fv[0] = r.g[1];
+          continue;
+        }
+        if (used > kFlushAt) {
+          flush_table(tab, a.grad_fv, lane);
+          used = 0;
+        }
+        used += accumulate_step(tab, lane, f[k], r);
+      }
+    } else {
+#pragma unroll 1
+      for (int k = 0; k < K; ++k) {
+        const int64_t i = base + k;
+        const int f = ok ? (int)a.p2f[i] : -1;
+        if (__ballot(f >= 0) == 0) continue;
+        FaceGrad r;
+        if (f >= 0) {
+          const float* g = a.face_verts + (int64_t)f * 9;
+          const f3 v0 = mk3(g[0], g[1], g[2]);
+          const f3 v1 = mk3(g[3], g[4], g[5]);
+          const f3 v2 = mk3(g[6], g[7], g[8]);
+          const f3 gb = mk3(a.grad_bary[i * 3 + 0], a.grad_bary[i * 3 + 1], a.grad_bary[i * 3 + 2]);
+          r = face_sample_bwd(v0, v1, v2, p, a.grad_zbuf[i], gb, a.grad_dists[i], persp, clip, false);
+        }
+        if (used > kFlushAt) {
+          flush_table(tab, a.grad_fv, lane);
+          used = 0;
+        }
+        used += accumulate_step(tab, lane, f, r);
+      }
+    }
+  }
+  if (used > 0) flush_table(tab, a.grad_fv, lane);
+}
+
+}  // namespace
+
+}  // namespace p3d
+
+using namespace p3d;
+
+P3D_API int p3d_rasterize_meshes_backward(const float* face_verts, const int64_t* p2f, const float* grad_zbuf,
+                                          const float* grad_bary, const float* grad_dists, int64_t F, int N, int H,
+                                          int W, int K, int persp, int clip, float* grad_face_verts,
+                                          p3d_stream_t stream) {
+  if (F < 0 || N < 0 || H < 0 || W < 0 || K < 0) return P3D_ERR_INVALID_ARG;
+  if (F == 0) return P3D_OK;
+  if (!grad_face_verts || !face_verts) return P3D_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(grad_face_verts, 0, (size_t)F * 9 * sizeof(float), s) != hipSuccess) return P3D_ERR_LAUNCH;
+  const int64_t npix = (int64_t)N * H * W;
+  if (npix * K == 0) return P3D_OK;
+  if (!p2f || !grad_zbuf || !grad_bary || !grad_dists) return P3D_ERR_INVALID_ARG;
+  BwdArgs a;
+  a.face_verts = face_verts;
+  a.p2f = p2f;
+  a.grad_zbuf = grad_zbuf;
+  a.grad_bary = grad_bary;
+  a.grad_dists = grad_dists;
+  a.grad_fv = grad_face_verts;
+  a.N = N;
+  a.H = H;
+  a.W = W;
+  a.K = K;
+  a.RY = (int)ceil_div(H, kRegion);
+  a.RX = (int)ceil_div(W, kRegion);
+  a.persp = persp;
+  a.clip = clip;
+  {
+    const char* e = getenv("P3D_DEBUG_BWD");
+    a.debug = e ? atoi(e) : 0;
+  }
+  const int64_t blocks = (int64_t)N * a.RY * a.RX;
+  if (blocks > 0x7fffffffll) return P3D_ERR_INVALID_ARG;
+  LaunchScope ls("mesh_backward", s);
+  const unsigned grid = (unsigned)blocks;
+  switch (K) {
+    case 1: mesh_backward_kernel<1><<<grid, 256, 0, s>>>(a); break;
+    case 2: mesh_backward_kernel<2><<<grid, 256, 0, s>>>(a); break;
+    case 4: mesh_backward_kernel<4><<<grid, 256, 0, s>>>(a); break;
+    case 8: mesh_backward_kernel<8><<<grid, 256, 0, s>>>(a); break;
+    default: mesh_backward_kernel<0><<<grid, 256, 0, s>>>(a); break;
+  }
+  return launch_status();
+}
