@@ -21,6 +21,8 @@
 #include "p3d_geom.h"
 #include "topk.h"
 
+#include <stdlib.h>
+
 namespace p3d {
 
 namespace {
@@ -45,6 +47,7 @@ struct MeshArgs {
   long long tiles_per_xcd;
   float blur, sqrt_blur;
   int persp, clip, cull;
+  int debug;  // P3D_DEBUG_FWD ablation bits (profiles/ablate.py): 1 no per-pixel evaluation, 2 no queue insertion, 4 no stores, 8 contiguous tile->XCD order, 16 no depth cull
   int64_t* p2f;
   float* zbuf;
   float* bary;
@@ -154,11 +157,18 @@ template <typename Queue, int KT, bool IN_REGS, bool BINNED>
 __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_kernel(MeshArgs a) {
   __shared__ float4 s_box[kStage];       // xlo, xhi, ylo, yhi (blur-expanded)
   __shared__ float4 s_vert[kStage][3];   // v0x v0y v0z v1x | v1y v1z v2x v2y | v2z idx nb -
+  __shared__ float s_zc[kStage];         // depth-cull key: every sample of the face has z >= s_zc (or -inf)
   __shared__ int s_wcnt[kStage / kWave];
 
   // XCD-aware tile order: consecutive logical tiles (which share a bin's face list) run on the
   // same XCD and hit the same L2 (workgroup b is dispatched to XCD b % 8).
-  const long long lt = (long long)(blockIdx.x % 8) * a.tiles_per_xcd + (long long)(blockIdx.x / 8);
+  long long lt = (long long)(blockIdx.x % 8) * a.tiles_per_xcd + (long long)(blockIdx.x / 8);
+  if (!(a.debug & 8)) {
+    // bins round-robin over the XCDs, the tiles of one bin adjacent on one XCD
+    const int tpb = a.Ty * a.Tx;
+    const long long slot = blockIdx.x / 8;
+    lt = ((slot / tpb) * 8 + (blockIdx.x % 8)) * tpb + slot % tpb;
+  }
   if (lt >= a.total_tiles) return;
   long long t = lt;
   const int tx = (int)(t % a.Tx);
@@ -244,6 +254,14 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
       s_vert[pos][0] = make_float4(v0.x, v0.y, v0.z, v1.x);
       s_vert[pos][1] = make_float4(v1.y, v1.z, v2.x, v2.y);
       s_vert[pos][2] = make_float4(v2.z, __int_as_float(fid), __int_as_float(nb), 0.0f);
+      // Depth cull (exact): with clipped barycentrics a sample's depth is a convex combination of
+      // the vertex depths, so pz >= zmin * (1 - 4e-7) in float arithmetic (three roundings each in
+      // the normalisation and the dot product); a lane whose queue is full with K-th depth below
+      // that bound can never admit the face.  Not applicable when barycentrics are unclipped (pz may
+      // leave [zmin, zmax]), when the face has a clipped neighbour (it may REPLACE a queued entry,
+      // rasterize_meshes.cu:186-215), or for depths so small that bary_clip's 1e-5 floor could bite.
+      const float zmin = min3(v0.z, v1.z, v2.z);
+      s_zc[pos] = (clip && nb == -1 && zmin >= 1e-3f) ? zmin * 0.999998f : -INFINITY;
     }
     __syncthreads();
 
@@ -262,7 +280,8 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
           cand &= cand - 1;
           const float4 b = s_box[jj];
           const bool out = p.x > b.y || p.x < b.x || p.y > b.w || p.y < b.z;
-          if (pix_ok && !out) {
+          const bool too_deep = s_zc[jj] > q.kth_z(K) && !(a.debug & 16);
+          if (pix_ok && !out && !too_deep && !(a.debug & 1)) {
             const float4 r0 = s_vert[jj][0], r1 = s_vert[jj][1], r2 = s_vert[jj][2];
             const f3 a0 = mk3(r0.x, r0.y, r0.z);
             const f3 a1 = mk3(r0.w, r1.x, r1.y);
@@ -287,7 +306,7 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
               }
               // a candidate that sorts after the K-th entry of a full queue would fall straight
               // off the end of the insertion network: skip the network for it
-              if (ins && q.admits(K, h.z, f)) q.insert(K, h.z, f, pl);
+              if (ins && q.admits(K, h.z, f) && !(a.debug & 2)) q.insert(K, h.z, f, pl);
             }
           }
         }
@@ -296,14 +315,24 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
     __syncthreads();
   }
 
-  if (pix_ok) {
+  if (pix_ok && !(a.debug & 4)) {
     const int64_t opix = ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi);
     write_pixel<Queue, KT, IN_REGS>(a, q, opix);
   }
 }
 
 template <bool BINNED>
-int launch_mesh_raster(const MeshArgs& a, hipStream_t stream) {
+int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
+  MeshArgs a = a0;
+  {
+    const char* e = getenv("P3D_DEBUG_FWD");
+    a.debug = e ? atoi(e) : 0;
+    if (!(a.debug & 8)) {
+      const long long tpb = (long long)a.Ty * a.Tx;
+      const long long bins = a.total_tiles / tpb;
+      a.tiles_per_xcd = ceil_div(bins, 8) * tpb;
+    }
+  }
   const unsigned grid = (unsigned)(a.tiles_per_xcd * 8);
   const char* name = BINNED ? "mesh_fine" : "mesh_naive";
   LaunchScope ls(name, stream);

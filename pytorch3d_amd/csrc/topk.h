@@ -79,6 +79,10 @@ struct TopKReg {
     return (cz < z[KT - 1]) || (cz == z[KT - 1] && cidx < idx[KT - 1]);
   }
 
+  // Depth a candidate must not exceed to enter the queue: the K-th entry's z, +inf while the queue
+  // has room (exact when K == KT; +inf, i.e. no information, when K < KT).
+  P3D_HDM float kth_z(int /*K*/) const { return z[KT - 1]; }
+
   // Position of primitive `want` in the queue, or -1.
   P3D_HDM int find(int want) const {
     int at = -1;
@@ -145,6 +149,8 @@ struct TopKMem {
     if (n < K) return true;
     return (cz < z[K - 1]) || (cz == z[K - 1] && cidx < idx[K - 1]);
   }
+
+  P3D_HDM float kth_z(int K) const { return n < K ? INFINITY : z[K - 1]; }
 
   P3D_HDM int find(int want) const {
     for (int k = 0; k < n; ++k)
