@@ -47,7 +47,7 @@ struct MeshArgs {
   long long tiles_per_xcd;
   float blur, sqrt_blur;
   int persp, clip, cull;
-  int debug;  // P3D_DEBUG_FWD ablation bits (profiles/ablate.py): 1 no per-pixel evaluation, 2 no queue insertion, 4 no stores, 8 contiguous tile->XCD order, 16 no depth cull
+  int debug;  // P3D_DEBUG_FWD ablation bits (profiles/ablate.py): 1 no per-pixel evaluation, 2 no queue insertion, 4 no stores, 8 contiguous tile->XCD order, 16 no depth cull, 32 no front-to-back order
   int64_t* p2f;
   float* zbuf;
   float* bary;
@@ -157,7 +157,8 @@ template <typename Queue, int KT, bool IN_REGS, bool BINNED>
 __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_kernel(MeshArgs a) {
   __shared__ float4 s_box[kStage];       // xlo, xhi, ylo, yhi (blur-expanded)
   __shared__ float4 s_vert[kStage][3];   // v0x v0y v0z v1x | v1y v1z v2x v2y | v2z idx nb -
-  __shared__ float s_zc[kStage];         // depth-cull key: every sample of the face has z >= s_zc (or -inf)
+  __shared__ __align__(16) float s_zc[kStage];  // depth-cull key: every sample of the face has z >= s_zc (or -inf)
+  __shared__ int s_order[kStage];        // visiting order of the staged faces: ascending s_zc when order is free
   __shared__ int s_wcnt[kStage / kWave];
 
   // XCD-aware tile order: consecutive logical tiles (which share a bin's face list) run on the
@@ -248,8 +249,10 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
       if (j < w) pos += c;
       staged += c;
     }
+    bool has_nb = false;
     if (keep) {
       const int nb = (int)a.neighbor[fid];
+      has_nb = nb != -1;
       s_box[pos] = make_float4(fs.xlo, fs.xhi, fs.ylo, fs.yhi);
       s_vert[pos][0] = make_float4(v0.x, v0.y, v0.z, v1.x);
       s_vert[pos][1] = make_float4(v1.y, v1.z, v2.x, v2.y);
@@ -263,20 +266,48 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
       const float zmin = min3(v0.z, v1.z, v2.z);
       s_zc[pos] = (clip && nb == -1 && zmin >= 1e-3f) ? zmin * 0.999998f : -INFINITY;
     }
+    // The K nearest under the total order (z, face index) do not depend on the order faces are
+    // offered in -- except through the clipped-neighbour rule.  A staged chunk without neighbour
+    // faces is therefore visited front to back (ascending depth key), which lets the depth cull
+    // discard almost everything behind the first K layers; a chunk with neighbour faces keeps
+    // the reference's ascending-index order.
+    const bool sorted = __syncthreads_or(has_nb ? 1 : 0) == 0 && !(a.debug & 32);
+    if (tid < staged) {
+      int rank = tid;
+      if (sorted) {
+        const float key = s_zc[tid];
+        rank = 0;
+        for (int j0 = 0; j0 < staged; j0 += 4) {
+          const float4 z4 = *reinterpret_cast<const float4*>(&s_zc[j0]);
+          const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u;
+            rank += (j < staged && (zz[u] < key || (zz[u] == key && j < tid))) ? 1 : 0;
+          }
+        }
+      }
+      s_order[rank] = tid;
+    }
     __syncthreads();
 
     // ---- per wave: sub-tile cull 64 faces at a time, then per-pixel evaluation -----------
     if (wave_ok) {
       for (int jb = 0; jb < staged; jb += kWave) {
+        // sorted chunk: once the nearest remaining face is too deep for every pixel of this wave,
+        // so is everything behind it
+        if (sorted && __ballot(pix_ok && !(s_zc[s_order[jb]] > q.kth_z(K))) == 0) break;
         const int j = jb + lane;
         bool touch = false;
+        int oj = 0;
         if (j < staged) {
-          const float4 b = s_box[j];
+          oj = s_order[j];
+          const float4 b = s_box[oj];
           touch = !(sub_x0 > b.y || sub_x1 < b.x || sub_y0 > b.w || sub_y1 < b.z);
         }
         unsigned long long cand = __ballot(touch);
         while (cand) {
-          const int jj = jb + __builtin_ctzll(cand);
+          const int jj = __builtin_amdgcn_readlane(oj, __builtin_ctzll(cand));
           cand &= cand - 1;
           const float4 b = s_box[jj];
           const bool out = p.x > b.y || p.x < b.x || p.y > b.w || p.y < b.z;
