@@ -21,6 +21,7 @@
 #include "p3d_geom.h"
 #include "topk.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace p3d {
@@ -45,9 +46,11 @@ struct MeshArgs {
   int bin_size, BH, BW, Ty, Tx;
   long long total_tiles;
   long long tiles_per_xcd;
+  long long bin_mult;  // odd multiplier coprime to the bin count: dispatch order -> bin (scatters busy and empty bins)
   float blur, sqrt_blur;
   int persp, clip, cull;
-  int debug;  // P3D_DEBUG_FWD ablation bits (profiles/ablate.py): 1 no per-pixel evaluation, 2 no queue insertion, 4 no stores, 8 contiguous tile->XCD order, 16 no depth cull, 32 no front-to-back order
+  int debug;  // P3D_DEBUG_FWD ablation bits (profiles/ablate.py): 1 no per-pixel evaluation, 2 no queue insertion, 4 no stores, 8 contiguous tile->XCD order, 16 no depth cull, 32 no front-to-back order, 64 print work statistics, 128 no bin permutation
+  unsigned long long* counters;  // debug bit 64: per-launch statistics (see launch_mesh_raster)
   int64_t* p2f;
   float* zbuf;
   float* bary;
@@ -168,7 +171,14 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
     // bins round-robin over the XCDs, the tiles of one bin adjacent on one XCD
     const int tpb = a.Ty * a.Tx;
     const long long slot = blockIdx.x / 8;
-    lt = ((slot / tpb) * 8 + (blockIdx.x % 8)) * tpb + slot % tpb;
+    long long bin = (slot / tpb) * 8 + (blockIdx.x % 8);
+    const long long bins = a.total_tiles / tpb;
+    if (bin >= bins) return;
+    // Busy bins (the projected mesh) and empty bins (background, pure -1 stores) come in long
+    // runs in (n, by, bx) order; an affine permutation of the bin index makes every CU hold a
+    // mix of both at any time, so the store-bound and the ALU-bound tiles overlap.
+    if (!(a.debug & 128)) bin = (long long)(((unsigned long long)bin * (unsigned long long)a.bin_mult) % (unsigned long long)bins);
+    lt = bin * tpb + slot % tpb;
   }
   if (lt >= a.total_tiles) return;
   long long t = lt;
@@ -219,6 +229,7 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
   Queue q;
   q.init();
   const int K = a.K;
+  unsigned long long c_cand = 0, c_body = 0, c_lanes = 0, c_hit = 0, c_ins = 0, c_staged = 0, c_groups = 0;
   const bool persp = a.persp != 0, clip = a.clip != 0, cull = a.cull != 0;
 
   for (int base = 0; base < count; base += kStage) {
@@ -291,12 +302,14 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
     }
     __syncthreads();
 
+    c_staged += staged;
     // ---- per wave: sub-tile cull 64 faces at a time, then per-pixel evaluation -----------
     if (wave_ok) {
       for (int jb = 0; jb < staged; jb += kWave) {
         // sorted chunk: once the nearest remaining face is too deep for every pixel of this wave,
         // so is everything behind it
         if (sorted && __ballot(pix_ok && !(s_zc[s_order[jb]] > q.kth_z(K))) == 0) break;
+        ++c_groups;
         const int j = jb + lane;
         bool touch = false;
         int oj = 0;
@@ -309,9 +322,15 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
         while (cand) {
           const int jj = __builtin_amdgcn_readlane(oj, __builtin_ctzll(cand));
           cand &= cand - 1;
+          ++c_cand;
           const float4 b = s_box[jj];
           const bool out = p.x > b.y || p.x < b.x || p.y > b.w || p.y < b.z;
           const bool too_deep = s_zc[jj] > q.kth_z(K) && !(a.debug & 16);
+          if (a.debug & 64) {
+            const unsigned long long m = __ballot(pix_ok && !out && !too_deep);
+            c_body += m != 0;
+            c_lanes += __popcll(m);
+          }
           if (pix_ok && !out && !too_deep && !(a.debug & 1)) {
             const float4 r0 = s_vert[jj][0], r1 = s_vert[jj][1], r2 = s_vert[jj][2];
             const f3 a0 = mk3(r0.x, r0.y, r0.z);
@@ -319,6 +338,7 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
             const f3 a2 = mk3(r1.z, r1.w, r2.x);
             FaceHit h;
             if (face_hit(a0, a1, a2, p, a.blur, persp, clip, &h)) {
+              ++c_hit;
               const int f = __float_as_int(r2.y);
               const int nb = __float_as_int(r2.z);
               const float pl[kMeshPayload] = {h.dist, h.bary.x, h.bary.y, h.bary.z};
@@ -337,7 +357,10 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
               }
               // a candidate that sorts after the K-th entry of a full queue would fall straight
               // off the end of the insertion network: skip the network for it
-              if (ins && q.admits(K, h.z, f) && !(a.debug & 2)) q.insert(K, h.z, f, pl);
+              if (ins && q.admits(K, h.z, f) && !(a.debug & 2)) {
+                ++c_ins;
+                q.insert(K, h.z, f, pl);
+              }
             }
           }
         }
@@ -346,6 +369,20 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
     __syncthreads();
   }
 
+  if ((a.debug & 64) && a.counters) {
+    // [0] waves, [1] staged faces (per wave), [2] 64-face groups, [3] candidate iterations, [4] iterations whose
+    // body ran, [5] lanes active in those bodies, [6] lane-level hits, [7] lane-level insertions
+    if (lane == 0) {
+      atomicAdd(&a.counters[0], 1ull);
+      atomicAdd(&a.counters[1], c_staged);
+      atomicAdd(&a.counters[2], c_groups);
+      atomicAdd(&a.counters[3], c_cand);
+      atomicAdd(&a.counters[4], c_body);
+      atomicAdd(&a.counters[5], c_lanes);
+    }
+    atomicAdd(&a.counters[6], c_hit);
+    atomicAdd(&a.counters[7], c_ins);
+  }
   if (pix_ok && !(a.debug & 4)) {
     const int64_t opix = ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi);
     write_pixel<Queue, KT, IN_REGS>(a, q, opix);
@@ -362,10 +399,45 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
       const long long tpb = (long long)a.Ty * a.Tx;
       const long long bins = a.total_tiles / tpb;
       a.tiles_per_xcd = ceil_div(bins, 8) * tpb;
+      // multiplier near bins / golden ratio, coprime to bins
+      long long m = (long long)((double)bins * 0.6180339887) | 1;
+      auto gcd = [](long long x, long long y) {
+        while (y) {
+          const long long t = x % y;
+          x = y;
+          y = t;
+        }
+        return x;
+      };
+      while (m > 1 && gcd(m, bins) != 1) m += 2;
+      a.bin_mult = m > 0 ? m : 1;
     }
   }
   const unsigned grid = (unsigned)(a.tiles_per_xcd * 8);
   const char* name = BINNED ? "mesh_fine" : "mesh_naive";
+  struct Stats {  // debug bit 64 only: synchronous, prints to stderr
+    unsigned long long* dev = nullptr;
+    hipStream_t s;
+    ~Stats() {
+      if (!dev) return;
+      unsigned long long h[8];
+      hipStreamSynchronize(s);
+      hipMemcpy(h, dev, sizeof(h), hipMemcpyDeviceToHost);
+      hipFree(dev);
+      fprintf(stderr,
+              "[p3d fwd stats] waves %llu | staged faces/wave %.1f | groups/wave %.2f | candidate iters/wave %.1f | body "
+              "iters/wave %.1f | lanes per body %.1f | hits/lane %.2f | inserts/lane %.2f\n",
+              h[0], (double)h[1] / h[0], (double)h[2] / h[0], (double)h[3] / h[0], (double)h[4] / h[0],
+              h[4] ? (double)h[5] / h[4] : 0.0, (double)h[6] / (h[0] * 64.0), (double)h[7] / (h[0] * 64.0));
+    }
+  } stats;
+  stats.s = stream;
+  a.counters = nullptr;
+  if (a.debug & 64) {
+    hipMalloc(&stats.dev, 8 * sizeof(unsigned long long));
+    hipMemsetAsync(stats.dev, 0, 8 * sizeof(unsigned long long), stream);
+    a.counters = stats.dev;
+  }
   LaunchScope ls(name, stream);
   const int K = a.K;
   if (K == 1)
