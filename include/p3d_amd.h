@@ -93,6 +93,17 @@ int p3d_rasterize_meshes_backward(const float* face_verts, const int64_t* pix_to
                                   int perspective_correct, int clip_barycentric_coords, float* grad_face_verts,
                                   p3d_stream_t stream);
 
+/* ---- packed vertices <-> per-face vertices (optional fast path of the L2 function) ------ */
+
+/* replaces the Python-side gather `face_verts = verts_packed[faces_packed]`
+ * (pytorch3d/renderer/mesh/rasterize_meshes.py:144-148): verts (V,3) f32, faces (F,3) i64 -> face_verts (F,3,3). */
+int p3d_gather_face_verts(const float* verts, const int64_t* faces, int64_t V, int64_t F, float* face_verts,
+                          p3d_stream_t stream);
+/* its autograd backward (torch: index_put_ accumulate, a sort on ROCm): grad_verts (V,3) is zeroed and
+ * accumulated here with f32 atomics (order not deterministic). */
+int p3d_scatter_face_grads(const float* grad_face_verts, const int64_t* faces, int64_t V, int64_t F, float* grad_verts,
+                           p3d_stream_t stream);
+
 /* ---- point clouds -------------------------------------------------------------------- */
 
 size_t p3d_rasterize_points_workspace_bytes(int64_t P, int N, int H, int W, int bin_size, int max_points_per_bin);

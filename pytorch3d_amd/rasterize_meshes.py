@@ -56,7 +56,7 @@ def rasterize_meshes(
             "use the reference's rasterize_meshes over pytorch3d_amd.shim.install()")
     verts_packed = meshes.verts_packed()
     faces_packed = meshes.faces_packed()
-    face_verts = verts_packed[faces_packed]
+    face_verts = gather_face_verts(verts_packed, faces_packed)
     mesh_to_face_first_idx = meshes.mesh_to_faces_packed_first_idx()
     num_faces_per_mesh = meshes.num_faces_per_mesh()
     im_size = parse_image_size(image_size)
@@ -80,6 +80,52 @@ def rasterize_meshes(
                                      max_faces_per_bin, perspective_correct, clip_barycentric_coords, cull_backfaces)
 
 
+def gather_face_verts(verts_packed, faces_packed):
+    """`verts_packed[faces_packed]` (rasterize_meshes.py:146) -> (F, 3, 3).  On the GPU both the gather and its
+    autograd scatter are single HIP kernels (include/p3d_amd.h: p3d_gather_face_verts / p3d_scatter_face_grads)
+    instead of torch indexing, whose backward on ROCm is a radix sort + segmented sum."""
+    if (verts_packed.is_cuda and verts_packed.dtype == torch.float32 and faces_packed.dtype == torch.int64
+            and faces_packed.device == verts_packed.device and verts_packed.dim() == 2 and faces_packed.dim() == 2):
+        return _GatherFaceVerts.apply(verts_packed, faces_packed)
+    return verts_packed[faces_packed]
+
+
+class _GatherFaceVerts(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, verts, faces):
+        import ctypes
+
+        from . import _lib
+
+        lib = _lib.load()
+        verts_c, faces_c = verts.contiguous(), faces.contiguous()
+        V, F = verts_c.shape[0], faces_c.shape[0]
+        with torch.cuda.device(verts.device):
+            out = torch.empty((F, 3, 3), dtype=torch.float32, device=verts.device)
+            if F:
+                rc = lib.p3d_gather_face_verts(_C._ptr(verts_c), _C._ptr(faces_c), V, F, _C._ptr(out),
+                                               _C._stream(verts.device))
+                _lib.check(rc, "gather_face_verts")
+        ctx.save_for_backward(faces_c)
+        ctx.V = V
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_face_verts):
+        from . import _lib
+
+        (faces,) = ctx.saved_tensors
+        lib = _lib.load()
+        g = grad_face_verts.contiguous()
+        V, F = ctx.V, faces.shape[0]
+        with torch.cuda.device(g.device):
+            out = torch.empty((V, 3), dtype=torch.float32, device=g.device)
+            if V:
+                rc = lib.p3d_scatter_face_grads(_C._ptr(g), _C._ptr(faces), V, F, _C._ptr(out), _C._stream(g.device))
+                _lib.check(rc, "scatter_face_grads")
+        return out, None
+
+
 class _RasterizeFaceVerts(torch.autograd.Function):
     """Autograd wrapper, as rasterize_meshes.py:252-357."""
 
@@ -93,6 +139,8 @@ class _RasterizeFaceVerts(torch.autograd.Function):
             cull_backfaces)
         ctx.save_for_backward(face_verts, pix_to_face)
         ctx.mark_non_differentiable(pix_to_face)
+        # do not let autograd materialise a zero "gradient" for the int64 pix_to_face (1 GB at the bench size)
+        ctx.set_materialize_grads(False)
         ctx.perspective_correct = perspective_correct
         ctx.clip_barycentric_coords = clip_barycentric_coords
         return pix_to_face, zbuf, barycentric_coords, dists
@@ -100,6 +148,15 @@ class _RasterizeFaceVerts(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_pix_to_face, grad_zbuf, grad_barycentric_coords, grad_dists):
         face_verts, pix_to_face = ctx.saved_tensors
+        if grad_zbuf is None and grad_barycentric_coords is None and grad_dists is None:
+            return (None,) * 12
+        if grad_zbuf is None:
+            grad_zbuf = torch.zeros(pix_to_face.shape, dtype=torch.float32, device=pix_to_face.device)
+        if grad_dists is None:
+            grad_dists = torch.zeros(pix_to_face.shape, dtype=torch.float32, device=pix_to_face.device)
+        if grad_barycentric_coords is None:
+            grad_barycentric_coords = torch.zeros(pix_to_face.shape + (3,), dtype=torch.float32,
+                                                  device=pix_to_face.device)
         grad_face_verts = _C.rasterize_meshes_backward(face_verts, pix_to_face, grad_zbuf, grad_barycentric_coords,
                                                        grad_dists, ctx.perspective_correct,
                                                        ctx.clip_barycentric_coords)
