@@ -1,0 +1,135 @@
+#!/usr/bin/env python
+"""Per-kernel timing of the other BASELINE configs (the headline config 3 is bench.py) on one MI355X.
+
+    python profiles/bench_configs.py            -> one JSON line per config
+
+config 2: one ~5k-face mesh (ico_sphere(4), 5120 faces -- the cow OBJ lives in the reference checkout, which
+          does not exist on the GPU box), 256x256, K=8, blur 1e-4, coarse + fine forward
+config 4: 1M points, 512x512, K=10, r=0.01, rasterize_points fwd+bwd + alpha compositor fwd+bwd (C=3)
+interp  : interpolate_face_attributes fwd+bwd, D=3, on the config-3 fragments (P = 64*512*512*8)
+Kernel times are HIP events on the launch stream (p3d_profile_*); GB/s = algorithmic bytes / time.
+"""
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+PEAK = 8000.0
+
+
+def timed(lib, _lib, fn, iters=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    lib.p3d_profile_reset()
+    lib.p3d_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / iters * 1e3
+    lib.p3d_profile_enable(0)
+    prof = _lib.profile_snapshot()
+    return wall, {k: ms / n for k, (n, ms) in prof.items()}
+
+
+def main():
+    import _util as U
+    import pytorch3d_amd as p3d
+    from pytorch3d_amd import _C, _lib
+
+    lib = _lib.load()
+    d = torch.device("cuda:0")
+    out = []
+
+    # ---- config 2 ---------------------------------------------------------------------------------
+    v, f = U.ico_sphere(4)
+    m = p3d.PackedMeshes([U.to_ndc(v).to(d)], [f.to(d)])
+    H = W = 256
+    K = 8
+
+    def c2():
+        return p3d.rasterize_meshes(m, image_size=H, blur_radius=1e-4, faces_per_pixel=K, perspective_correct=True,
+                                    clip_barycentric_coords=True)
+
+    wall, k = timed(lib, _lib, c2, iters=20)
+    alg = H * W * K * 28 + f.shape[0] * 44 + 16
+    kern = sum(k.values())
+    out.append({"config": "2: ico_sphere(4) 5120 faces, 256x256, K=8, blur 1e-4, coarse+fine fwd", "wall_ms": wall,
+                "kernels_ms": k, "kernel_sum_ms": kern, "algorithmic_bytes": alg,
+                "GBps_over_kernel_sum": alg / kern / 1e6, "Mpix_per_s_wall": H * W / wall / 1e3})
+
+    # ---- config 4 ---------------------------------------------------------------------------------
+    gen = torch.Generator().manual_seed(0)
+    P = 1_000_000
+    pts = torch.cat([torch.rand(P, 2, generator=gen) * 2 - 1, torch.rand(P, 1, generator=gen) * 2 + 0.5], 1).to(d)
+    feats = torch.rand(P, 3, generator=gen).to(d)
+    H = W = 512
+    K = 10
+    r = 0.01
+    pts_g = pts.clone().requires_grad_(True)
+    feats_g = feats.clone().requires_grad_(True)
+    g_img = torch.randn(1, 3, H, W, generator=gen).to(d)
+
+    def c4():
+        pts_g.grad = None
+        feats_g.grad = None
+        pc = p3d.PackedPointclouds([pts_g])
+        idx, zbuf, dists = p3d.rasterize_points(pc, image_size=H, radius=r, points_per_pixel=K)
+        weights = 1 - dists.permute(0, 3, 1, 2) / (r * r)  # points/renderer.py:64-65
+        img = p3d.alpha_composite(idx.long().permute(0, 3, 1, 2), weights, feats_g.permute(1, 0))
+        img.backward(g_img)
+        return idx
+
+    wall, k = timed(lib, _lib, c4, iters=5)
+    idx = c4()
+    fill = float((idx >= 0).float().mean())
+    px = H * W
+    alg = {"points_fine": px * K * 12 + P * 16, "points_backward": px * K * 12 + P * 24,
+           "composite_forward": px * K * 12 + min(px * K, P) * 12 + px * 12,
+           "composite_backward": px * K * 12 + min(px * K, P) * 12 + px * 12 + px * K * 4 + P * 12}
+    out.append({"config": "4: 1M points, 512x512, K=10, r=0.01, rasterize fwd+bwd + alpha composite fwd+bwd (C=3)",
+                "wall_ms": wall, "kernels_ms": k, "kernel_sum_ms": sum(k.values()), "slot_fill": fill,
+                "algorithmic_bytes": alg,
+                "GBps": {n: alg[n] / k[n] / 1e6 for n in alg if n in k},
+                "Mpix_per_s_wall": px / wall / 1e3})
+
+    # ---- interp on config-3 fragments ----------------------------------------------------------------
+    verts, faces = U.hetero_batch(64, seed=0)
+    m3 = p3d.PackedMeshes([x.to(d) for x in verts], [x.to(d) for x in faces])
+    blur = math.log(1.0 / 1e-4 - 1.0) * 1e-4
+    p2f, zbuf, bary, dists = p3d.rasterize_meshes(m3, image_size=512, blur_radius=blur, faces_per_pixel=8,
+                                                  perspective_correct=True, clip_barycentric_coords=True)
+    del zbuf, dists
+    F = m3.faces_packed().shape[0]
+    D = 3
+    attrs = torch.rand(F, 3, D, generator=gen).to(d).requires_grad_(True)
+    bary_g = bary.detach().requires_grad_(True)
+    g_out = torch.randn(64, 512, 512, 8, D, generator=gen).to(d)
+
+    def ci():
+        attrs.grad = None
+        bary_g.grad = None
+        o = p3d.interpolate_face_attributes(p2f, bary_g, attrs)
+        o.backward(g_out)
+
+    wall, k = timed(lib, _lib, ci, iters=3, warm=1)
+    Pn = p2f.numel()
+    alg = {"interp_forward": Pn * (8 + 12 + D * 4) + F * 3 * D * 4,
+           "interp_backward": Pn * (8 + 12 + D * 4 + 12) + 2 * F * 3 * D * 4}
+    out.append({"config": "interp_face_attrs fwd+bwd, D=3, on config-3 fragments (P=134M)", "wall_ms": wall,
+                "kernels_ms": k, "algorithmic_bytes": alg,
+                "GBps": {n: alg[n] / k[n] / 1e6 for n in alg if n in k},
+                "frac_of_hbm_peak": {n: alg[n] / k[n] / 1e6 / PEAK for n in alg if n in k}})
+    for o in out:
+        print(json.dumps(o), flush=True)
+
+
+if __name__ == "__main__":
+    main()

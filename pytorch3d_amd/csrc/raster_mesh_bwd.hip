@@ -27,6 +27,7 @@
 // (rasterize_meshes.cu:587 alertNotDeterministic).
 #include "p3d_common.h"
 #include "p3d_geom.h"
+#include "wave_table.h"
 
 #include <stdlib.h>
 
@@ -34,10 +35,9 @@ namespace p3d {
 
 namespace {
 
-constexpr int kRegion = 32;   // pixels per workgroup-region side (four 16x16 wave areas)
-constexpr int kSlots = 232;   // hash-table slots per wave: 4 waves x 232 x 44 B = 40832 B -> 4 workgroups per CU
-constexpr int kFlushAt = kSlots - 64;  // a step adds at most 64 faces: the table can never overflow
-constexpr int kEmptyKey = -1;
+constexpr int kRegion = 32;  // pixels per workgroup-region side (four 16x16 wave areas)
+// 4 waves x 232 slots x (8 + 9*4) B = 40832 B of LDS -> 4 workgroups per CU
+using FaceTable = WaveTable<9, 232>;
 
 struct BwdArgs {
   const float* face_verts;
@@ -51,10 +51,6 @@ struct BwdArgs {
   int persp, clip;
   int debug;  // P3D_DEBUG_BWD ablation bits (profiles/ablate.py): 1 no compute, 2 no accumulate, 4 no vertex gathers
 };
-
-__device__ __forceinline__ int hash_face(int f) {
-  return (int)(((unsigned long long)((unsigned)f * 2654435761u) * (unsigned)kSlots) >> 32);
-}
 
 // Row loaders: KT contiguous elements starting at a (KT * elemsize)-aligned address.
 template <int KT>
@@ -96,98 +92,14 @@ __device__ __forceinline__ void load_f32_row(const float* p, float (&out)[M]) {
   }
 }
 
-// Wave-private accumulation table (LDS).
-struct Table {
-  volatile int* keys;   // [kSlots] face id or kEmptyKey (volatile: other lanes of the wave write it between my store and my re-load)
-  volatile int* owner;  // [kSlots] scratch for the per-step visitor lists, -1 between steps
-  float* vals;          // [9][kSlots]
-};
-
-__device__ __forceinline__ float lane_read(float v, int src_lane) {
-  return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
-}
-
-// Flush every occupied slot with global atomics and empty the table.  All 64 lanes.
-__device__ __forceinline__ void flush_table(const Table& t, float* __restrict__ grad_fv, int lane) {
-  for (int s = lane; s < kSlots; s += 64) {
-    const int f = t.keys[s];
-    if (f != kEmptyKey) {
-      float* o = grad_fv + (int64_t)f * 9;
-#pragma unroll
-      for (int j = 0; j < 9; ++j) unsafeAtomicAdd(o + j, t.vals[j * kSlots + s]);
-      t.keys[s] = kEmptyKey;
-    }
-  }
-}
-
-// One K slot of one 8x8 tile: every lane with f >= 0 contributes r to face f.  Must be called by
-// all 64 lanes (wave-uniform control flow).  Returns the number of table slots newly occupied.
-__device__ __forceinline__ int accumulate_step(const Table& t, int lane, int f, FaceGrad& r) {
-  const bool active = f >= 0;
-  // ---- locate / claim the face's slot.  All lanes of one face probe in lockstep (same hash,
-  // same sequence), so they see the same thing at every probe.
-  int slot = -1;
-  bool fresh = false;
-  if (active) {
-    int h = hash_face(f);
-    for (;;) {
-      const int cur = t.keys[h];
-      if (cur == f) {
-        slot = h;
-        break;
-      }
-      if (cur == kEmptyKey) {
-        t.keys[h] = f;  // several faces may race for one empty slot: the last store wins
-        if (t.keys[h] == f) {
-          slot = h;
-          fresh = true;
-          break;
-        }
-      }
-      h = (h + 1 == kSlots) ? 0 : h + 1;
-    }
-  }
-  // ---- link the visitors of each slot: prev = the lane that visited before me (or -1).
-  int prev = -1;
-  if (active) prev = atomicExch(const_cast<int*>(&t.owner[slot]), lane);
-  const bool head = active && t.owner[slot] == lane;  // the last visitor heads the list
-  // ---- sum along the lists by pointer jumping: after step s every lane holds the sum of the
-  // 2^s list entries starting at itself, so the head ends with the group total.
-  while (__ballot(prev >= 0)) {
-    const int src = prev >= 0 ? prev : lane;
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      const float o = lane_read(r.g[j], src);
-      if (prev >= 0) r.g[j] += o;
-    }
-    const int pp = __builtin_amdgcn_ds_bpermute(src << 2, prev);
-    prev = prev >= 0 ? pp : -1;
-  }
-  // ---- heads fold their total into the table (distinct faces -> distinct slots: plain ld/st)
-  if (head) {
-    t.owner[slot] = -1;
-    if (fresh) {
-#pragma unroll
-      for (int j = 0; j < 9; ++j) t.vals[j * kSlots + slot] = r.g[j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 9; ++j) t.vals[j * kSlots + slot] += r.g[j];
-    }
-  }
-  return __popcll(__ballot(head && fresh));
-}
-
 // KT > 0: K == KT, rows read with vector loads.  KT == 0: any K, per-slot scalar loads.
 template <int KT>
 __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
-  __shared__ int s_keys[4][kSlots];
-  __shared__ int s_owner[4][kSlots];
-  __shared__ float s_vals[4][9 * kSlots];
+  __shared__ int s_table[4][FaceTable::kLdsInts];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = tid >> 6;
-  const Table tab{s_keys[w], s_owner[w], s_vals[w]};
   // region of this workgroup, 16x16 area of this wave
   long long t = blockIdx.x;
   const int rx = (int)(t % a.RX);
@@ -199,12 +111,9 @@ __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
   const int H = a.H, W = a.W, K = a.K;
   if (ay >= H || ax >= W) return;  // wave-uniform; no workgroup barriers in this kernel
 
-  for (int i = lane; i < kSlots; i += 64) {
-    tab.keys[i] = kEmptyKey;
-    tab.owner[i] = -1;
-  }
+  FaceTable tab;
+  tab.init(s_table[w], lane);
   const bool persp = a.persp != 0, clip = a.clip != 0;
-  int used = 0;  // occupied slots (wave-uniform)
 
 #pragma unroll 1
   for (int tile = 0; tile < 4; ++tile) {
@@ -251,11 +160,7 @@ __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
           if (f[k] >= 0 && r.g[0] == 1234.5f) a.grad_fv[0] = r.g[1];
           continue;
         }
-        if (used > kFlushAt) {
-          flush_table(tab, a.grad_fv, lane);
-          used = 0;
-        }
-        used += accumulate_step(tab, lane, f[k], r);
+        tab.add(a.grad_fv, lane, f[k], r.g);
       }
     } else {
 #pragma unroll 1
@@ -272,15 +177,11 @@ __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
           const f3 gb = mk3(a.grad_bary[i * 3 + 0], a.grad_bary[i * 3 + 1], a.grad_bary[i * 3 + 2]);
           r = face_sample_bwd(v0, v1, v2, p, a.grad_zbuf[i], gb, a.grad_dists[i], persp, clip, false);
         }
-        if (used > kFlushAt) {
-          flush_table(tab, a.grad_fv, lane);
-          used = 0;
-        }
-        used += accumulate_step(tab, lane, f, r);
+        tab.add(a.grad_fv, lane, f, r.g);
       }
     }
   }
-  if (used > 0) flush_table(tab, a.grad_fv, lane);
+  if (tab.used > 0) tab.flush(a.grad_fv, lane);
 }
 
 }  // namespace
