@@ -18,6 +18,7 @@
 //
 // The SoftRas backward lives in raster_mesh_bwd.hip.
 #include "binning.h"
+#include "tile_map.h"
 #include "p3d_geom.h"
 #include "topk.h"
 
@@ -43,13 +44,10 @@ struct MeshArgs {
   const int64_t* mesh_count;
   BinCSR csr;
   int N, H, W, K;
-  int bin_size, BH, BW, Ty, Tx;
-  long long total_tiles;
-  long long tiles_per_xcd;
-  long long bin_mult;  // odd multiplier coprime to the bin count: dispatch order -> bin (scatters busy and empty bins)
+  TileMap tm;
   float blur, sqrt_blur;
   int persp, clip, cull;
-  int debug;  // P3D_DEBUG_FWD ablation bits (profiles/ablate.py): 1 no per-pixel evaluation, 2 no queue insertion, 4 no stores, 8 contiguous tile->XCD order, 16 no depth cull, 32 no front-to-back order, 64 print work statistics, 128 no bin permutation
+  int debug;  // P3D_DEBUG_FWD ablation bits (profiles/ablate.py): 1 no per-pixel evaluation, 2 no queue insertion, 4 no stores, 16 no depth cull, 32 no front-to-back order, 64 print work statistics, 128 no bin permutation
   unsigned long long* counters;  // debug bit 64: per-launch statistics (see launch_mesh_raster)
   int64_t* p2f;
   float* zbuf;
@@ -164,38 +162,15 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
   __shared__ int s_order[kStage];        // visiting order of the staged faces: ascending s_zc when order is free
   __shared__ int s_wcnt[kStage / kWave];
 
-  // XCD-aware tile order: consecutive logical tiles (which share a bin's face list) run on the
-  // same XCD and hit the same L2 (workgroup b is dispatched to XCD b % 8).
-  long long lt = (long long)(blockIdx.x % 8) * a.tiles_per_xcd + (long long)(blockIdx.x / 8);
-  if (!(a.debug & 8)) {
-    // bins round-robin over the XCDs, the tiles of one bin adjacent on one XCD
-    const int tpb = a.Ty * a.Tx;
-    const long long slot = blockIdx.x / 8;
-    long long bin = (slot / tpb) * 8 + (blockIdx.x % 8);
-    const long long bins = a.total_tiles / tpb;
-    if (bin >= bins) return;
-    // Busy bins (the projected mesh) and empty bins (background, pure -1 stores) come in long
-    // runs in (n, by, bx) order; an affine permutation of the bin index makes every CU hold a
-    // mix of both at any time, so the store-bound and the ALU-bound tiles overlap.
-    if (!(a.debug & 128)) bin = (long long)(((unsigned long long)bin * (unsigned long long)a.bin_mult) % (unsigned long long)bins);
-    lt = bin * tpb + slot % tpb;
-  }
-  if (lt >= a.total_tiles) return;
-  long long t = lt;
-  const int tx = (int)(t % a.Tx);
-  t /= a.Tx;
-  const int ty = (int)(t % a.Ty);
-  t /= a.Ty;
-  const int bx = (int)(t % a.BW);
-  t /= a.BW;
-  const int by = (int)(t % a.BH);
-  const int n = (int)(t / a.BH);
+  TileCoord tc;
+  if (!tile_of_block(a.tm, blockIdx.x, &tc)) return;
+  const int n = tc.n, by = tc.by, bx = tc.bx, ty = tc.ty, tx = tc.tx;
 
   const int H = a.H, W = a.W;
-  const int y_end = min(H, (by + 1) * a.bin_size);
-  const int x_end = min(W, (bx + 1) * a.bin_size);
-  const int ty0 = by * a.bin_size + ty * kTile;
-  const int tx0 = bx * a.bin_size + tx * kTile;
+  const int y_end = min(H, (by + 1) * a.tm.bin_size);
+  const int x_end = min(W, (bx + 1) * a.tm.bin_size);
+  const int ty0 = by * a.tm.bin_size + ty * kTile;
+  const int tx0 = bx * a.tm.bin_size + tx * kTile;
   if (ty0 >= y_end || tx0 >= x_end) return;  // tile has no pixel (uniform)
 
   const int tid = threadIdx.x;
@@ -218,7 +193,7 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
   int64_t src_base;
   int count;
   if (BINNED) {
-    const int64_t row = ((int64_t)n * a.BH + by) * a.BW + bx;
+    const int64_t row = ((int64_t)n * a.tm.BH + by) * a.tm.BW + bx;
     src_base = a.csr.offset[row];
     count = a.csr.total[row];
   } else {
@@ -395,25 +370,9 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
   {
     const char* e = getenv("P3D_DEBUG_FWD");
     a.debug = e ? atoi(e) : 0;
-    if (!(a.debug & 8)) {
-      const long long tpb = (long long)a.Ty * a.Tx;
-      const long long bins = a.total_tiles / tpb;
-      a.tiles_per_xcd = ceil_div(bins, 8) * tpb;
-      // multiplier near bins / golden ratio, coprime to bins
-      long long m = (long long)((double)bins * 0.6180339887) | 1;
-      auto gcd = [](long long x, long long y) {
-        while (y) {
-          const long long t = x % y;
-          x = y;
-          y = t;
-        }
-        return x;
-      };
-      while (m > 1 && gcd(m, bins) != 1) m += 2;
-      a.bin_mult = m > 0 ? m : 1;
-    }
+    if (a.debug & 128) a.tm.bin_mult = 1;
   }
-  const unsigned grid = (unsigned)(a.tiles_per_xcd * 8);
+  const unsigned grid = tile_grid(a.tm);
   const char* name = BINNED ? "mesh_fine" : "mesh_naive";
   struct Stats {  // debug bit 64 only: synchronous, prints to stderr
     unsigned long long* dev = nullptr;
@@ -453,17 +412,7 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
   return launch_status();
 }
 
-void set_tiles(MeshArgs* a, int bin_size, int BH, int BW) {
-  a->bin_size = bin_size;
-  a->BH = BH;
-  a->BW = BW;
-  const int span_y = bin_size < a->H ? bin_size : a->H;
-  const int span_x = bin_size < a->W ? bin_size : a->W;
-  a->Ty = (int)ceil_div(span_y, kTile);
-  a->Tx = (int)ceil_div(span_x, kTile);
-  a->total_tiles = (long long)a->N * BH * BW * a->Ty * a->Tx;
-  a->tiles_per_xcd = ceil_div(a->total_tiles, 8);
-}
+void set_tiles(MeshArgs* a, int bin_size, int BH, int BW) { a->tm = make_tile_map(a->N, a->H, a->W, bin_size, BH, BW, true); }
 
 int check_common(int N, int H, int W, int K) {
   if (N < 0 || H < 0 || W < 0 || K < 0) return P3D_ERR_INVALID_ARG;

@@ -10,6 +10,7 @@
 // (z, point index) -- the CPU variant's tuple order (rasterize_points_cpu.cpp:55-75); the CUDA
 // variant compares z only and leaves ties to the (unspecified) bin order.
 #include "binning.h"
+#include "tile_map.h"
 #include "p3d_geom.h"
 #include "topk.h"
 
@@ -27,9 +28,7 @@ struct PointArgs {
   const int64_t* count;
   BinCSR csr;
   int N, H, W, K;
-  int bin_size, BH, BW, Ty, Tx;
-  long long total_tiles;
-  long long tiles_per_xcd;
+  TileMap tm;
   int32_t* idxs;
   float* zbuf;
   float* dists;
@@ -42,23 +41,15 @@ __global__ __launch_bounds__(kStage) void point_raster_kernel(PointArgs a) {
   __shared__ int s_idx[kStage];
   __shared__ int s_wcnt[kStage / kWave];
 
-  const long long lt = (long long)(blockIdx.x % 8) * a.tiles_per_xcd + (long long)(blockIdx.x / 8);
-  if (lt >= a.total_tiles) return;
-  long long t = lt;
-  const int tx = (int)(t % a.Tx);
-  t /= a.Tx;
-  const int ty = (int)(t % a.Ty);
-  t /= a.Ty;
-  const int bx = (int)(t % a.BW);
-  t /= a.BW;
-  const int by = (int)(t % a.BH);
-  const int n = (int)(t / a.BH);
+  TileCoord tc;
+  if (!tile_of_block(a.tm, blockIdx.x, &tc)) return;
+  const int n = tc.n, by = tc.by, bx = tc.bx, ty = tc.ty, tx = tc.tx;
 
   const int H = a.H, W = a.W;
-  const int y_end = min(H, (by + 1) * a.bin_size);
-  const int x_end = min(W, (bx + 1) * a.bin_size);
-  const int ty0 = by * a.bin_size + ty * kTile;
-  const int tx0 = bx * a.bin_size + tx * kTile;
+  const int y_end = min(H, (by + 1) * a.tm.bin_size);
+  const int x_end = min(W, (bx + 1) * a.tm.bin_size);
+  const int ty0 = by * a.tm.bin_size + ty * kTile;
+  const int tx0 = bx * a.tm.bin_size + tx * kTile;
   if (ty0 >= y_end || tx0 >= x_end) return;
 
   const int tid = threadIdx.x;
@@ -81,7 +72,7 @@ __global__ __launch_bounds__(kStage) void point_raster_kernel(PointArgs a) {
   int64_t src_base;
   int count;
   if (BINNED) {
-    const int64_t row = ((int64_t)n * a.BH + by) * a.BW + bx;
+    const int64_t row = ((int64_t)n * a.tm.BH + by) * a.tm.BW + bx;
     src_base = a.csr.offset[row];
     count = a.csr.total[row];
   } else {
@@ -181,7 +172,7 @@ __global__ __launch_bounds__(kStage) void point_raster_kernel(PointArgs a) {
 
 template <bool BINNED>
 int launch_point_raster(const PointArgs& a, hipStream_t stream) {
-  const unsigned grid = (unsigned)(a.tiles_per_xcd * 8);
+  const unsigned grid = tile_grid(a.tm);
   LaunchScope ls(BINNED ? "points_fine" : "points_naive", stream);
   const int K = a.K;
   if (K == 1)
@@ -199,17 +190,7 @@ int launch_point_raster(const PointArgs& a, hipStream_t stream) {
   return launch_status();
 }
 
-void set_tiles(PointArgs* a, int bin_size, int BH, int BW) {
-  a->bin_size = bin_size;
-  a->BH = BH;
-  a->BW = BW;
-  const int span_y = bin_size < a->H ? bin_size : a->H;
-  const int span_x = bin_size < a->W ? bin_size : a->W;
-  a->Ty = (int)ceil_div(span_y, kTile);
-  a->Tx = (int)ceil_div(span_x, kTile);
-  a->total_tiles = (long long)a->N * BH * BW * a->Ty * a->Tx;
-  a->tiles_per_xcd = ceil_div(a->total_tiles, 8);
-}
+void set_tiles(PointArgs* a, int bin_size, int BH, int BW) { a->tm = make_tile_map(a->N, a->H, a->W, bin_size, BH, BW, true); }
 
 __global__ __launch_bounds__(256) void point_backward_kernel(const float* __restrict__ points,
                                                              const int32_t* __restrict__ idxs,

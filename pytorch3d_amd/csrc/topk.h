@@ -29,6 +29,11 @@ struct TopKReg {
   int idx[KT];
   float pl[NP][KT];
 
+  // (kz, ki): the K-th entry of the live queue -- what a candidate has to beat -- cached so that the
+  // admission test is one compare also when K < KT (+inf / kEmptyIdx while the queue has room).
+  float kz;
+  int ki;
+
   P3D_HDM void init() {
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
@@ -36,6 +41,23 @@ struct TopKReg {
       idx[k] = kEmptyIdx;
 #pragma unroll
       for (int p = 0; p < NP; ++p) pl[p][k] = -1.0f;
+    }
+    kz = INFINITY;
+    ki = kEmptyIdx;
+  }
+
+  P3D_HDM void refresh_kth(int K) {
+    if (K >= KT) {
+      kz = z[KT - 1];
+      ki = idx[KT - 1];
+    } else {
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        if (k == K - 1) {
+          kz = z[k];
+          ki = idx[k];
+        }
+      }
     }
   }
 
@@ -71,17 +93,14 @@ struct TopKReg {
         }
       }
     }
+    refresh_kth(K);
   }
 
-  // Cheap pre-test: can (cz, cidx) enter the queue at all?  Exact when K == KT (slot KT-1 is the
-  // K-th entry); when K < KT that slot is always empty and the test passes (insert() sorts it out).
-  P3D_HDM bool admits(int /*K*/, float cz, int cidx) const {
-    return (cz < z[KT - 1]) || (cz == z[KT - 1] && cidx < idx[KT - 1]);
-  }
+  // Exact pre-test: can (cz, cidx) enter the queue at all?
+  P3D_HDM bool admits(int /*K*/, float cz, int cidx) const { return (cz < kz) || (cz == kz && cidx < ki); }
 
-  // Depth a candidate must not exceed to enter the queue: the K-th entry's z, +inf while the queue
-  // has room (exact when K == KT; +inf, i.e. no information, when K < KT).
-  P3D_HDM float kth_z(int /*K*/) const { return z[KT - 1]; }
+  // Depth a candidate must not exceed to enter the queue: the K-th entry's z, +inf while the queue has room.
+  P3D_HDM float kth_z(int /*K*/) const { return kz; }
 
   // Position of primitive `want` in the queue, or -1.
   P3D_HDM int find(int want) const {
@@ -115,6 +134,8 @@ struct TopKReg {
     }
     z[KT - 1] = INFINITY;
     idx[KT - 1] = kEmptyIdx;
+    kz = INFINITY;  // the queue has room again
+    ki = kEmptyIdx;
   }
 
   P3D_HDM bool valid(int k) const { return idx[k] != kEmptyIdx; }
