@@ -50,6 +50,17 @@ P3D_HD f3 mk3(float x, float y, float z) {
   return r;
 }
 
+// Division for GRADIENT arithmetic only (tolerance-gated, rtol 2e-3 in the reference's own tests):
+// on the device one v_rcp_f32 (1 ulp) + one multiply instead of the 11-instruction IEEE sequence.
+// Everything that decides pix_to_face / zbuf / bary / dists keeps IEEE division.
+template <bool FAST>
+P3D_HD float qdiv(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (FAST) return a * __builtin_amdgcn_rcpf(b);
+#endif
+  return a / b;
+}
+
 P3D_HD float min3(float a, float b, float c) { return fminf(a, fminf(b, c)); }
 P3D_HD float max3(float a, float b, float c) { return fmaxf(a, fmaxf(b, c)); }
 // __saturatef semantics: clamp to [+0, 1], NaN -> +0.
@@ -92,32 +103,35 @@ P3D_HD float edge_fn(f2 p, f2 a, f2 b) { return (p.x - a.x) * (b.y - a.y) - (p.y
 // area = float(double(edge) + 1e-8): one double add, then narrowing.
 P3D_HD float bary_area(f2 v0, f2 v1, f2 v2) { return (float)((double)edge_fn(v2, v0, v1) + P3D_KEPS); }
 
+template <bool FAST = false>
 P3D_HD f3 bary_coords(f2 p, f2 v0, f2 v1, f2 v2) {
   const float area = bary_area(v0, v1, v2);
-  const float w0 = edge_fn(p, v1, v2) / area;
-  const float w1 = edge_fn(p, v2, v0) / area;
-  const float w2 = edge_fn(p, v0, v1) / area;
+  const float w0 = qdiv<FAST>(edge_fn(p, v1, v2), area);
+  const float w1 = qdiv<FAST>(edge_fn(p, v2, v0), area);
+  const float w2 = qdiv<FAST>(edge_fn(p, v0, v1), area);
   return mk3(w0, w1, w2);
 }
 
 // Perspective correction (geometry_utils.cuh:172-185).  Product order is the
 // CUDA one: (b.x*z1)*z2, (z0*b.y)*z2, (z0*z1)*b.z.
+template <bool FAST = false>
 P3D_HD f3 bary_perspective(f3 b, float z0, float z1, float z2) {
   const float t0 = b.x * z1 * z2;
   const float t1 = z0 * b.y * z2;
   const float t2 = z0 * z1 * b.z;
   const float denom = fmaxf(t0 + t1 + t2, (float)P3D_KEPS);
-  return mk3(t0 / denom, t1 / denom, t2 / denom);
+  return mk3(qdiv<FAST>(t0, denom), qdiv<FAST>(t1, denom), qdiv<FAST>(t2, denom));
 }
 
 // Clip to >= 0 and renormalise (geometry_utils.cuh:246-259).
+template <bool FAST = false>
 P3D_HD f3 bary_clip(f3 b) {
   float w0 = b.x > 0.0f ? b.x : 0.0f;
   float w1 = b.y > 0.0f ? b.y : 0.0f;
   float w2 = b.z > 0.0f ? b.z : 0.0f;
   float s = w0 + w1 + w2;
   s = fmaxf(s, 1e-5f);
-  return mk3(w0 / s, w1 / s, w2 / s);
+  return mk3(qdiv<FAST>(w0, s), qdiv<FAST>(w1, s), qdiv<FAST>(w2, s));
 }
 
 // Squared distance from p to segment (a, b) (geometry_utils.cuh:340-352).
@@ -235,25 +249,26 @@ P3D_HD TriGrad bary_coords_bwd(f2 p, f2 v0, f2 v1, f2 v2, f3 g) {
   const float e0 = edge_fn(p, v1, v2);
   const float e1 = edge_fn(p, v2, v0);
   const float e2 = edge_fn(p, v0, v1);
-  const float inv_area = 1.0f / area;
+  const float inv_area = qdiv<true>(1.0f, area);
+  const float inv_area2 = qdiv<true>(1.0f, area2);
 
   // w0 = e0(p, v1, v2) / area(v2, v0, v1)
   const EdgeGrad n0 = edge_fn_bwd(p, v1, v2, g.x * inv_area);
-  const EdgeGrad a0 = edge_fn_bwd(v2, v0, v1, g.x * (-e0 / area2));
+  const EdgeGrad a0 = edge_fn_bwd(v2, v0, v1, g.x * (-e0 * inv_area2));
   const f2 w0_v0 = a0.da;
   const f2 w0_v1 = add2(n0.da, a0.db);
   const f2 w0_v2 = add2(n0.db, a0.dp);
 
   // w1 = e1(p, v2, v0) / area
   const EdgeGrad n1 = edge_fn_bwd(p, v2, v0, g.y * inv_area);
-  const EdgeGrad a1 = edge_fn_bwd(v2, v0, v1, g.y * (-e1 / area2));
+  const EdgeGrad a1 = edge_fn_bwd(v2, v0, v1, g.y * (-e1 * inv_area2));
   const f2 w1_v0 = add2(n1.db, a1.da);
   const f2 w1_v1 = a1.db;
   const f2 w1_v2 = add2(n1.da, a1.dp);
 
   // w2 = e2(p, v0, v1) / area
   const EdgeGrad n2 = edge_fn_bwd(p, v0, v1, g.z * inv_area);
-  const EdgeGrad a2 = edge_fn_bwd(v2, v0, v1, g.z * (-e2 / area2));
+  const EdgeGrad a2 = edge_fn_bwd(v2, v0, v1, g.z * (-e2 * inv_area2));
   const f2 w2_v0 = add2(n2.da, a2.da);
   const f2 w2_v1 = add2(n2.db, a2.db);
   const f2 w2_v2 = a2.dp;
@@ -276,10 +291,11 @@ P3D_HD PerspGrad bary_perspective_bwd(f3 b, float z0, float z1, float z2, f3 g) 
   const float t2 = z0 * z1 * b.z;
   const float denom = fmaxf(t0 + t1 + t2, (float)P3D_KEPS);
   const float gd_top = -t0 * g.x - t1 * g.y - t2 * g.z;
-  const float gd = gd_top / (denom * denom);
-  const float g0 = gd + g.x / denom;
-  const float g1 = gd + g.y / denom;
-  const float g2 = gd + g.z / denom;
+  const float inv_denom = qdiv<true>(1.0f, denom);
+  const float gd = gd_top * (inv_denom * inv_denom);
+  const float g0 = gd + g.x * inv_denom;
+  const float g1 = gd + g.y * inv_denom;
+  const float g2 = gd + g.z * inv_denom;
   PerspGrad r;
   r.dbary = mk3(g0 * z1 * z2, g1 * z0 * z2, g2 * z0 * z1);
   r.dz0 = g1 * b.y * z2 + g2 * b.z * z1;
@@ -301,11 +317,11 @@ P3D_HD f3 bary_clip_bwd(f3 b, f3 g) {
   const float m0 = b.x < 0.0f ? 0.0f : 1.0f;
   const float m1 = b.y < 0.0f ? 0.0f : 1.0f;
   const float m2 = b.z < 0.0f ? 0.0f : 1.0f;
-  const float s2 = s * s;
-  const float q0 = -w0 / s2 * live;
-  const float q1 = -w1 / s2 * live;
-  const float q2 = -w2 / s2 * live;
-  const float inv = 1.0f / s;
+  const float inv = qdiv<true>(1.0f, s);
+  const float inv_s2 = inv * inv;
+  const float q0 = -w0 * inv_s2 * live;
+  const float q1 = -w1 * inv_s2 * live;
+  const float q2 = -w2 * inv_s2 * live;
   return mk3(m0 * (g.x * (inv + q0) + g.y * q1 + g.z * q2), m1 * (g.y * (inv + q1) + g.x * q0 + g.z * q2),
              m2 * (g.z * (inv + q2) + g.x * q0 + g.y * q1));
 }
@@ -319,7 +335,7 @@ P3D_HD SegGrad seg_dist2_bwd(f2 p, f2 a, f2 b, float g) {
   const float bay = b.y - a.y;
   const float bot = bax * bax + bay * bay;
   const float top = bax * (p.x - a.x) + bay * (p.y - a.y);
-  const float tt = sat01(top / bot);
+  const float tt = sat01(qdiv<true>(top, bot));
   const float dx = ((1.0f - tt) * a.x + tt * b.x) - p.x;
   const float dy = ((1.0f - tt) * a.y + tt * b.y) - p.y;
   const float sa = g * (1.0f - tt) * 2.0f;
@@ -371,9 +387,11 @@ P3D_HD FaceGrad face_sample_bwd(f3 v0, f3 v1, f3 v2, f2 p, float g_zbuf, f3 g_ba
   const f2 a = mk2(v0.x, v0.y);
   const f2 b = mk2(v1.x, v1.y);
   const f2 c = mk2(v2.x, v2.y);
-  const f3 bw = bary_coords(p, a, b, c);
-  const f3 bp = perspective_correct ? bary_perspective(bw, v0.z, v1.z, v2.z) : bw;
-  const f3 bc = clip_bary ? bary_clip(bp) : bp;
+  // forward recompute: only signs of bw / bp decide anything here (inside test, clip masks), and the
+  // sign of a quotient does not depend on how the division rounds
+  const f3 bw = bary_coords<true>(p, a, b, c);
+  const f3 bp = perspective_correct ? bary_perspective<true>(bw, v0.z, v1.z, v2.z) : bw;
+  const f3 bc = clip_bary ? bary_clip<true>(bp) : bp;
   const bool inside = bp.x > 0.0f && bp.y > 0.0f && bp.z > 0.0f;
   const float sign = inside ? -1.0f : 1.0f;
 
