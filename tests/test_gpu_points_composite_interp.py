@@ -197,3 +197,124 @@ def test_interp_mirror_shapes_and_grads():
     assert torch.allclose(oa, ga, atol=1e-4) and torch.allclose(ob, gb, atol=1e-5)
     with pytest.raises(ValueError):
         p3d.interpolate_face_attributes(p2f[0], bary, attrs)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE full sizes: the oracle is too slow there, so check size-independent properties
+# ---------------------------------------------------------------------------------------------
+def test_config4_points_properties_at_full_size():
+    """BASELINE configs[3]: 1M points, 512x512, K=10, r=0.01.  Two different binnings must agree bit for bit;
+    every slot is sorted by (z, idx), points lie within r of the pixel centre, zbuf is the point's own z,
+    the backward equals the closed form 2*g*(p - pix) accumulated per point (checked through a dense
+    re-derivation from the forward outputs with torch ops)."""
+    from pytorch3d_amd import _C
+
+    d = _dev()
+    gen = torch.Generator().manual_seed(0)
+    P, H, W, K, r = 1_000_000, 512, 512, 10, 0.01
+    pts = torch.cat([torch.rand(P, 2, generator=gen) * 2 - 1, torch.rand(P, 1, generator=gen) * 2 + 0.5], 1).to(d)
+    first = torch.zeros(1, dtype=torch.int64, device=d)
+    count = torch.full((1,), P, dtype=torch.int64, device=d)
+    radius = torch.full((P,), r, device=d)
+    a = _C.rasterize_points(pts, first, count, (H, W), radius, K, 32, 200000)
+    b = _C.rasterize_points(pts, first, count, (H, W), radius, K, 64, 400000)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    idx, zbuf, dists = a
+    valid = idx >= 0
+    assert valid.float().mean() > 0.99  # ~78 points cover every pixel
+    assert (dists[valid] < r * r).all() and (dists[valid] >= 0).all()
+    li = idx.long().clamp(min=0)
+    assert torch.equal(zbuf[valid], pts[:, 2][li][valid])
+    z = torch.where(valid, zbuf, torch.full_like(zbuf, float("inf")))
+    assert (z[..., 1:] >= z[..., :-1]).all()
+    tie = (z[..., 1:] == z[..., :-1]) & valid[..., 1:]
+    assert (idx[..., 1:][tie] > idx[..., :-1][tie]).all()
+    # dists re-derived from the indices: pixel centres with the flipped axes (rasterize_points.cu:117-121)
+    ys = torch.arange(H, device=d, dtype=torch.float32)
+    xs = torch.arange(W, device=d, dtype=torch.float32)
+    py = (1.0 - (2.0 * ys + 1.0) / H).view(1, H, 1, 1)
+    px = (1.0 - (2.0 * xs + 1.0) / W).view(1, 1, W, 1)
+    dx = pts[:, 0][li] - px
+    dy = pts[:, 1][li] - py
+    assert torch.allclose((dx * dx + dy * dy)[valid], dists[valid], atol=1e-6, rtol=0)
+    # backward vs the closed form (rasterize_points.cu:402-409), accumulated with index_add in float64
+    gz = torch.randn(idx.shape, generator=gen).to(d)
+    gd = torch.randn(idx.shape, generator=gen).to(d)
+    got = _C.rasterize_points_backward(pts, idx, gz, gd)
+    ref = torch.zeros(P, 3, dtype=torch.float64, device=d)
+    w = valid.double()
+    ref[:, 0].index_add_(0, li.reshape(-1), (2.0 * gd.double() * dx.double() * w).reshape(-1))
+    ref[:, 1].index_add_(0, li.reshape(-1), (2.0 * gd.double() * dy.double() * w).reshape(-1))
+    ref[:, 2].index_add_(0, li.reshape(-1), (gz.double() * w).reshape(-1))
+    assert torch.allclose(got.double(), ref, atol=5e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("mode", ["alphacomposite", "weightedsumnorm", "weightedsum"])
+def test_config4_compositor_properties_at_full_size(mode):
+    """512x512, K=10, P=1M, C=3 on permuted (N,H,W,K) views: linear in the features; forward equals a
+    dense torch re-derivation; backward equals torch autograd of that re-derivation."""
+    from pytorch3d_amd import _C
+
+    d = _dev()
+    gen = torch.Generator().manual_seed(1)
+    N, H, W, K, P, C = 1, 512, 512, 10, 1_000_000, 3
+    idx = torch.randint(-1, P, (N, H, W, K), generator=gen).to(d).permute(0, 3, 1, 2)
+    # alphas < 0.95: the reference's alpha backward divides by (1 - alpha + 1e-9) (alpha_composite.cu:20,135), which
+    # only equals the analytic derivative away from alpha = 1
+    alphas = (torch.rand(N, H, W, K, generator=gen) * 0.95).to(d).permute(0, 3, 1, 2)
+    f1 = torch.rand(C, P, generator=gen).to(d)
+    f2 = torch.rand(C, P, generator=gen).to(d)
+    fwd = getattr(_C, "accum_" + mode)
+    o1, o2, o12 = fwd(f1, alphas, idx), fwd(f2, alphas, idx), fwd(f1 + f2, alphas, idx)
+    assert torch.allclose(o1 + o2, o12, atol=1e-5, rtol=1e-5)
+
+    def dense(feats, al):
+        ok = (idx >= 0).float()
+        g = feats[:, idx.clamp(min=0)]  # (C, N, K, H, W)
+        a = al * ok
+        if mode == "alphacomposite":
+            one_minus = torch.where(idx >= 0, 1 - al, torch.ones_like(al))
+            cum = torch.cumprod(torch.cat([torch.ones_like(al[:, :1]), one_minus[:, :-1]], 1), 1)
+            wgt = a * cum
+        elif mode == "weightedsumnorm":
+            wgt = a / a.sum(1, keepdim=True).clamp(min=1e-4)
+        else:
+            wgt = a
+        return (g * wgt.unsqueeze(0)).sum(2).permute(1, 0, 2, 3)
+
+    fr = f1.clone().requires_grad_(True)
+    ar = alphas.clone().requires_grad_(True)
+    ref = dense(fr, ar)
+    assert torch.allclose(o1, ref, atol=2e-5, rtol=1e-5)
+    go = torch.randn(ref.shape, generator=gen).to(d)
+    ref.backward(go)
+    gf, ga = getattr(_C, "accum_" + mode + "_backward")(go, f1, alphas, idx)
+    assert torch.allclose(gf, fr.grad, atol=1e-4, rtol=1e-4)
+    assert torch.allclose(ga, ar.grad, atol=1e-4, rtol=1e-3)
+
+
+def test_interp_properties_at_full_fragment_size():
+    """P = 16 x 512 x 512 x 8 = 33.5M samples (a quarter of the bench fragments), D = 3: forward equals the torch
+    gather formula (interp_face_attrs.py:86-102), backward equals its autograd."""
+    from pytorch3d_amd import _C
+
+    d = _dev()
+    gen = torch.Generator().manual_seed(2)
+    Pn, F, D = 16 * 512 * 512 * 8, 100_000, 3
+    # runs of equal faces, like real fragments, with 60% background
+    base = torch.randint(0, F, (Pn // 16,), generator=gen).repeat_interleave(16)
+    p2f = torch.where(torch.rand(Pn, generator=gen) < 0.6, torch.full((Pn,), -1), base).to(d)
+    bary = torch.rand(Pn, 3, generator=gen).to(d)
+    attrs = torch.randn(F, 3, D, generator=gen).to(d)
+    out = _C.interp_face_attrs_forward(p2f, bary, attrs)
+    br = bary.clone().requires_grad_(True)
+    ar = attrs.clone().requires_grad_(True)
+    ok = (p2f >= 0).float().view(-1, 1)
+    ref = (br.unsqueeze(-1) * ar[p2f.clamp(min=0)]).sum(1) * ok
+    assert torch.allclose(out, ref, atol=1e-5, rtol=1e-5)
+    g = torch.randn(Pn, D, generator=gen).to(d)
+    ref.backward(g)
+    gb, ga = _C.interp_face_attrs_backward(p2f, bary, attrs, g)
+    assert torch.allclose(gb, br.grad, atol=1e-5, rtol=1e-5)
+    assert torch.allclose(ga, ar.grad, atol=2e-3, rtol=2e-3)
