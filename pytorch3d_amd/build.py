@@ -52,7 +52,8 @@ def build(force=False, verbose=False):
 
     def compile_one(src):
         obj = os.path.join(objdir, src + ".o")
-        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        extra = os.environ.get("P3D_EXTRA_FLAGS", "").split()  # e.g. -DP3D_FWD_STATS, -DP3D_FINE_WAVES_PER_SIMD=3
+        cmd = [hipcc] + FLAGS + extra + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

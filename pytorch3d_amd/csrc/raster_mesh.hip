@@ -47,7 +47,7 @@ struct MeshArgs {
   TileMap tm;
   float blur, sqrt_blur;
   int persp, clip, cull;
-  int debug;  // P3D_DEBUG_FWD ablation bits (profiles/ablate.py): 1 no per-pixel evaluation, 2 no queue insertion, 4 no stores, 16 no depth cull, 32 no front-to-back order, 64 print work statistics, 128 no bin permutation
+  int debug;  // P3D_DEBUG_FWD ablation bits (profiles/ablate.py): 1 no per-pixel evaluation, 2 no queue insertion, 4 no stores, 16 no depth cull, 32 no front-to-back order, 64 print work statistics (build with -DP3D_FWD_STATS), 128 no bin permutation
   unsigned long long* counters;  // debug bit 64: per-launch statistics (see launch_mesh_raster)
   int64_t* p2f;
   float* zbuf;
@@ -204,7 +204,12 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
   Queue q;
   q.init();
   const int K = a.K;
+#ifdef P3D_FWD_STATS
   unsigned long long c_cand = 0, c_body = 0, c_lanes = 0, c_hit = 0, c_ins = 0, c_staged = 0, c_groups = 0;
+#define P3D_STAT(x) x
+#else
+#define P3D_STAT(x)
+#endif
   const bool persp = a.persp != 0, clip = a.clip != 0, cull = a.cull != 0;
 
   for (int base = 0; base < count; base += kStage) {
@@ -277,14 +282,14 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
     }
     __syncthreads();
 
-    c_staged += staged;
+    P3D_STAT(c_staged += staged);
     // ---- per wave: sub-tile cull 64 faces at a time, then per-pixel evaluation -----------
     if (wave_ok) {
       for (int jb = 0; jb < staged; jb += kWave) {
         // sorted chunk: once the nearest remaining face is too deep for every pixel of this wave,
         // so is everything behind it
         if (sorted && __ballot(pix_ok && !(s_zc[s_order[jb]] > q.kth_z(K))) == 0) break;
-        ++c_groups;
+        P3D_STAT(++c_groups);
         const int j = jb + lane;
         bool touch = false;
         int oj = 0;
@@ -297,15 +302,17 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
         while (cand) {
           const int jj = __builtin_amdgcn_readlane(oj, __builtin_ctzll(cand));
           cand &= cand - 1;
-          ++c_cand;
+          P3D_STAT(++c_cand);
           const float4 b = s_box[jj];
           const bool out = p.x > b.y || p.x < b.x || p.y > b.w || p.y < b.z;
           const bool too_deep = s_zc[jj] > q.kth_z(K) && !(a.debug & 16);
+#ifdef P3D_FWD_STATS
           if (a.debug & 64) {
             const unsigned long long m = __ballot(pix_ok && !out && !too_deep);
             c_body += m != 0;
             c_lanes += __popcll(m);
           }
+#endif
           if (pix_ok && !out && !too_deep && !(a.debug & 1)) {
             const float4 r0 = s_vert[jj][0], r1 = s_vert[jj][1], r2 = s_vert[jj][2];
             const f3 a0 = mk3(r0.x, r0.y, r0.z);
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
             const f3 a2 = mk3(r1.z, r1.w, r2.x);
             FaceHit h;
             if (face_hit(a0, a1, a2, p, a.blur, persp, clip, &h)) {
-              ++c_hit;
+              P3D_STAT(++c_hit);
               const int f = __float_as_int(r2.y);
               const int nb = __float_as_int(r2.z);
               const float pl[kMeshPayload] = {h.dist, h.bary.x, h.bary.y, h.bary.z};
@@ -333,7 +340,7 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
               // a candidate that sorts after the K-th entry of a full queue would fall straight
               // off the end of the insertion network: skip the network for it
               if (ins && q.admits(K, h.z, f) && !(a.debug & 2)) {
-                ++c_ins;
+                P3D_STAT(++c_ins);
                 q.insert(K, h.z, f, pl);
               }
             }
@@ -344,6 +351,7 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
     __syncthreads();
   }
 
+#ifdef P3D_FWD_STATS
   if ((a.debug & 64) && a.counters) {
     // [0] waves, [1] staged faces (per wave), [2] 64-face groups, [3] candidate iterations, [4] iterations whose
     // body ran, [5] lanes active in those bodies, [6] lane-level hits, [7] lane-level insertions
@@ -358,6 +366,7 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
     atomicAdd(&a.counters[6], c_hit);
     atomicAdd(&a.counters[7], c_ins);
   }
+#endif
   if (pix_ok && !(a.debug & 4)) {
     const int64_t opix = ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi);
     write_pixel<Queue, KT, IN_REGS>(a, q, opix);

@@ -62,28 +62,31 @@ struct TopKReg {
   }
 
   // Sorted insertion; the largest entry falls off the end.  `K` <= KT is the live capacity.
+  // Shift formulation: lt[k] = "the candidate sorts before entry k" is monotone in k (the queue is
+  // sorted), so entry k becomes  lt[k] ? (lt[k-1] ? old entry k-1 : candidate) : itself.  All KT
+  // slots update independently of each other (select depth 2) -- a compare-exchange chain that
+  // carries the displaced entry from slot to slot has the same instruction count but a dependency
+  // chain 2*KT long, which a SIMD with 3-4 resident waves cannot hide.
   P3D_HDM void insert(int K, float cz, int cidx, const float (&cpl)[NP]) {
-    float vz = cz;
-    int vi = cidx;
-    float vp[NP];
+    bool lt[KT];
 #pragma unroll
-    for (int p = 0; p < NP; ++p) vp[p] = cpl[p];
+    for (int k = 0; k < KT; ++k) lt[k] = (cz < z[k]) || (cz == z[k] && cidx < idx[k]);
 #pragma unroll
-    for (int k = 0; k < KT; ++k) {
-      const bool lt = (vz < z[k]) || (vz == z[k] && vi < idx[k]);
-      const float tz = z[k];
-      const int ti = idx[k];
-      z[k] = lt ? vz : tz;
-      idx[k] = lt ? vi : ti;
-      vz = lt ? tz : vz;
-      vi = lt ? ti : vi;
+    for (int k = KT - 1; k >= 1; --k) {
+      const float tz = lt[k - 1] ? z[k - 1] : cz;
+      const int ti = lt[k - 1] ? idx[k - 1] : cidx;
+      z[k] = lt[k] ? tz : z[k];
+      idx[k] = lt[k] ? ti : idx[k];
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        const float tp = pl[p][k];
-        pl[p][k] = lt ? vp[p] : tp;
-        vp[p] = lt ? tp : vp[p];
+        const float tp = lt[k - 1] ? pl[p][k - 1] : cpl[p];
+        pl[p][k] = lt[k] ? tp : pl[p][k];
       }
     }
+    z[0] = lt[0] ? cz : z[0];
+    idx[0] = lt[0] ? cidx : idx[0];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) pl[p][0] = lt[0] ? cpl[p] : pl[p][0];
     if (K < KT) {
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
