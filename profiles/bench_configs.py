@@ -77,10 +77,11 @@ def main():
     feats_g = feats.clone().requires_grad_(True)
     g_img = torch.randn(1, 3, H, W, generator=gen).to(d)
 
+    pc = p3d.PackedPointclouds([pts_g])
+
     def c4():
         pts_g.grad = None
         feats_g.grad = None
-        pc = p3d.PackedPointclouds([pts_g])
         idx, zbuf, dists = p3d.rasterize_points(pc, image_size=H, radius=r, points_per_pixel=K)
         weights = 1 - dists.permute(0, 3, 1, 2) / (r * r)  # points/renderer.py:64-65
         img = p3d.alpha_composite(idx.long().permute(0, 3, 1, 2), weights, feats_g.permute(1, 0))
@@ -92,12 +93,13 @@ def main():
     fill = float((idx >= 0).float().mean())
     px = H * W
     alg = {"points_fine": px * K * 12 + P * 16, "points_backward": px * K * 12 + P * 24,
-           "composite_forward": px * K * 12 + min(px * K, P) * 12 + px * 12,
-           "composite_backward": px * K * 12 + min(px * K, P) * 12 + px * 12 + px * K * 4 + P * 12}
+           "alpha_composite_fwd": px * K * 12 + min(px * K, P) * 12 + px * 12,
+           "alpha_composite_bwd": px * K * 12 + min(px * K, P) * 12 + px * 12 + px * K * 4 + P * 12}
     out.append({"config": "4: 1M points, 512x512, K=10, r=0.01, rasterize fwd+bwd + alpha composite fwd+bwd (C=3)",
                 "wall_ms": wall, "kernels_ms": k, "kernel_sum_ms": sum(k.values()), "slot_fill": fill,
                 "algorithmic_bytes": alg,
                 "GBps": {n: alg[n] / k[n] / 1e6 for n in alg if n in k},
+                "frac_of_hbm_peak": {n: alg[n] / k[n] / 1e6 / PEAK for n in alg if n in k},
                 "Mpix_per_s_wall": px / wall / 1e3})
 
     # ---- interp on config-3 fragments ----------------------------------------------------------------
@@ -121,8 +123,8 @@ def main():
 
     wall, k = timed(lib, _lib, ci, iters=3, warm=1)
     Pn = p2f.numel()
-    alg = {"interp_forward": Pn * (8 + 12 + D * 4) + F * 3 * D * 4,
-           "interp_backward": Pn * (8 + 12 + D * 4 + 12) + 2 * F * 3 * D * 4}
+    alg = {"interp_fwd": Pn * (8 + 12 + D * 4) + F * 3 * D * 4,
+           "interp_bwd": Pn * (8 + 12 + D * 4 + 12) + 2 * F * 3 * D * 4}
     out.append({"config": "interp_face_attrs fwd+bwd, D=3, on config-3 fragments (P=134M)", "wall_ms": wall,
                 "kernels_ms": k, "algorithmic_bytes": alg,
                 "GBps": {n: alg[n] / k[n] / 1e6 for n in alg if n in k},

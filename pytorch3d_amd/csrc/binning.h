@@ -52,8 +52,12 @@ size_t bin_workspace_bytes(int64_t E, int N, const BinGeom& g, int M);
 bool bin_carve(Arena& arena, int64_t E, int N, const BinGeom& g, int M, BinWorkspace* ws);
 
 // Build the CSR lists.  elems: face_verts (E,3,3) or points (E,3); aux: radius (E) for points.
+// ordered = false (points only): ids inside a 1024-primitive chunk land in arrival order (integer LDS
+// atomics) instead of ascending order -- for consumers whose result is order-free; which ids survive
+// an overflowing bin (> M) is then unspecified, as in the reference (rasterize_coarse.cu:186-201).
 int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t* first, const int64_t* count, int64_t E,
-              int N, const BinGeom& g, int M, float sqrt_blur, const BinWorkspace& ws, hipStream_t stream);
+              int N, const BinGeom& g, int M, float sqrt_blur, const BinWorkspace& ws, hipStream_t stream,
+              bool ordered = true);
 
 // CSR -> the reference's padded (N,BH,BW,M) int32 layout, -1 filled.
 int bin_expand_padded(const BinWorkspace& ws, int N, const BinGeom& g, int M, int32_t* out, hipStream_t stream);

@@ -168,7 +168,7 @@ __device__ __forceinline__ bool rect_has(const BinRect& r, int by, int bx) {
 // ---------------------------------------------------------------------------------------
 // count: counts[chunk][bin] = members of `bin` among the chunk's 1024 primitives.
 // ---------------------------------------------------------------------------------------
-template <int KIND>
+template <int KIND, bool ORDERED>
 __global__ __launch_bounds__(kBinChunk) void bin_count_kernel(const float* __restrict__ elems,
                                                               const float* __restrict__ aux,
                                                               const int64_t* __restrict__ first,
@@ -185,11 +185,18 @@ __global__ __launch_bounds__(kBinChunk) void bin_count_kernel(const float* __res
                             ylo_t, yhi_t, &c))
     return;
   const int lane = lane_id();
-  for (int by = c.u.y0; by <= c.u.y1; ++by) {
-    for (int bx = c.u.x0; bx <= c.u.x1; ++bx) {
-      const unsigned long long m = __ballot(rect_has(c.r, by, bx));
-      if (lane == 0 && m) atomicAdd(&blk_cnt[by * BW + bx], __popcll(m));
+  if (ORDERED) {
+    for (int by = c.u.y0; by <= c.u.y1; ++by) {
+      for (int bx = c.u.x0; bx <= c.u.x1; ++bx) {
+        const unsigned long long m = __ballot(rect_has(c.r, by, bx));
+        if (lane == 0 && m) atomicAdd(&blk_cnt[by * BW + bx], __popcll(m));
+      }
     }
+  } else {
+    // primitives in arbitrary spatial order (point clouds): the wave's union rectangle is the whole
+    // image, while each primitive touches a handful of bins -- one integer LDS atomic per (primitive, bin)
+    for (int by = c.r.y0; by <= c.r.y1; ++by)
+      for (int bx = c.r.x0; bx <= c.r.x1; ++bx) atomicAdd(&blk_cnt[by * BW + bx], 1);
   }
   __syncthreads();
   int* out = counts + (int64_t)blockIdx.x * nbins;
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(1024) void bin_scan_offsets_kernel(const int* __res
 // ---------------------------------------------------------------------------------------
 // fill: re-derive the ballots and write ids at offset + row prefix + wave prefix + lane rank.
 // ---------------------------------------------------------------------------------------
-template <int KIND>
+template <int KIND, bool ORDERED>
 __global__ __launch_bounds__(kBinChunk) void bin_fill_kernel(const float* __restrict__ elems,
                                                              const float* __restrict__ aux,
                                                              const int64_t* __restrict__ first,
@@ -281,6 +288,23 @@ __global__ __launch_bounds__(kBinChunk) void bin_fill_kernel(const float* __rest
     return;
   const int lane = lane_id();
   const int w = threadIdx.x / kWave;
+  if (!ORDERED) {
+    // unordered placement: slot = chunk's row prefix + arrival order inside the chunk (integer LDS
+    // atomic with return).  The list order inside a chunk is then arbitrary -- only for consumers
+    // whose result does not depend on it (point rasterization: top-K under a total order).
+    int* pos_t = &wcnt[0][0];
+    for (int b = threadIdx.x; b < nbins; b += kBinChunk) pos_t[b] = counts[(int64_t)blockIdx.x * nbins + b];
+    __syncthreads();
+    const int64_t row0u = (int64_t)c.n * nbins;
+    for (int by = c.r.y0; by <= c.r.y1; ++by) {
+      for (int bx = c.r.x0; bx <= c.r.x1; ++bx) {
+        const int b = by * BW + bx;
+        const int pos = atomicAdd(&pos_t[b], 1);
+        if (pos < M) list[offset[row0u + b] + pos] = (int)c.e;
+      }
+    }
+    return;
+  }
   // pass A: per-wave member counts (the prologue's barrier ordered the zero fill)
   for (int by = c.u.y0; by <= c.u.y1; ++by) {
     for (int bx = c.u.x0; bx <= c.u.x1; ++bx) {
@@ -377,7 +401,7 @@ size_t bin_workspace_bytes(int64_t E, int N, const BinGeom& g, int M) {
 }
 
 int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t* first, const int64_t* count, int64_t E,
-              int N, const BinGeom& g, int M, float sqrt_blur, const BinWorkspace& ws, hipStream_t stream) {
+              int N, const BinGeom& g, int M, float sqrt_blur, const BinWorkspace& ws, hipStream_t stream, bool ordered) {
   if (N <= 0) return P3D_OK;
   const int64_t rows = (int64_t)N * g.nbins;
   {
@@ -388,11 +412,16 @@ int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t*
   {
     LaunchScope ls("bin_count", stream);
     if (kind == kTriangles)
-      bin_count_kernel<kTriangles><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, ws.chunk_start, N, g.H,
-                                                                    g.W, g.bin_size, g.BH, g.BW, sqrt_blur, ws.counts);
+      bin_count_kernel<kTriangles, true><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, ws.chunk_start, N,
+                                                                          g.H, g.W, g.bin_size, g.BH, g.BW, sqrt_blur,
+                                                                          ws.counts);
+    else if (ordered)
+      bin_count_kernel<kPoints, true><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, ws.chunk_start, N, g.H,
+                                                                       g.W, g.bin_size, g.BH, g.BW, sqrt_blur, ws.counts);
     else
-      bin_count_kernel<kPoints><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, ws.chunk_start, N, g.H, g.W,
-                                                                 g.bin_size, g.BH, g.BW, sqrt_blur, ws.counts);
+      bin_count_kernel<kPoints, false><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, ws.chunk_start, N,
+                                                                        g.H, g.W, g.bin_size, g.BH, g.BW, sqrt_blur,
+                                                                        ws.counts);
   }
   {
     LaunchScope ls("bin_scan_rows", stream);
@@ -406,13 +435,17 @@ int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t*
   {
     LaunchScope ls("bin_fill", stream);
     if (kind == kTriangles)
-      bin_fill_kernel<kTriangles><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, ws.chunk_start, N, g.H,
-                                                                   g.W, g.bin_size, g.BH, g.BW, sqrt_blur, M, ws.counts,
-                                                                   ws.offset, ws.list);
+      bin_fill_kernel<kTriangles, true><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, ws.chunk_start, N,
+                                                                         g.H, g.W, g.bin_size, g.BH, g.BW, sqrt_blur, M,
+                                                                         ws.counts, ws.offset, ws.list);
+    else if (ordered)
+      bin_fill_kernel<kPoints, true><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, ws.chunk_start, N, g.H,
+                                                                      g.W, g.bin_size, g.BH, g.BW, sqrt_blur, M,
+                                                                      ws.counts, ws.offset, ws.list);
     else
-      bin_fill_kernel<kPoints><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, ws.chunk_start, N, g.H, g.W,
-                                                                g.bin_size, g.BH, g.BW, sqrt_blur, M, ws.counts,
-                                                                ws.offset, ws.list);
+      bin_fill_kernel<kPoints, false><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, ws.chunk_start, N, g.H,
+                                                                       g.W, g.bin_size, g.BH, g.BW, sqrt_blur, M,
+                                                                       ws.counts, ws.offset, ws.list);
   }
   return launch_status();
 }

@@ -279,7 +279,8 @@ P3D_API int p3d_rasterize_points(const float* points, const int64_t* first, cons
   BinWorkspace ws;
   if (!workspace || !bin_carve(arena, P, N, g, max_points_per_bin, &ws)) return P3D_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  int st = bin_build(kPoints, points, radius, first, count, P, N, g, max_points_per_bin, 0.0f, ws, s);
+  // the K nearest under (z, point index) do not depend on the order inside a bin: unordered fast binning
+  int st = bin_build(kPoints, points, radius, first, count, P, N, g, max_points_per_bin, 0.0f, ws, s, /*ordered=*/false);
   if (st != P3D_OK) return st;
   PointArgs a{};
   fill_args(&a, points, radius, N, H, W, K, idxs, zbuf, dists);
