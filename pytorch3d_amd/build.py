@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libp3d_amd.so")
 ARCH = "gfx950"
 
 SOURCES = ["binning.hip", "raster_mesh.hip", "raster_mesh_bwd.hip", "gather.hip", "raster_points.hip", "composite.hip", "interp.hip", "profile.cpp"]
-HEADERS = ["binning.h", "p3d_common.h", "p3d_geom.h", "topk.h", "wave_table.h", "tile_map.h", os.path.join("..", "..", "include", "p3d_amd.h")]
+HEADERS = ["binning.h", "p3d_common.h", "p3d_geom.h", "topk.h", "wave_table.h", "tile_map.h", "chunk_order.h", os.path.join("..", "..", "include", "p3d_amd.h")]
 
 FLAGS = [
     f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off",

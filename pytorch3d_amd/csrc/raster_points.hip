@@ -11,6 +11,7 @@
 // variant compares z only and leaves ties to the (unspecified) bin order.
 #include "binning.h"
 #include "tile_map.h"
+#include "chunk_order.h"
 #include "p3d_geom.h"
 #include "topk.h"
 
@@ -39,6 +40,10 @@ __global__ __launch_bounds__(kStage) void point_raster_kernel(PointArgs a) {
   __shared__ float4 s_box[kStage];  // x-r, x+r, y-r, y+r
   __shared__ float4 s_pt[kStage];   // x, y, z, r*r
   __shared__ int s_idx[kStage];
+  __shared__ float s_key[kStage];   // depth key of the staged point (its z)
+  __shared__ float s_qlow[kStage];  // lower bound of the keys at sorted positions >= i
+  __shared__ int s_order[kStage];
+  __shared__ ChunkOrderScratch s_ord;
   __shared__ int s_wcnt[kStage / kWave];
 
   TileCoord tc;
@@ -115,20 +120,27 @@ __global__ __launch_bounds__(kStage) void point_raster_kernel(PointArgs a) {
       s_box[pos] = make_float4(px - r, px + r, py - r, py + r);
       s_pt[pos] = make_float4(px, py, pz, r * r);
       s_idx[pos] = pid;
+      s_key[pos] = pz;
     }
     __syncthreads();
+    // front-to-back visiting order (chunk_order.h); a point's depth is its sample depth, so the cull is exact
+    chunk_bucket_order(s_key, staged, s_order, s_qlow, s_ord, tid);
 
     if (wave_ok) {
       for (int jb = 0; jb < staged; jb += kWave) {
+        // nothing at or behind sorted position jb can enter any queue of this wave any more
+        if (__ballot(pix_ok && !(s_qlow[jb] > q.kth_z(K))) == 0) break;
         const int j = jb + lane;
         bool touch = false;
+        int oj = 0;
         if (j < staged) {
-          const float4 b = s_box[j];
+          oj = s_order[j];
+          const float4 b = s_box[oj];
           touch = !(sub_x0 > b.y || sub_x1 < b.x || sub_y0 > b.w || sub_y1 < b.z);
         }
         unsigned long long cand = __ballot(touch);
         while (cand) {
-          const int jj = jb + __builtin_ctzll(cand);
+          const int jj = __builtin_amdgcn_readlane(oj, __builtin_ctzll(cand));
           cand &= cand - 1;
           const float4 pt = s_pt[jj];
           const float dx = xf - pt.x;
