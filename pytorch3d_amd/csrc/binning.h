@@ -10,7 +10,11 @@
 namespace p3d {
 
 constexpr int kBinChunk = 1024;  // primitives per workgroup in the count / fill passes
-constexpr int kMaxBins = P3D_MAX_BINS_PER_SIDE * P3D_MAX_BINS_PER_SIDE;
+// The binning kernels handle up to 32 x 32 bins per image: more than the operator interface admits
+// (P3D_MAX_BINS_PER_SIDE = 21, the reference's limit), because the fused rasterizers bin internally
+// at tile granularity (make_internal_geom).
+constexpr int kMaxBinsSide = 32;
+constexpr int kMaxBins = kMaxBinsSide * kMaxBinsSide;
 
 enum BinKind { kTriangles = 0, kPoints = 1 };
 
@@ -29,6 +33,23 @@ inline BinGeom make_geom(int H, int W, int bin_size) {
   return g;
 }
 
+// Geometry the fused operators (rasterize_meshes / rasterize_points with bin_size > 0) bin with.
+// Which bins the coarse stage uses is invisible in their results (the K nearest per pixel do not
+// depend on it), so they use bins of one 16x16 tile -- every workgroup of the fine stage then
+// streams only primitives that touch its own tile, instead of its whole 32x32 (or larger) bin --
+// doubling the bin side until at most 32 bins span the image, and never coarser than the caller's
+// bin_size.  The test-visible _rasterize_*_coarse / _fine operators keep the caller's geometry.
+inline BinGeom make_internal_geom(int H, int W, int user_bin_size) {
+  int b = 16;
+  const int m = H > W ? H : W;
+  while ((m + b - 1) / b > kMaxBinsSide) b *= 2;
+  if (user_bin_size < b) {
+    // the caller asked for finer bins than a tile: honour them when the kernels can (<= 32 per side)
+    if ((m + user_bin_size - 1) / user_bin_size <= kMaxBinsSide) b = user_bin_size;
+  }
+  return make_geom(H, W, b);
+}
+
 // Device-side CSR view consumed by the fine kernels.
 struct BinCSR {
   const int64_t* offset;  // (N*nbins) start of each bin's list inside `list`
@@ -41,6 +62,7 @@ struct BinWorkspace {
   int* counts;       // (max_chunks * nbins)
   int* total;        // (N*nbins)
   int64_t* offset;   // (N*nbins + 1)
+  long long* blocksum;  // (ceil(N*nbins / 1024) + 1) scratch of the offsets scan
   int* list;         // (capacity)
   int64_t max_chunks;
   int64_t capacity;

@@ -234,35 +234,59 @@ __global__ __launch_bounds__(256) void bin_scan_rows_kernel(int* __restrict__ co
 }
 
 // ---------------------------------------------------------------------------------------
-// offsets: exclusive scan of total[] -> offset[] (int64), single workgroup.
+// offsets: exclusive scan of total[] -> offset[] (int64) in two small launches:
+//   A  one workgroup per 1024 rows: block sum -> blocksum[b]
+//   B  the same grid: base = sum of the preceding block sums (<= rows/1024 coalesced adds per
+//      thread), then a local exclusive scan of the block's 1024 rows.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void bin_scan_offsets_kernel(const int* __restrict__ total, int64_t rows,
-                                                                int64_t* __restrict__ offset) {
-  __shared__ int wsum[16];
-  __shared__ long long carry_s;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, w = tid >> 6;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (int64_t base = 0; base < rows; base += 1024) {
-    const int64_t i = base + tid;
-    const int v = i < rows ? total[i] : 0;
-    int x = v;
-    for (int d = 1; d < kWave; d <<= 1) {
-      const int y = __shfl_up(x, d);
-      if (lane >= d) x += y;
-    }
-    if (lane == 63) wsum[w] = x;
-    __syncthreads();
-    int wbase = 0;
-    for (int j = 0; j < w; ++j) wbase += wsum[j];
-    const long long carry = carry_s;
-    if (i < rows) offset[i] = carry + wbase + x - v;
-    __syncthreads();
-    if (tid == 1023) carry_s = carry + wbase + x;
-    __syncthreads();
+__device__ __forceinline__ long long block_exclusive_scan_1024(long long v, long long* wsum, long long* block_total) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  long long x = v;
+  for (int d = 1; d < kWave; d <<= 1) {
+    const long long y = __shfl_up(x, d);
+    if (lane >= d) x += y;
   }
-  if (tid == 0) offset[rows] = carry_s;
+  if (lane == 63) wsum[w] = x;
+  __syncthreads();
+  long long base = 0, all = 0;
+  for (int j = 0; j < 16; ++j) {
+    const long long c = wsum[j];
+    if (j < w) base += c;
+    all += c;
+  }
+  *block_total = all;
+  return base + x - v;
+}
+
+__global__ __launch_bounds__(1024) void bin_block_sums_kernel(const int* __restrict__ total, int64_t rows,
+                                                              long long* __restrict__ blocksum) {
+  __shared__ long long wsum[16];
+  const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+  long long all;
+  block_exclusive_scan_1024(i < rows ? total[i] : 0, wsum, &all);
+  if (threadIdx.x == 0) blocksum[blockIdx.x] = all;
+}
+
+__global__ __launch_bounds__(1024) void bin_scan_offsets_kernel(const int* __restrict__ total, int64_t rows,
+                                                                const long long* __restrict__ blocksum,
+                                                                int64_t* __restrict__ offset) {
+  __shared__ long long wsum[16];
+  __shared__ long long part[16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // base = sum of blocksum[0 .. blockIdx.x)
+  long long acc = 0;
+  for (int j = tid; j < (int)blockIdx.x; j += 1024) acc += blocksum[j];
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+  if (lane == 0) part[w] = acc;
+  __syncthreads();
+  long long base = 0;
+  for (int j = 0; j < 16; ++j) base += part[j];
+  const int64_t i = (int64_t)blockIdx.x * 1024 + tid;
+  const int v = i < rows ? total[i] : 0;
+  long long all;
+  const long long ex = block_exclusive_scan_1024(v, wsum, &all);
+  if (i < rows) offset[i] = base + ex;
+  if (i == rows - 1) offset[rows] = base + ex + v;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -279,9 +303,12 @@ __global__ __launch_bounds__(kBinChunk) void bin_fill_kernel(const float* __rest
                                                              const int64_t* __restrict__ offset,
                                                              int* __restrict__ list) {
   __shared__ float xlo_t[32], xhi_t[32], ylo_t[32], yhi_t[32];
-  __shared__ int wcnt[kWavesPerChunk][kMaxBins];
+  __shared__ unsigned short wpre[ORDERED ? kWavesPerChunk : 1][kMaxBins];  // per-wave counts, then prefixes (<= 1024)
+  __shared__ int base_t[kMaxBins];                                         // this chunk's row prefix per bin
   const int nbins = BH * BW;
-  for (int i = threadIdx.x; i < kWavesPerChunk * kMaxBins; i += kBinChunk) (&wcnt[0][0])[i] = 0;
+  if (ORDERED)
+    for (int i = threadIdx.x; i < kWavesPerChunk * kMaxBins / 2; i += kBinChunk)
+      reinterpret_cast<unsigned*>(&wpre[0][0])[i] = 0u;
   ChunkCtx c;
   if (!chunk_prologue<KIND>(elems, aux, first, count, chunk_start, N, H, W, bin_size, BH, BW, sqrt_blur, xlo_t, xhi_t,
                             ylo_t, yhi_t, &c))
@@ -292,7 +319,7 @@ __global__ __launch_bounds__(kBinChunk) void bin_fill_kernel(const float* __rest
     // unordered placement: slot = chunk's row prefix + arrival order inside the chunk (integer LDS
     // atomic with return).  The list order inside a chunk is then arbitrary -- only for consumers
     // whose result does not depend on it (point rasterization: top-K under a total order).
-    int* pos_t = &wcnt[0][0];
+    int* pos_t = base_t;
     for (int b = threadIdx.x; b < nbins; b += kBinChunk) pos_t[b] = counts[(int64_t)blockIdx.x * nbins + b];
     __syncthreads();
     const int64_t row0u = (int64_t)c.n * nbins;
@@ -309,16 +336,17 @@ __global__ __launch_bounds__(kBinChunk) void bin_fill_kernel(const float* __rest
   for (int by = c.u.y0; by <= c.u.y1; ++by) {
     for (int bx = c.u.x0; bx <= c.u.x1; ++bx) {
       const unsigned long long m = __ballot(rect_has(c.r, by, bx));
-      if (lane == 0) wcnt[w][by * BW + bx] = __popcll(m);
+      if (lane == 0) wpre[w][by * BW + bx] = (unsigned short)__popcll(m);
     }
   }
   __syncthreads();
   // pass B: exclusive prefix over the 16 waves, seeded with this chunk's row prefix
   for (int b = threadIdx.x; b < nbins; b += kBinChunk) {
-    int run = counts[(int64_t)blockIdx.x * nbins + b];
+    base_t[b] = counts[(int64_t)blockIdx.x * nbins + b];
+    int run = 0;
     for (int j = 0; j < kWavesPerChunk; ++j) {
-      const int v = wcnt[j][b];
-      wcnt[j][b] = run;
+      const int v = wpre[ORDERED ? j : 0][b];
+      wpre[ORDERED ? j : 0][b] = (unsigned short)run;
       run += v;
     }
   }
@@ -331,7 +359,7 @@ __global__ __launch_bounds__(kBinChunk) void bin_fill_kernel(const float* __rest
       const unsigned long long m = __ballot(mem);
       if (mem) {
         const int b = by * BW + bx;
-        const int pos = wcnt[w][b] + mask_rank(m);
+        const int pos = base_t[b] + wpre[ORDERED ? w : 0][b] + mask_rank(m);
         if (pos < M) list[offset[row0 + b] + pos] = (int)c.e;
       }
     }
@@ -389,6 +417,7 @@ bool bin_carve(Arena& arena, int64_t E, int N, const BinGeom& g, int M, BinWorks
   ws->counts = arena.take<int>((size_t)ws->max_chunks * g.nbins);
   ws->total = arena.take<int>((size_t)N * g.nbins);
   ws->offset = arena.take<int64_t>((size_t)N * g.nbins + 1);
+  ws->blocksum = arena.take<long long>((size_t)ceil_div((int64_t)N * g.nbins, 1024) + 1);
   ws->list = arena.take<int>((size_t)ws->capacity);
   return arena.ok();
 }
@@ -430,7 +459,9 @@ int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t*
   }
   {
     LaunchScope ls("bin_scan_offsets", stream);
-    bin_scan_offsets_kernel<<<1, 1024, 0, stream>>>(ws.total, rows, ws.offset);
+    const unsigned nb = (unsigned)ceil_div(rows, 1024);
+    bin_block_sums_kernel<<<nb, 1024, 0, stream>>>(ws.total, rows, ws.blocksum);
+    bin_scan_offsets_kernel<<<nb, 1024, 0, stream>>>(ws.total, rows, ws.blocksum, ws.offset);
   }
   {
     LaunchScope ls("bin_fill", stream);

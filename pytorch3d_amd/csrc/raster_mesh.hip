@@ -19,6 +19,7 @@
 // The SoftRas backward lives in raster_mesh_bwd.hip.
 #include "binning.h"
 #include "tile_map.h"
+#include "chunk_order.h"
 #include "p3d_geom.h"
 #include "topk.h"
 
@@ -47,7 +48,7 @@ struct MeshArgs {
   TileMap tm;
   float blur, sqrt_blur;
   int persp, clip, cull;
-  int debug;  // P3D_DEBUG_FWD ablation bits (profiles/ablate.py): 1 no per-pixel evaluation, 2 no queue insertion, 4 no stores, 16 no depth cull, 32 no front-to-back order, 64 print work statistics (build with -DP3D_FWD_STATS), 128 no bin permutation
+  int debug;  // P3D_DEBUG_FWD ablation bits (profiles/ablate.py): 1 no per-pixel evaluation, 2 no queue insertion, 4 no stores, 16 no depth cull, 32 no front-to-back order, 64 print work statistics (build with -DP3D_FWD_STATS), 128 no bin permutation, 512 caller's bin geometry instead of tile-sized bins
   unsigned long long* counters;  // debug bit 64: per-launch statistics (see launch_mesh_raster)
   int64_t* p2f;
   float* zbuf;
@@ -159,7 +160,9 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
   __shared__ float4 s_box[kStage];       // xlo, xhi, ylo, yhi (blur-expanded)
   __shared__ float4 s_vert[kStage][3];   // v0x v0y v0z v1x | v1y v1z v2x v2y | v2z idx nb -
   __shared__ __align__(16) float s_zc[kStage];  // depth-cull key: every sample of the face has z >= s_zc (or -inf)
-  __shared__ int s_order[kStage];        // visiting order of the staged faces: ascending s_zc when order is free
+  __shared__ int s_order[kStage];        // visiting order of the staged faces: ascending s_zc (by bucket) when order is free
+  __shared__ float s_qlow[kStage];       // lower bound of s_zc over sorted positions >= i
+  __shared__ ChunkOrderScratch s_ord;
   __shared__ int s_wcnt[kStage / kWave];
 
   TileCoord tc;
@@ -263,24 +266,12 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
     // discard almost everything behind the first K layers; a chunk with neighbour faces keeps
     // the reference's ascending-index order.
     const bool sorted = __syncthreads_or(has_nb ? 1 : 0) == 0 && !(a.debug & 32);
-    if (tid < staged) {
-      int rank = tid;
-      if (sorted) {
-        const float key = s_zc[tid];
-        rank = 0;
-        for (int j0 = 0; j0 < staged; j0 += 4) {
-          const float4 z4 = *reinterpret_cast<const float4*>(&s_zc[j0]);
-          const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int j = j0 + u;
-            rank += (j < staged && (zz[u] < key || (zz[u] == key && j < tid))) ? 1 : 0;
-          }
-        }
-      }
-      s_order[rank] = tid;
+    if (sorted) {
+      chunk_bucket_order(s_zc, staged, s_order, s_qlow, s_ord, tid);
+    } else {
+      if (tid < staged) s_order[tid] = tid;
+      __syncthreads();
     }
-    __syncthreads();
 
     P3D_STAT(c_staged += staged);
     // ---- per wave: sub-tile cull 64 faces at a time, then per-pixel evaluation -----------
@@ -288,7 +279,7 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
       for (int jb = 0; jb < staged; jb += kWave) {
         // sorted chunk: once the nearest remaining face is too deep for every pixel of this wave,
         // so is everything behind it
-        if (sorted && __ballot(pix_ok && !(s_zc[s_order[jb]] > q.kth_z(K))) == 0) break;
+        if (sorted && __ballot(pix_ok && !(s_qlow[jb] > q.kth_z(K))) == 0) break;
         P3D_STAT(++c_groups);
         const int j = jb + lane;
         bool touch = false;
@@ -438,8 +429,10 @@ using namespace p3d;
 P3D_API size_t p3d_rasterize_meshes_workspace_bytes(int64_t F, int N, int H, int W, int bin_size,
                                                     int max_faces_per_bin) {
   if (bin_size <= 0 || max_faces_per_bin <= 0 || N <= 0 || H <= 0 || W <= 0) return 0;
-  const BinGeom g = make_geom(H, W, bin_size);
-  return bin_workspace_bytes(F, N, g, max_faces_per_bin) + 256;
+  // enough for both the caller's geometry (_rasterize_meshes_coarse) and the internal one (rasterize_meshes)
+  const size_t user = bin_workspace_bytes(F, N, make_geom(H, W, bin_size), max_faces_per_bin);
+  const size_t internal = bin_workspace_bytes(F, N, make_internal_geom(H, W, bin_size), max_faces_per_bin);
+  return (user > internal ? user : internal) + 256;
 }
 
 P3D_API size_t p3d_rasterize_fine_workspace_bytes(int N, int BH, int BW, int M) {
@@ -518,8 +511,11 @@ P3D_API int p3d_rasterize_meshes(const float* face_verts, const int64_t* mesh_fi
   if ((int64_t)N * H * W * K == 0) return P3D_OK;
   if ((!face_verts || !neighbor) && F > 0) return P3D_ERR_INVALID_ARG;
   if (!mesh_first || !mesh_count || !p2f || !zbuf || !bary || !dists) return P3D_ERR_INVALID_ARG;
-  const BinGeom g = make_geom(H, W, bin_size);
-  if (g.BH > P3D_MAX_BINS_PER_SIDE || g.BW > P3D_MAX_BINS_PER_SIDE) return P3D_ERR_TOO_MANY_BINS;
+  const BinGeom gu = make_geom(H, W, bin_size);
+  if (gu.BH > P3D_MAX_BINS_PER_SIDE || gu.BW > P3D_MAX_BINS_PER_SIDE) return P3D_ERR_TOO_MANY_BINS;
+  const char* dbg_env = getenv("P3D_DEBUG_FWD");
+  const bool user_bins = dbg_env && (atoi(dbg_env) & 512);  // ablation: bin with the caller's geometry
+  const BinGeom g = user_bins ? gu : make_internal_geom(H, W, bin_size);  // tile-sized bins: results do not depend on the binning
   Arena arena(workspace, workspace_bytes);
   BinWorkspace ws;
   if (!workspace || !bin_carve(arena, F, N, g, max_faces_per_bin, &ws)) return P3D_ERR_WORKSPACE;

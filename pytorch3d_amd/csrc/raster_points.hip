@@ -256,8 +256,9 @@ using namespace p3d;
 P3D_API size_t p3d_rasterize_points_workspace_bytes(int64_t P, int N, int H, int W, int bin_size,
                                                     int max_points_per_bin) {
   if (bin_size <= 0 || max_points_per_bin <= 0 || N <= 0 || H <= 0 || W <= 0) return 0;
-  const BinGeom g = make_geom(H, W, bin_size);
-  return bin_workspace_bytes(P, N, g, max_points_per_bin) + 256;
+  const size_t user = bin_workspace_bytes(P, N, make_geom(H, W, bin_size), max_points_per_bin);
+  const size_t internal = bin_workspace_bytes(P, N, make_internal_geom(H, W, bin_size), max_points_per_bin);
+  return (user > internal ? user : internal) + 256;
 }
 
 P3D_API int p3d_rasterize_points_naive(const float* points, const int64_t* first, const int64_t* count,
@@ -285,8 +286,9 @@ P3D_API int p3d_rasterize_points(const float* points, const int64_t* first, cons
   if (rc != P3D_OK) return rc;
   if ((int64_t)N * H * W * K == 0) return P3D_OK;
   if ((P > 0 && (!points || !radius)) || !first || !count || !idxs || !zbuf || !dists) return P3D_ERR_INVALID_ARG;
-  const BinGeom g = make_geom(H, W, bin_size);
-  if (g.BH > P3D_MAX_BINS_PER_SIDE || g.BW > P3D_MAX_BINS_PER_SIDE) return P3D_ERR_TOO_MANY_BINS;
+  const BinGeom gu = make_geom(H, W, bin_size);
+  if (gu.BH > P3D_MAX_BINS_PER_SIDE || gu.BW > P3D_MAX_BINS_PER_SIDE) return P3D_ERR_TOO_MANY_BINS;
+  const BinGeom g = make_internal_geom(H, W, bin_size);  // tile-sized bins: results do not depend on the binning
   Arena arena(workspace, workspace_bytes);
   BinWorkspace ws;
   if (!workspace || !bin_carve(arena, P, N, g, max_points_per_bin, &ws)) return P3D_ERR_WORKSPACE;
