@@ -294,9 +294,12 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
           const int jj = __builtin_amdgcn_readlane(oj, __builtin_ctzll(cand));
           cand &= cand - 1;
           P3D_STAT(++c_cand);
+          // all LDS reads of this candidate are issued together (one round trip instead of three dependent ones)
           const float4 b = s_box[jj];
+          const float zc = s_zc[jj];
+          const float4 r0 = s_vert[jj][0], r1 = s_vert[jj][1], r2 = s_vert[jj][2];
           const bool out = p.x > b.y || p.x < b.x || p.y > b.w || p.y < b.z;
-          const bool too_deep = s_zc[jj] > q.kth_z(K) && !(a.debug & 16);
+          const bool too_deep = zc > q.kth_z(K) && !(a.debug & 16);
 #ifdef P3D_FWD_STATS
           if (a.debug & 64) {
             const unsigned long long m = __ballot(pix_ok && !out && !too_deep);
@@ -305,7 +308,6 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
           }
 #endif
           if (pix_ok && !out && !too_deep && !(a.debug & 1)) {
-            const float4 r0 = s_vert[jj][0], r1 = s_vert[jj][1], r2 = s_vert[jj][2];
             const f3 a0 = mk3(r0.x, r0.y, r0.z);
             const f3 a1 = mk3(r0.w, r1.x, r1.y);
             const f3 a2 = mk3(r1.z, r1.w, r2.x);
