@@ -166,6 +166,31 @@ int p3d_interp_face_attrs_backward(int dtype, const int64_t* pix_to_face, const 
                                    const void* face_attrs, const void* grad_pix_attrs, int64_t P, int64_t F, int64_t D,
                                    void* grad_barycentric_coords, void* grad_face_attrs, p3d_stream_t stream);
 
+/* ---- fragment blending (the step right after rasterization) --------------------------- */
+
+/* replaces SigmoidAlphaBlend / SigmoidAlphaBlendBackward, pytorch3d/csrc/blending/sigmoid_alpha_blend.h:73-103
+ * (_C.sigmoid_alpha_blend[_backward]).  dists, pix_to_face (npix,K); alphas, grad_alphas (npix); grad_dists
+ * (npix,K) fully written.  npix = N*H*W. */
+int p3d_sigmoid_alpha_blend_forward(const float* dists, const int64_t* pix_to_face, float sigma, int64_t npix, int K,
+                                    float* alphas, p3d_stream_t stream);
+int p3d_sigmoid_alpha_blend_backward(const float* grad_alphas, const float* alphas, const float* dists,
+                                     const int64_t* pix_to_face, float sigma, int64_t npix, int K, float* grad_dists,
+                                     p3d_stream_t stream);
+
+/* replaces the Python function softmax_rgb_blend (pytorch3d/renderer/blending.py:147-244: ~20 elementwise torch
+ * ops over (N,H,W,K)) and its autograd graph.  colors (N*P,K,3), pix_to_face / dists / zbuf (N*P,K) with
+ * P = pix_per_image; znear / zfar either the scalars or, when the pointers are non-null, per-image device arrays
+ * (N); out (N*P,4) RGBA.  Backward: grad_out (N*P,4) -> grad_colors (N*P,K,3), grad_dists, grad_zbuf (N*P,K). */
+int p3d_softmax_rgb_blend_forward(const float* colors, const int64_t* pix_to_face, const float* dists,
+                                  const float* zbuf, float sigma, float gamma, const float background[3], float znear,
+                                  float zfar, const float* znear_per_image, const float* zfar_per_image, int64_t N,
+                                  int64_t pix_per_image, int K, float* out, p3d_stream_t stream);
+int p3d_softmax_rgb_blend_backward(const float* grad_out, const float* colors, const int64_t* pix_to_face,
+                                   const float* dists, const float* zbuf, float sigma, float gamma,
+                                   const float background[3], float znear, float zfar, const float* znear_per_image,
+                                   const float* zfar_per_image, int64_t N, int64_t pix_per_image, int K,
+                                   float* grad_colors, float* grad_dists, float* grad_zbuf, p3d_stream_t stream);
+
 /* ---- built-in per-kernel timing (HIP events on the launch stream) --------------------- */
 
 /* enable != 0: every kernel launch is bracketed by hipEventRecord on its stream. */

@@ -35,6 +35,7 @@ def build_oracle(force=False):
 _REF_SOURCES = [
     "pytorch3d/csrc/rasterize_meshes/rasterize_meshes_cpu.cpp",
     "pytorch3d/csrc/rasterize_points/rasterize_points_cpu.cpp",
+    "pytorch3d/csrc/blending/sigmoid_alpha_blend_cpu.cpp",
     "pytorch3d/csrc/compositing/alpha_composite_cpu.cpp",
     "pytorch3d/csrc/compositing/norm_weighted_sum_cpu.cpp",
     "pytorch3d/csrc/compositing/weighted_sum_cpu.cpp",

@@ -151,6 +151,55 @@ def interp_backward(pix_to_face, bary, face_attrs, grad_pix_attrs):
     return gb, gf
 
 
+def sigmoid_alpha_blend(dists, pix_to_face, sigma):
+    d, p2f = _f32(dists), _i64(pix_to_face)
+    N, H, W, K = p2f.shape
+    out = torch.empty((N, H, W), dtype=torch.float32)
+    lib().orc_sigmoid_alpha_blend(_p(d), _p(p2f), ctypes.c_float(sigma), ctypes.c_int64(N * H * W), K, _p(out))
+    return out
+
+
+def sigmoid_alpha_blend_backward(grad_alphas, alphas, dists, pix_to_face, sigma):
+    ga, al, d, p2f = _f32(grad_alphas), _f32(alphas), _f32(dists), _i64(pix_to_face)
+    N, H, W, K = p2f.shape
+    out = torch.empty((N, H, W, K), dtype=torch.float32)
+    lib().orc_sigmoid_alpha_blend_backward(_p(ga), _p(al), _p(d), _p(p2f), ctypes.c_float(sigma),
+                                           ctypes.c_int64(N * H * W), K, _p(out))
+    return out
+
+
+def _per_image(v, N):
+    if isinstance(v, torch.Tensor):
+        return _f32(v).reshape(-1).expand(N).contiguous() if v.numel() == 1 else _f32(v).reshape(N)
+    return torch.full((N,), float(v), dtype=torch.float32)
+
+
+def softmax_rgb_blend(colors, pix_to_face, dists, zbuf, sigma, gamma, background_color, znear=1.0, zfar=100.0):
+    c, p2f, d, z = _f32(colors), _i64(pix_to_face), _f32(dists), _f32(zbuf)
+    N, H, W, K = p2f.shape
+    bg = _f32(torch.as_tensor(background_color, dtype=torch.float32))
+    zn, zf = _per_image(znear, N), _per_image(zfar, N)
+    out = torch.empty((N, H, W, 4), dtype=torch.float32)
+    lib().orc_softmax_rgb_blend(_p(c), _p(p2f), _p(d), _p(z), ctypes.c_float(sigma), ctypes.c_float(gamma), _p(bg),
+                                _p(zn), _p(zf), ctypes.c_int64(N * H * W), ctypes.c_int64(H * W), K, _p(out))
+    return out
+
+
+def softmax_rgb_blend_backward(grad_out, colors, pix_to_face, dists, zbuf, sigma, gamma, background_color, znear=1.0,
+                               zfar=100.0):
+    g, c, p2f, d, z = _f32(grad_out), _f32(colors), _i64(pix_to_face), _f32(dists), _f32(zbuf)
+    N, H, W, K = p2f.shape
+    bg = _f32(torch.as_tensor(background_color, dtype=torch.float32))
+    zn, zf = _per_image(znear, N), _per_image(zfar, N)
+    gc = torch.empty((N, H, W, K, 3), dtype=torch.float32)
+    gd = torch.empty((N, H, W, K), dtype=torch.float32)
+    gz = torch.empty((N, H, W, K), dtype=torch.float32)
+    lib().orc_softmax_rgb_blend_backward(_p(g), _p(c), _p(p2f), _p(d), _p(z), ctypes.c_float(sigma),
+                                         ctypes.c_float(gamma), _p(bg), _p(zn), _p(zf), ctypes.c_int64(N * H * W),
+                                         ctypes.c_int64(H * W), K, _p(gc), _p(gd), _p(gz))
+    return gc, gd, gz
+
+
 # ---------------------------------------------------------------------------
 # The real reference, when its CPU build is present (oracle/_ref/p3d_ref_cpu.so).
 # ---------------------------------------------------------------------------

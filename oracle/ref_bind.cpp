@@ -6,6 +6,8 @@
 // against, and the "reference" kind of bench.py's cpu_baseline.
 #include <torch/extension.h>
 
+#include "utils/pytorch3d_cutils.h"  // sigmoid_alpha_blend.h relies on ext.cpp having included it
+#include "blending/sigmoid_alpha_blend.h"
 #include "compositing/alpha_composite.h"
 #include "compositing/norm_weighted_sum.h"
 #include "compositing/weighted_sum.h"
@@ -23,6 +25,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("accum_weightedsumnorm_backward", &weightedSumNormBackward);
   m.def("accum_weightedsum_backward", &weightedSumBackward);
   m.def("accum_alphacomposite_backward", &alphaCompositeBackward);
+  m.def("sigmoid_alpha_blend", &SigmoidAlphaBlend);
+  m.def("sigmoid_alpha_blend_backward", &SigmoidAlphaBlendBackward);
   m.def("_rasterize_points_coarse", &RasterizePointsCoarse);
   m.def("_rasterize_points_naive", &RasterizePointsNaive);
   m.def("_rasterize_meshes_naive", &RasterizeMeshesNaive);

@@ -129,6 +129,60 @@ def main():
                 "kernels_ms": k, "algorithmic_bytes": alg,
                 "GBps": {n: alg[n] / k[n] / 1e6 for n in alg if n in k},
                 "frac_of_hbm_peak": {n: alg[n] / k[n] / 1e6 / PEAK for n in alg if n in k}})
+    # ---- blending on config-3 fragments -------------------------------------------
+    del bary_g, g_out, attrs
+    from collections import namedtuple
+
+    Frag = namedtuple("Frag", "pix_to_face zbuf dists")
+    zbuf3, dists3 = (t.detach() for t in p3d.rasterize_meshes(m3, image_size=512, blur_radius=blur, faces_per_pixel=8,
+                                                              perspective_correct=True,
+                                                              clip_barycentric_coords=True)[1::2])
+    colors = torch.rand(64, 512, 512, 8, 3, generator=gen).to(d).requires_grad_(True)
+    dg = dists3.clone().requires_grad_(True)
+    zg = zbuf3.clone().requires_grad_(True)
+    g_img = torch.randn(64, 512, 512, 4, generator=gen).to(d)
+    bp = p3d.BlendParams(1e-4, 1e-4, (1.0, 1.0, 1.0))
+
+    def cb():
+        colors.grad = dg.grad = zg.grad = None
+        img = p3d.softmax_rgb_blend(colors, Frag(p2f, zg, dg), bp)
+        img.backward(g_img)
+
+    wall, k = timed(lib, _lib, cb, iters=3, warm=1)
+    px = 64 * 512 * 512
+    alg = {"softmax_blend_fwd": px * (8 * 28 + 16), "softmax_blend_bwd": px * (8 * 28 + 16 + 8 * 20)}
+    row = {"config": "softmax_rgb_blend fwd+bwd (fused) on config-3 fragments, N=64 512x512 K=8", "wall_ms": wall,
+           "kernels_ms": k, "algorithmic_bytes": alg, "GBps": {n: alg[n] / k[n] / 1e6 for n in alg if n in k},
+           "frac_of_hbm_peak": {n: alg[n] / k[n] / 1e6 / PEAK for n in alg if n in k}}
+
+    def torch_blend(nb):
+        cs = colors[:nb].detach().requires_grad_(True)
+        ds = dg[:nb].detach().requires_grad_(True)
+        zs = zg[:nb].detach().requires_grad_(True)
+        eps = 1e-10
+        mask = p2f[:nb] >= 0
+        prob = torch.sigmoid(-ds / 1e-4) * mask
+        alpha = torch.prod(1.0 - prob, dim=-1)
+        z_inv = (100.0 - zs) / 99.0 * mask
+        z_inv_max = torch.max(z_inv, dim=-1).values[..., None].clamp(min=eps)
+        wn = prob * torch.exp((z_inv - z_inv_max) / 1e-4)
+        delta = torch.exp((eps - z_inv_max) / 1e-4).clamp(min=eps)
+        denom = wn.sum(dim=-1)[..., None] + delta
+        rgb = ((wn[..., None] * cs).sum(dim=-2) + delta) / denom
+        img = torch.cat([rgb, (1.0 - alpha)[..., None]], -1)
+        img.backward(g_img[:nb])
+
+    # the reference's formulation (blending.py:147-244 as torch ops + autograd) on the same GPU; at N = 64 torch's
+    # own backward fails on ROCm ("invalid configuration argument"), so it is timed on 16 images and scaled by 4
+    nb = 16
+    torch_blend(nb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        torch_blend(nb)
+    torch.cuda.synchronize()
+    row["torch_elementwise_same_gpu_ms_scaled_from_16_images"] = (time.perf_counter() - t0) / 3 * 1e3 * (64 / nb)
+    out.append(row)
     for o in out:
         print(json.dumps(o), flush=True)
 

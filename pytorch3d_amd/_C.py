@@ -484,10 +484,48 @@ def interp_face_attrs_backward(pix_to_face, barycentric_coords, face_attrs, grad
     return gb, gf
 
 
+# ----------------------------------------------------------------------------------------------
+# blending
+# ----------------------------------------------------------------------------------------------
+def sigmoid_alpha_blend(distances, pix_to_face, sigma):
+    """SigmoidAlphaBlend, blending/sigmoid_alpha_blend.h:73-84.  distances, pix_to_face (N,H,W,K) -> alphas (N,H,W)."""
+    dev = _same_device(("distances", distances), ("pix_to_face", pix_to_face))
+    if distances.dim() != 4 or pix_to_face.shape != distances.shape:
+        raise RuntimeError("distances and pix_to_face must both have shape (N, H, W, K)")
+    d, p2f = _c(distances, torch.float32), _c(pix_to_face, torch.int64)
+    N, H, W, K = d.shape
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        out = torch.empty((N, H, W), dtype=torch.float32, device=dev)
+        if out.numel() == 0:
+            return out
+        rc = lib.p3d_sigmoid_alpha_blend_forward(_ptr(d), _ptr(p2f), float(sigma), N * H * W, K, _ptr(out), _stream(dev))
+        _lib.check(rc, "sigmoid_alpha_blend")
+    return out
+
+
+def sigmoid_alpha_blend_backward(grad_alphas, alphas, distances, pix_to_face, sigma):
+    """SigmoidAlphaBlendBackward, sigmoid_alpha_blend.h:86-103.  Returns grad_distances (N,H,W,K)."""
+    dev = _same_device(("distances", distances), ("pix_to_face", pix_to_face), ("alphas", alphas),
+                       ("grad_alphas", grad_alphas))
+    d, p2f = _c(distances, torch.float32), _c(pix_to_face, torch.int64)
+    ga, al = _c(grad_alphas, torch.float32), _c(alphas, torch.float32)
+    N, H, W, K = d.shape
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        out = torch.empty((N, H, W, K), dtype=torch.float32, device=dev)
+        if out.numel() == 0:
+            return out
+        rc = lib.p3d_sigmoid_alpha_blend_backward(_ptr(ga), _ptr(al), _ptr(d), _ptr(p2f), float(sigma), N * H * W, K,
+                                                  _ptr(out), _stream(dev))
+        _lib.check(rc, "sigmoid_alpha_blend_backward")
+    return out
+
+
 HOT_PATH_EXPORTS = (
     "rasterize_meshes", "rasterize_meshes_backward", "_rasterize_meshes_naive", "_rasterize_meshes_coarse",
     "_rasterize_meshes_fine", "rasterize_points", "rasterize_points_backward", "_rasterize_points_naive",
     "_rasterize_points_coarse", "_rasterize_points_fine", "accum_alphacomposite", "accum_alphacomposite_backward",
     "accum_weightedsumnorm", "accum_weightedsumnorm_backward", "accum_weightedsum", "accum_weightedsum_backward",
-    "interp_face_attrs_forward", "interp_face_attrs_backward",
+    "interp_face_attrs_forward", "interp_face_attrs_backward", "sigmoid_alpha_blend", "sigmoid_alpha_blend_backward",
 )

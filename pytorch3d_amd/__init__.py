@@ -10,6 +10,7 @@ Importing the package does not load the HIP library; the first operator call doe
 if it is missing (no CPU / eager fallback exists).
 """
 from . import _C  # noqa: F401
+from .blending import BlendParams, sigmoid_alpha_blend, softmax_rgb_blend  # noqa: F401
 from .compositing import alpha_composite, norm_weighted_sum, weighted_sum  # noqa: F401
 from .interp_face_attrs import interpolate_face_attributes  # noqa: F401
 from .rasterize_meshes import rasterize_meshes  # noqa: F401

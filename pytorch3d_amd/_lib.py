@@ -53,6 +53,13 @@ _SIGNATURES = {
     "p3d_interp_face_attrs_forward": (c_int, [c_int, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     "p3d_interp_face_attrs_backward": (c_int, [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr,
                                                c_ptr]),
+    "p3d_sigmoid_alpha_blend_forward": (c_int, [c_ptr, c_ptr, c_f32, c_i64, c_int, c_ptr, c_ptr]),
+    "p3d_sigmoid_alpha_blend_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_i64, c_int, c_ptr, c_ptr]),
+    "p3d_softmax_rgb_blend_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, ctypes.POINTER(c_f32), c_f32,
+                                              c_f32, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr]),
+    "p3d_softmax_rgb_blend_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, ctypes.POINTER(c_f32),
+                                               c_f32, c_f32, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr,
+                                               c_ptr]),
     "p3d_profile_enable": (None, [c_int]),
     "p3d_profile_collect": (None, []),
     "p3d_profile_num_entries": (c_int, []),

@@ -33,7 +33,9 @@ def test_header_declares_the_operator_surface():
                  "p3d_rasterize_meshes_fine", "p3d_rasterize_meshes_backward", "p3d_rasterize_points",
                  "p3d_rasterize_points_naive", "p3d_rasterize_points_coarse", "p3d_rasterize_points_fine",
                  "p3d_rasterize_points_backward", "p3d_composite_forward", "p3d_composite_backward",
-                 "p3d_interp_face_attrs_forward", "p3d_interp_face_attrs_backward"):
+                 "p3d_interp_face_attrs_forward", "p3d_interp_face_attrs_backward", "p3d_sigmoid_alpha_blend_forward",
+                 "p3d_sigmoid_alpha_blend_backward", "p3d_softmax_rgb_blend_forward", "p3d_softmax_rgb_blend_backward",
+                 "p3d_gather_face_verts", "p3d_scatter_face_grads"):
         assert want in names
 
 
@@ -102,7 +104,7 @@ def test_operator_surface_names_match_the_reference_pybind_module():
                  "_rasterize_points_coarse", "_rasterize_points_fine", "accum_alphacomposite",
                  "accum_alphacomposite_backward", "accum_weightedsumnorm", "accum_weightedsumnorm_backward",
                  "accum_weightedsum", "accum_weightedsum_backward", "interp_face_attrs_forward",
-                 "interp_face_attrs_backward"]
+                 "interp_face_attrs_backward", "sigmoid_alpha_blend", "sigmoid_alpha_blend_backward"]
     mod = shim.make_module()
     for n in ref_names:
         assert callable(getattr(_C, n)) and callable(getattr(mod, n))

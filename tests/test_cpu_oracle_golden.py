@@ -219,3 +219,30 @@ def test_device_headers_backward_host_build_vs_oracle(persp, clip):
     ref = orc.rasterize_meshes_backward(fv, fwd[0], gz, gb, gd, persp, clip)
     got = U.hg_rasterize_meshes_backward(fv, fwd[0], gz, gb, gd, persp, clip)
     assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5 * max(1.0, ref.abs().max().item()))
+
+
+# ---------------------------------------------------------------------------------------------
+# blending: reference C++ sigmoid_alpha_blend, reference Python softmax_rgb_blend
+# ---------------------------------------------------------------------------------------------
+def test_oracle_sigmoid_alpha_blend_vs_reference_cpu_kernels():
+    g = _load("blend_ref")
+    a = orc.sigmoid_alpha_blend(g["dists"], g["pix_to_face"], g["sigma"])
+    assert torch.allclose(a, g["sig_alphas"], atol=1e-6, rtol=0)
+    gd = orc.sigmoid_alpha_blend_backward(g["sig_grad_alphas"], g["sig_alphas"], g["dists"], g["pix_to_face"],
+                                          g["sigma"])
+    assert torch.allclose(gd, g["sig_grad_dists"], atol=1e-6 * g["sig_grad_dists"].abs().max().item(), rtol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_oracle_softmax_rgb_blend_vs_reference_python(tag):
+    g = _load("blend_ref")
+    k = lambda n: g[f"sm_{tag}_{n}"]
+    args = (g["colors"], g["pix_to_face"], g["dists"], g["zbuf"], k("sigma"), k("gamma"), k("bg"))
+    zn = k("znear") if isinstance(k("znear"), torch.Tensor) else float(k("znear"))
+    zf = k("zfar") if isinstance(k("zfar"), torch.Tensor) else float(k("zfar"))
+    out = orc.softmax_rgb_blend(*args, znear=zn, zfar=zf)
+    assert torch.allclose(out, k("out"), atol=1e-5, rtol=1e-5)
+    gc, gd, gz = orc.softmax_rgb_blend_backward(k("grad_out"), *args, znear=zn, zfar=zf)
+    for got, name in ((gc, "grad_colors"), (gd, "grad_dists"), (gz, "grad_zbuf")):
+        ref = k(name)
+        assert torch.allclose(got, ref, atol=2e-5 * max(1.0, ref.abs().max().item()), rtol=2e-4), name
