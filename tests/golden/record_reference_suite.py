@@ -4,7 +4,7 @@
     python tests/golden/record_reference_suite.py
 
 The reference's unittest modules for this path (tests/test_rasterize_meshes.py,
-tests/test_rasterize_points.py, tests/test_compositing.py) are run unmodified with `pytorch3d._C`
+tests/test_rasterize_points.py, tests/test_compositing.py, tests/test_blending.py) are run unmodified with `pytorch3d._C`
 bound to the reference's own CPU kernels (oracle/_ref/p3d_ref_cpu.so).  A thin recorder around each
 operator stores (operator, inputs, outputs, the unittest id that made the call).  The tests that pass
 are the ones that compare those outputs with the suite's hand-written golden tensors
@@ -33,6 +33,7 @@ OPS = (
     "rasterize_points", "rasterize_points_backward", "_rasterize_points_naive", "_rasterize_points_coarse",
     "accum_alphacomposite", "accum_alphacomposite_backward", "accum_weightedsumnorm",
     "accum_weightedsumnorm_backward", "accum_weightedsum", "accum_weightedsum_backward",
+    "sigmoid_alpha_blend", "sigmoid_alpha_blend_backward",
 )
 MAX_CALL_BYTES = 1 << 20   # skip calls larger than 1 MiB (the suite's benchmark-sized cases)
 MAX_TOTAL_BYTES = 12 << 20
@@ -105,7 +106,7 @@ def main():
 
     pytorch3d._C = mod
     os.chdir(REFERENCE)
-    names = ["tests.test_rasterize_meshes", "tests.test_rasterize_points", "tests.test_compositing"]
+    names = ["tests.test_rasterize_meshes", "tests.test_rasterize_points", "tests.test_compositing", "tests.test_blending"]
     suite = unittest.defaultTestLoader.loadTestsFromNames(names)
     runner = unittest.TextTestRunner(resultclass=Result, verbosity=0, stream=open(os.devnull, "w"))
     res = runner.run(suite)
