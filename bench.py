@@ -9,7 +9,7 @@ backward (SoftRas gradient to the packed vertices) through the L2 mirror's autog
 driven by fixed random upstream gradients for zbuf / bary / dists (the reference's gradient
 check, tests/test_rasterize_meshes.py:563-571).  Inputs are resident in HBM before the timed
 region.  With --gpus N every rank rasterizes its own batch of 64 (weak scaling, no data-path
-collective); the only collective is the final all_gather of the last step's depth images over
+collective); the only collective is the final gather of the last step's depth images to rank 0 over
 RCCL/xGMI, inside the timed region.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
@@ -99,6 +99,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); no CPU fallback exists for the product path")
+    # P3D_BENCH_TEST_BACKEND=gloo maps every rank to cuda:0 and uses gloo: lets the multi-rank code path (barriers,
+    # max-over-ranks timing, final gather) be exercised on a single-GPU box.  Never set by the driver.
+    test_backend = os.environ.get("P3D_BENCH_TEST_BACKEND")
+    if test_backend:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist_on = world > 1
@@ -106,7 +111,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if test_backend:
+            dist.init_process_group(test_backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import pytorch3d_amd as p3d
     from pytorch3d_amd import _lib
@@ -148,8 +156,12 @@ def main():
     for _ in range(args.steps):
         zbuf = step()
     if dist_on:
-        # the one collective of the job: gather the final depth images of every rank
-        final = sharding.gather_batch(zbuf[..., 0].detach().contiguous(), [B] * world)
+        # the one collective of the job: the final depth images of every rank are gathered on rank 0
+        shard = zbuf[..., 0].detach().contiguous()
+        try:
+            final = sharding.gather_batch(shard, [B] * world, dst=0)
+        except (RuntimeError, NotImplementedError):  # a backend without gather: every rank raises alike
+            final = sharding.gather_batch(shard, [B] * world)
         del final
     torch.cuda.synchronize()
     if dist_on:
@@ -202,11 +214,11 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[2]: batch of 64 heterogeneous meshes (1k-20k faces, tori/icospheres), "
+                "workload": f"BASELINE configs[2]: batch of {B} heterogeneous meshes per GPU (1k-20k faces, tori/icospheres), "
                             "512x512, faces_per_pixel=8, SoftRas blur, perspective-correct + clipped bary, fwd+bwd",
                 "global_batch": world * B, "image_size": [H, W], "faces_per_pixel": K, "blur_radius": blur,
                 "total_faces_per_rank": total_faces, "pixel_slot_fill": hit_frac,
-                "parallelism": f"batch-sharded x{world}, final all_gather only",
+                "parallelism": f"batch-sharded x{world}, final gather to rank 0 only",
             },
             "roofline": roofline,
             "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in sorted(kernels.items())},

@@ -2,7 +2,7 @@
 
 The path shards embarrassingly: every job reads only its own slice of the packed
 arrays and writes only its own output images, so ranks exchange nothing until the end.  One
-process per GPU (torchrun); the only collective is one `all_gather` of the final per-rank
+process per GPU (torchrun); the only collective is one gather of the final per-rank
 result over RCCL/xGMI (backend "nccl" on ROCm; "gloo" in the CPU tests).
 
 `partition()` is pure host logic; `gather_batch()` is the collective.  Nothing here is specific
@@ -58,17 +58,27 @@ def rebase_indices(idx: torch.Tensor, offset: int) -> torch.Tensor:
     return torch.where(idx >= 0, idx + offset, idx)
 
 
-def gather_batch(local: torch.Tensor, sizes: Sequence[int], group=None) -> torch.Tensor:
-    """all_gather per-rank results of shape (sizes[rank], ...) into the full batch (sum(sizes), ...).
+def gather_batch(local: torch.Tensor, sizes: Sequence[int], group=None, dst=None):
+    """Collect per-rank results of shape (sizes[rank], ...) into the full batch (sum(sizes), ...).
 
-    Ranks may own different numbers of jobs: shards are padded to max(sizes) for the collective
-    (RCCL all_gather needs equal shapes) and trimmed after.  Not differentiable (final gather)."""
+    dst=None: `all_gather`, every rank gets the batch.  dst=r: `gather` to rank r only (returns None on the other
+    ranks) -- on xGMI's point-to-point links the seven peers then send to the destination in parallel, one shard
+    per link, instead of circulating all shards around a ring.  Ranks may own different numbers of jobs: shards are
+    padded to max(sizes) for the collective (RCCL needs equal shapes) and trimmed after.  Not differentiable (final
+    gather)."""
     world = dist.get_world_size(group)
     m = max(int(s) for s in sizes) if len(sizes) else 0
     tail = tuple(local.shape[1:])
     pad = local.new_zeros((m,) + tail)
     if local.shape[0]:
         pad[: local.shape[0]] = local
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad, group=group)
+    if dst is None:
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(bufs, pad, group=group)
+    else:
+        me = dist.get_rank(group)
+        bufs = [torch.empty_like(pad) for _ in range(world)] if me == dst else None
+        dist.gather(pad, bufs, dst=dst, group=group)
+        if me != dst:
+            return None
     return torch.cat([b[: int(s)] for b, s in zip(bufs, sizes)], 0)

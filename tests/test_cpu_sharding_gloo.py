@@ -54,6 +54,10 @@ def _worker(rank, world, port, out_dir):
         sizes = [b - a for a, b in parts]
         full_idx = sharding.gather_batch(p2f, sizes)
         full_z = sharding.gather_batch(zbuf, sizes)
+        to_zero = sharding.gather_batch(zbuf, sizes, dst=0)  # bench.py's variant: only rank 0 receives
+        assert (to_zero is None) == (rank != 0)
+        if rank == 0:
+            assert torch.equal(to_zero, full_z)
         torch.save({"idx": full_idx, "z": full_z, "parts": parts}, os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
