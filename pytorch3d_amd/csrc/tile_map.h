@@ -25,6 +25,8 @@ struct TileMap {
   long long bin_mult;         // odd multiplier coprime to `bins` (1 = identity)
   long long groups_per_xcd;   // ceil(bins / 8)
   long long xcd_rot;          // per-XCD rotation of the walk through its own range (decorrelates the XCDs in time)
+  unsigned long long bins_magic;  // floor((2^64 - 1) / bins): x % bins without a 64-bit division on the device
+  unsigned long long grp_magic;   // the same for groups_per_xcd
 };
 
 inline TileMap make_tile_map(int N, int H, int W, int bin_size, int BH, int BW, bool permute) {
@@ -53,6 +55,8 @@ inline TileMap make_tile_map(int N, int H, int W, int bin_size, int BH, int BW, 
     while (gcd(mult, m.bins) != 1) mult += 2;
   }
   m.bin_mult = mult;
+  m.bins_magic = m.bins > 0 ? ~0ull / (unsigned long long)m.bins : 0;
+  m.grp_magic = m.groups_per_xcd > 0 ? ~0ull / (unsigned long long)m.groups_per_xcd : 0;
   m.xcd_rot = permute ? (((long long)((double)m.groups_per_xcd * 0.3819660113)) | 1) : 0;
   return m;
 }
@@ -64,30 +68,44 @@ struct TileCoord {
   int n, by, bx, ty, tx;
 };
 
-// false: this workgroup has no tile (grid padding)
+// x % d for x < 2^63 given magic = floor((2^64 - 1) / d): the quotient estimate mulhi(x, magic) is at most 2 low.
+__device__ __forceinline__ unsigned long long fast_mod(unsigned long long x, unsigned long long d,
+                                                       unsigned long long magic) {
+  unsigned long long r = x - __umul64hi(x, magic) * d;
+  if (r >= d) r -= d;
+  if (r >= d) r -= d;
+  return r;
+}
+
+// false: this workgroup has no tile (grid padding).  32-bit arithmetic wherever the ranges allow: a runtime
+// 64-bit division is ~200 instructions on gfx950, and every one of 65536 workgroups decodes its tile.
 __device__ __forceinline__ bool tile_of_block(const TileMap& m, unsigned block, TileCoord* c) {
-  const int tpb = m.Ty * m.Tx;
-  const long long slot = block / 8;
-  // XCD x = block % 8 owns the contiguous range [x * G, (x + 1) * G) of pre-permutation bin indices; the
-  // multiplicative permutation scatters every such range evenly over the batch.  (Dealing bins
-  // round-robin -- index % 8 -- BEFORE the permutation ties the XCD to a residue class of the
-  // permuted index whenever 8 divides the bin count, i.e. to fixed image columns.)
-  const long long grp = slot / tpb;
-  if (grp >= m.groups_per_xcd) return false;
-  // every XCD starts its walk at a different phase: without this all eight XCDs sit on the same image
-  // position of eight different batch elements at any moment (their ranges are bins/8 apart and the
-  // permutation is linear), so the whole chip alternates between store-bound and ALU-bound phases
-  const long long x = block % 8;
-  long long bin = x * m.groups_per_xcd + (grp + x * m.xcd_rot) % m.groups_per_xcd;
-  if (bin >= m.bins) return false;
-  bin = (long long)(((unsigned long long)bin * (unsigned long long)m.bin_mult) % (unsigned long long)m.bins);
-  const int t = (int)(slot % tpb);
-  c->tx = t % m.Tx;
-  c->ty = t / m.Tx;
-  c->bx = (int)(bin % m.BW);
-  bin /= m.BW;
-  c->by = (int)(bin % m.BH);
-  c->n = (int)(bin / m.BH);
+  const unsigned tpb = (unsigned)(m.Ty * m.Tx);
+  const unsigned slot = block >> 3, x = block & 7u;
+  const unsigned grp = slot / tpb, t = slot - grp * tpb;
+  if ((long long)grp >= m.groups_per_xcd) return false;
+  // XCD x owns the contiguous range [x * G, (x + 1) * G) of pre-permutation bin indices; the multiplicative
+  // permutation scatters every such range evenly over the batch.  (Dealing bins round-robin -- index % 8 --
+  // BEFORE the permutation ties the XCD to a residue class of the permuted index whenever 8 divides the bin
+  // count, i.e. to fixed image columns.)  Every XCD starts its walk at a different phase: without it all eight
+  // XCDs sit on the same image position of eight different batch elements at any moment (their ranges are
+  // bins/8 apart and the permutation is linear), so the whole chip alternates between store-bound and
+  // ALU-bound phases.
+  const unsigned long long G = (unsigned long long)m.groups_per_xcd;
+  unsigned long long walk = (unsigned long long)grp + (unsigned long long)x * (unsigned long long)m.xcd_rot;
+  if (walk >= G) walk = fast_mod(walk, G, m.grp_magic);
+  unsigned long long bin = (unsigned long long)x * G + walk;
+  if (bin >= (unsigned long long)m.bins) return false;
+  if (m.bin_mult != 1) bin = fast_mod(bin * (unsigned long long)m.bin_mult, (unsigned long long)m.bins, m.bins_magic);
+  c->tx = (int)(t % (unsigned)m.Tx);
+  c->ty = (int)(t / (unsigned)m.Tx);
+  const unsigned per_image = (unsigned)(m.BH * m.BW);
+  const unsigned b32 = (unsigned)bin;  // the grid is 32-bit, so bins < 2^32
+  const unsigned n = b32 / per_image;
+  const unsigned rem = b32 - n * per_image;
+  c->bx = (int)(rem % (unsigned)m.BW);
+  c->by = (int)(rem / (unsigned)m.BW);
+  c->n = (int)n;
   return true;
 }
 #endif
