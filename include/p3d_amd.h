@@ -166,6 +166,47 @@ int p3d_interp_face_attrs_backward(int dtype, const int64_t* pix_to_face, const 
                                    const void* face_attrs, const void* grad_pix_attrs, int64_t P, int64_t F, int64_t D,
                                    void* grad_barycentric_coords, void* grad_face_attrs, p3d_stream_t stream);
 
+/* ---- frustum culling / z-plane clipping before rasterization, un-clipping after -------- */
+
+/* Together these replace clip_faces and convert_clipped_rasterization_to_original_faces,
+ * pytorch3d/renderer/mesh/clip.py:324-615, 618-734 (pure torch in the reference).
+ *
+ * plan:  classify every face (1 kept, 2 removed, 3 clipped to one triangle, 4 clipped to two) and scan the
+ *        destination indices.  `plan` is caller-allocated scratch of p3d_clip_faces_plan_bytes(F) that must stay
+ *        alive until emit / backward; its first four int64 receive {F_clipped, T3, T4, F} -- read them (one sync,
+ *        as in the reference) to size the outputs.  planes = {left, right, top, bottom, znear, zfar}, bit i of
+ *        plane_mask set when plane i is used; cull as ClipFrustum.cull.
+ * emit:  face_verts_clipped (F_clipped,3,3), mesh_to_face_first_idx / num_faces_per_mesh (N),
+ *        faces_clipped_to_unclipped_idx (F_clipped); when T3 + T4 > 0 also barycentric_conversion (T3 + 2*T4,3,3),
+ *        faces_clipped_to_conversion_idx and clipped_faces_neighbor_idx (F_clipped).
+ * backward: gradient of (face_verts_clipped, barycentric_conversion) w.r.t. face_verts, with the reference's
+ *        autograd semantics (w3 detached, clip.py:291). */
+size_t p3d_clip_faces_plan_bytes(int64_t F);
+int p3d_clip_faces_plan(const float* face_verts, int64_t F, const float planes[6], int plane_mask, int cull,
+                        int has_z_clip, float z_clip_value, void* plan, size_t plan_bytes, p3d_stream_t stream);
+int p3d_clip_faces_emit(const float* face_verts, int64_t F, const int64_t* mesh_to_face_first_idx, int N,
+                        const void* plan, size_t plan_bytes, int64_t F_clipped, int64_t T3, int64_t T4,
+                        float z_clip_value, int perspective_correct, float* face_verts_clipped,
+                        int64_t* mesh_to_face_first_idx_clipped, int64_t* num_faces_per_mesh_clipped,
+                        int64_t* faces_clipped_to_unclipped_idx, float* barycentric_conversion,
+                        int64_t* faces_clipped_to_conversion_idx, int64_t* clipped_faces_neighbor_idx,
+                        p3d_stream_t stream);
+int p3d_clip_faces_backward(const float* face_verts, int64_t F, const void* plan, size_t plan_bytes, int64_t T3,
+                            int64_t T4, float z_clip_value, int perspective_correct,
+                            const float* grad_face_verts_clipped, const float* grad_barycentric_conversion,
+                            float* grad_face_verts, p3d_stream_t stream);
+/* pix_to_face (S) / bary (S,3) of the clipped faces -> of the original faces; S = N*H*W*K samples.
+ * barycentric_conversion may be null (only culling happened).  Backward: grad_bary_clipped (S,3) fully written,
+ * grad_barycentric_conversion (T,3,3) zeroed and accumulated (may be null). */
+int p3d_convert_clipped_forward(const int64_t* pix_to_face_clipped, const float* bary_coords_clipped,
+                                const int64_t* faces_clipped_to_unclipped_idx, const float* barycentric_conversion,
+                                const int64_t* faces_clipped_to_conversion_idx, int64_t num_samples,
+                                int64_t* pix_to_face_unclipped, float* bary_coords_unclipped, p3d_stream_t stream);
+int p3d_convert_clipped_backward(const int64_t* pix_to_face_clipped, const float* bary_coords_clipped,
+                                 const float* barycentric_conversion, const int64_t* faces_clipped_to_conversion_idx,
+                                 const float* grad_bary_unclipped, int64_t num_samples, int64_t T,
+                                 float* grad_bary_clipped, float* grad_barycentric_conversion, p3d_stream_t stream);
+
 /* ---- fragment blending (the step right after rasterization) --------------------------- */
 
 /* replaces SigmoidAlphaBlend / SigmoidAlphaBlendBackward, pytorch3d/csrc/blending/sigmoid_alpha_blend.h:73-103

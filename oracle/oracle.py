@@ -168,6 +168,43 @@ def sigmoid_alpha_blend_backward(grad_alphas, alphas, dists, pix_to_face, sigma)
     return out
 
 
+def clip_faces(face_verts, mesh_first, planes, cull, z_clip_value, perspective_correct):
+    """planes: [left, right, top, bottom, znear, zfar] with None for unused.  Returns a dict with the ClippedFaces
+    fields (trimmed), plus counts (F_clipped, T3, T4)."""
+    fv, mf = _f32(face_verts), _i64(mesh_first)
+    F, N = fv.shape[0], mf.shape[0]
+    mask = sum(1 << i for i, v in enumerate(planes) if v is not None)
+    pl = torch.tensor([0.0 if v is None else float(v) for v in planes], dtype=torch.float32)
+    out_fv = torch.zeros((2 * F + 1, 3, 3), dtype=torch.float32)
+    first_c = torch.zeros((N,), dtype=torch.int64)
+    count_c = torch.zeros((N,), dtype=torch.int64)
+    c2u = torch.zeros((2 * F + 1,), dtype=torch.int64)
+    conv = torch.zeros((2 * F + 1, 3, 3), dtype=torch.float32)
+    conv_idx = torch.zeros((2 * F + 1,), dtype=torch.int64)
+    nbr = torch.zeros((2 * F + 1,), dtype=torch.int64)
+    counts = torch.zeros((4,), dtype=torch.int64)
+    has_z = z_clip_value is not None
+    lib().orc_clip_faces(_p(fv), ctypes.c_int64(F), _p(mf), N, _p(pl), mask, int(bool(cull)), int(has_z),
+                         ctypes.c_float(z_clip_value if has_z else 0.0), int(bool(perspective_correct)), _p(out_fv),
+                         _p(first_c), _p(count_c), _p(c2u), _p(conv), _p(conv_idx), _p(nbr), _p(counts))
+    Fc, T3, T4 = (int(x) for x in counts[:3])
+    T = T3 + 2 * T4
+    return dict(face_verts=out_fv[:Fc], first=first_c, count=count_c, faces_clipped_to_unclipped_idx=c2u[:Fc],
+                barycentric_conversion=conv[:T], faces_clipped_to_conversion_idx=conv_idx[:Fc],
+                clipped_faces_neighbor_idx=nbr[:Fc], counts=(Fc, T3, T4))
+
+
+def convert_clipped(pix_to_face_clipped, bary_clipped, c2u, conv, conv_idx):
+    p2f, b = _i64(pix_to_face_clipped), _f32(bary_clipped)
+    S = p2f.numel()
+    p2f_u = torch.empty_like(p2f)
+    b_u = torch.empty_like(b)
+    has = conv is not None and conv.numel() > 0
+    lib().orc_convert_clipped(_p(p2f), _p(b), _p(_i64(c2u)), _p(_f32(conv)) if has else None,
+                              _p(_i64(conv_idx)) if has else None, ctypes.c_int64(S), _p(p2f_u), _p(b_u))
+    return p2f_u, b_u
+
+
 def _per_image(v, N):
     if isinstance(v, torch.Tensor):
         return _f32(v).reshape(-1).expand(N).contiguous() if v.numel() == 1 else _f32(v).reshape(N)

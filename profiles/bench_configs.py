@@ -183,6 +183,28 @@ def main():
     torch.cuda.synchronize()
     row["torch_elementwise_same_gpu_ms_scaled_from_16_images"] = (time.perf_counter() - t0) / 3 * 1e3 * (64 / nb)
     out.append(row)
+    # ---- clipping on the config-3 batch ------------------------------------------------
+    from pytorch3d_amd import clip as pclip
+
+    fv3 = m3.verts_packed()[m3.faces_packed()].contiguous()
+    first3, count3 = m3.mesh_to_faces_packed_first_idx(), m3.num_faces_per_mesh()
+    zmid = float(fv3[:, :, 2].median())
+
+    def clip_noop():  # the usual case: everything in front of the plane -> classification + one sync, early exit
+        return pclip.clip_faces(fv3, first3, count3, pclip.ClipFrustum(left=-1, right=1, top=-1, bottom=1,
+                                                                       perspective_correct=True, z_clip_value=0.1))
+
+    def clip_half():  # stress: the plane cuts through the middle of every mesh
+        return pclip.clip_faces(fv3, first3, count3, pclip.ClipFrustum(left=-1, right=1, top=-1, bottom=1,
+                                                                       perspective_correct=True, z_clip_value=zmid))
+
+    w0, k0 = timed(lib, _lib, clip_noop, iters=10)
+    w1, k1 = timed(lib, _lib, clip_half, iters=10)
+    cf = clip_half()
+    out.append({"config": f"clip_faces on the config-3 batch ({F} faces): no-op plane / plane through the median depth",
+                "noop_wall_ms": w0, "noop_kernels_ms": k0, "half_wall_ms": w1, "half_kernels_ms": k1,
+                "half_faces_out": int(cf.face_verts.shape[0]),
+                "half_conversion_rows": int(cf.barycentric_conversion.shape[0])})
     for o in out:
         print(json.dumps(o), flush=True)
 

@@ -81,6 +81,9 @@ int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t*
               int N, const BinGeom& g, int M, float sqrt_blur, const BinWorkspace& ws, hipStream_t stream,
               bool ordered = true);
 
+// out[i] = sum(in[0..i)) for i in 0..n (n + 1 outputs, int64); blocksum: scratch of ceil(n / 1024) + 1 entries.
+int exclusive_scan_i32(const int* in, int64_t n, long long* blocksum, int64_t* out, hipStream_t stream);
+
 // CSR -> the reference's padded (N,BH,BW,M) int32 layout, -1 filled.
 int bin_expand_padded(const BinWorkspace& ws, int N, const BinGeom& g, int M, int32_t* out, hipStream_t stream);
 

@@ -481,6 +481,14 @@ int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t*
   return launch_status();
 }
 
+int exclusive_scan_i32(const int* in, int64_t n, long long* blocksum, int64_t* out, hipStream_t stream) {
+  if (n <= 0) return P3D_OK;
+  const unsigned nb = (unsigned)ceil_div(n, 1024);
+  bin_block_sums_kernel<<<nb, 1024, 0, stream>>>(in, n, blocksum);
+  bin_scan_offsets_kernel<<<nb, 1024, 0, stream>>>(in, n, blocksum, out);
+  return launch_status();
+}
+
 int bin_expand_padded(const BinWorkspace& ws, int N, const BinGeom& g, int M, int32_t* out, hipStream_t stream) {
   const int64_t rows = (int64_t)N * g.nbins;
   const int64_t n = rows * M;

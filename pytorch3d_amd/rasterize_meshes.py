@@ -1,10 +1,9 @@
 """Host-side mirror of pytorch3d/renderer/mesh/rasterize_meshes.py:32-357 over pytorch3d_amd._C.
 
 Same function name, arguments, defaults, heuristics and error messages as the reference's L2
-entry point, so the parity tests read like the reference's own tests.  Frustum clipping
-(`z_clip_value` / `cull_to_frustum`, pure-torch pytorch3d/renderer/mesh/clip.py) is SURVEY §8f
-"next" #1 and not part of this path: with the reference installed, use its own
-`rasterize_meshes` through pytorch3d_amd.shim (clip.py then runs unmodified on top of our `_C`).
+entry point, so the parity tests read like the reference's own tests.  Frustum culling / z-plane
+clipping (`z_clip_value` / `cull_to_frustum`; pure torch in the reference, pytorch3d/renderer/mesh/clip.py)
+runs on the HIP kernels of pytorch3d_amd.clip.
 """
 from typing import List, Optional, Tuple, Union
 
@@ -50,10 +49,6 @@ def rasterize_meshes(
     cull_to_frustum: bool = False,
 ):
     """Returns (pix_to_face, zbuf, barycentric_coords, dists), each (N, H, W, faces_per_pixel[, 3])."""
-    if z_clip_value is not None or cull_to_frustum:
-        raise NotImplementedError(
-            "clip_faces (z_clip_value / cull_to_frustum) is outside the hot path (SURVEY §8f next #1); "
-            "use the reference's rasterize_meshes over pytorch3d_amd.shim.install()")
     verts_packed = meshes.verts_packed()
     faces_packed = meshes.faces_packed()
     face_verts = gather_face_verts(verts_packed, faces_packed)
@@ -62,8 +57,22 @@ def rasterize_meshes(
     im_size = parse_image_size(image_size)
     max_image_size = max(*im_size)
 
-    clipped_faces_neighbor_idx = torch.full(
-        size=(face_verts.shape[0],), fill_value=-1, device=face_verts.device, dtype=torch.int64)
+    clipped_faces = None
+    clipped_faces_neighbor_idx = None
+    if z_clip_value is not None or cull_to_frustum:
+        # rasterize_meshes.py:160-183: cull faces outside the view frustum, clip faces partially behind the camera
+        from .clip import ClipFrustum, clip_faces
+
+        frustum = ClipFrustum(left=-1, right=1, top=-1, bottom=1, perspective_correct=perspective_correct,
+                              z_clip_value=z_clip_value, cull=cull_to_frustum)
+        clipped_faces = clip_faces(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, frustum=frustum)
+        face_verts = clipped_faces.face_verts
+        mesh_to_face_first_idx = clipped_faces.mesh_to_face_first_idx
+        num_faces_per_mesh = clipped_faces.num_faces_per_mesh
+        clipped_faces_neighbor_idx = clipped_faces.clipped_faces_neighbor_idx
+    if clipped_faces_neighbor_idx is None:
+        clipped_faces_neighbor_idx = torch.full(
+            size=(face_verts.shape[0],), fill_value=-1, device=face_verts.device, dtype=torch.int64)
 
     if bin_size is None:
         bin_size = default_bin_size(max_image_size)
@@ -75,9 +84,16 @@ def rasterize_meshes(
     if max_faces_per_bin is None:
         max_faces_per_bin = int(max(10000, meshes._F / 5))
 
-    return _RasterizeFaceVerts.apply(face_verts, mesh_to_face_first_idx, num_faces_per_mesh,
-                                     clipped_faces_neighbor_idx, im_size, blur_radius, faces_per_pixel, bin_size,
-                                     max_faces_per_bin, perspective_correct, clip_barycentric_coords, cull_backfaces)
+    pix_to_face, zbuf, barycentric_coords, dists = _RasterizeFaceVerts.apply(
+        face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, im_size, blur_radius,
+        faces_per_pixel, bin_size, max_faces_per_bin, perspective_correct, clip_barycentric_coords, cull_backfaces)
+    if clipped_faces is not None:
+        # rasterize_meshes.py:239-249: fragments of the clipped faces -> fragments of the original faces
+        from .clip import convert_clipped_rasterization_to_original_faces
+
+        pix_to_face, barycentric_coords = convert_clipped_rasterization_to_original_faces(
+            pix_to_face, barycentric_coords, clipped_faces)
+    return pix_to_face, zbuf, barycentric_coords, dists
 
 
 def gather_face_verts(verts_packed, faces_packed):

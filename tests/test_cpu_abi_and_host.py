@@ -35,7 +35,8 @@ def test_header_declares_the_operator_surface():
                  "p3d_rasterize_points_backward", "p3d_composite_forward", "p3d_composite_backward",
                  "p3d_interp_face_attrs_forward", "p3d_interp_face_attrs_backward", "p3d_sigmoid_alpha_blend_forward",
                  "p3d_sigmoid_alpha_blend_backward", "p3d_softmax_rgb_blend_forward", "p3d_softmax_rgb_blend_backward",
-                 "p3d_gather_face_verts", "p3d_scatter_face_grads"):
+                 "p3d_gather_face_verts", "p3d_scatter_face_grads", "p3d_clip_faces_plan", "p3d_clip_faces_emit",
+                 "p3d_clip_faces_backward", "p3d_convert_clipped_forward", "p3d_convert_clipped_backward"):
         assert want in names
 
 
@@ -161,7 +162,7 @@ def test_l2_mirror_heuristics_follow_the_reference():
 
     with pytest.raises(ValueError, match="bin_size too small"):
         rm.rasterize_meshes(M(), image_size=512, bin_size=8)  # tests/test_rasterize_meshes.py:461-466
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="GPU path only"):  # clipping is implemented: it reaches the GPU check
         rm.rasterize_meshes(M(), image_size=32, z_clip_value=0.1)
 
 

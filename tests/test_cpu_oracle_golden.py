@@ -246,3 +246,31 @@ def test_oracle_softmax_rgb_blend_vs_reference_python(tag):
     for got, name in ((gc, "grad_colors"), (gd, "grad_dists"), (gz, "grad_zbuf")):
         ref = k(name)
         assert torch.allclose(got, ref, atol=2e-5 * max(1.0, ref.abs().max().item()), rtol=2e-4), name
+
+
+# ---------------------------------------------------------------------------------------------
+# clipping: reference clip_faces / convert_clipped_rasterization_to_original_faces
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_oracle_clip_faces_vs_reference_python(tag):
+    g = _load("clip_ref")
+    k = lambda n: g[f"{tag}_{n}"]
+    z = float(k("z_clip")) if k("has_z_clip") else None
+    o = orc.clip_faces(k("face_verts"), k("first"), [-1, 1, -1, 1, None, None], bool(k("cull")), z, bool(k("persp")))
+    Fc, T3, T4 = o["counts"]
+    assert Fc == k("out_face_verts").shape[0]
+    assert torch.allclose(o["face_verts"], k("out_face_verts"), atol=1e-6, rtol=1e-6)
+    assert torch.equal(o["first"], k("out_first")) and torch.equal(o["count"], k("out_count"))
+    if k("has_faces_clipped_to_unclipped_idx"):
+        assert torch.equal(o["faces_clipped_to_unclipped_idx"], k("faces_clipped_to_unclipped_idx"))
+    if k("has_barycentric_conversion"):
+        assert torch.allclose(o["barycentric_conversion"], k("barycentric_conversion"), atol=1e-6, rtol=1e-6)
+        assert torch.equal(o["faces_clipped_to_conversion_idx"], k("faces_clipped_to_conversion_idx"))
+        assert torch.equal(o["clipped_faces_neighbor_idx"], k("clipped_faces_neighbor_idx"))
+    else:
+        assert T3 + T4 == 0
+    if k("has_faces_clipped_to_unclipped_idx"):
+        p2f_u, bary_u = orc.convert_clipped(k("conv_p2f"), k("conv_bary"), o["faces_clipped_to_unclipped_idx"],
+                                            o["barycentric_conversion"], o["faces_clipped_to_conversion_idx"])
+        assert torch.equal(p2f_u, k("conv_out_p2f"))
+        assert torch.allclose(bary_u, k("conv_out_bary"), atol=1e-6, rtol=1e-6)
