@@ -70,7 +70,8 @@ struct TopKReg {
   P3D_HDM void insert(int K, float cz, int cidx, const float (&cpl)[NP]) {
     bool lt[KT];
 #pragma unroll
-    for (int k = 0; k < KT; ++k) lt[k] = (cz < z[k]) || (cz == z[k] && cidx < idx[k]);
+    // bitwise, not short-circuit: `||` / `&&` compile to exec-masked branches (12 instructions per slot instead of 5)
+    for (int k = 0; k < KT; ++k) lt[k] = (cz < z[k]) | ((cz == z[k]) & (cidx < idx[k]));
 #pragma unroll
     for (int k = KT - 1; k >= 1; --k) {
       const float tz = lt[k - 1] ? z[k - 1] : cz;
@@ -100,7 +101,7 @@ struct TopKReg {
   }
 
   // Exact pre-test: can (cz, cidx) enter the queue at all?
-  P3D_HDM bool admits(int /*K*/, float cz, int cidx) const { return (cz < kz) || (cz == kz && cidx < ki); }
+  P3D_HDM bool admits(int /*K*/, float cz, int cidx) const { return (cz < kz) | ((cz == kz) & (cidx < ki)); }
 
   // Depth a candidate must not exceed to enter the queue: the K-th entry's z, +inf while the queue has room.
   P3D_HDM float kth_z(int /*K*/) const { return kz; }
