@@ -210,7 +210,7 @@ P3D_HD bool face_hit(f3 v0, f3 v1, f3 v2, f2 p, float blur_radius, bool perspect
     return false;
   }
   const float dist = tri_dist2(p, a, b, c);
-  const bool inside = bp.x > 0.0f && bp.y > 0.0f && bp.z > 0.0f;
+  const bool inside = (bp.x > 0.0f) & (bp.y > 0.0f) & (bp.z > 0.0f);
   if (!inside && dist >= blur_radius) {
     return false;
   }
@@ -352,23 +352,18 @@ P3D_HD TriGrad tri_dist2_bwd(f2 p, f2 v0, f2 v1, f2 v2, float g) {
   const float e01 = seg_dist2(p, v0, v1);
   const float e02 = seg_dist2(p, v0, v2);
   const float e12 = seg_dist2(p, v1, v2);
+  // Which edge is closest (ties: e01, then e02, then e12); 3 = none (NaN distances).  The three candidate
+  // branches of the reference are folded into ONE evaluation on selected endpoints: lanes of a wave pick
+  // different edges, and divergent branches would run the edge gradient three times.
+  const int sel = ((e01 <= e02) & (e01 <= e12)) ? 0 : (((e02 <= e01) & (e02 <= e12)) ? 1 : (((e12 <= e01) & (e12 <= e02)) ? 2 : 3));
+  const f2 ea = sel == 2 ? v1 : v0;
+  const f2 eb = sel == 0 ? v1 : v2;
+  const SegGrad s = seg_dist2_bwd(p, ea, eb, sel == 3 ? 0.0f : g);
+  const f2 zero = mk2(0.0f, 0.0f);
   TriGrad r;
-  r.d0 = mk2(0.0f, 0.0f);
-  r.d1 = mk2(0.0f, 0.0f);
-  r.d2 = mk2(0.0f, 0.0f);
-  if (e01 <= e02 && e01 <= e12) {
-    const SegGrad s = seg_dist2_bwd(p, v0, v1, g);
-    r.d0 = s.da;
-    r.d1 = s.db;
-  } else if (e02 <= e01 && e02 <= e12) {
-    const SegGrad s = seg_dist2_bwd(p, v0, v2, g);
-    r.d0 = s.da;
-    r.d2 = s.db;
-  } else if (e12 <= e01 && e12 <= e02) {
-    const SegGrad s = seg_dist2_bwd(p, v1, v2, g);
-    r.d1 = s.da;
-    r.d2 = s.db;
-  }
+  r.d0 = sel <= 1 ? s.da : zero;
+  r.d1 = sel == 0 ? s.db : (sel == 2 ? s.da : zero);
+  r.d2 = (sel == 1 || sel == 2) ? s.db : zero;
   return r;
 }
 
@@ -392,7 +387,7 @@ P3D_HD FaceGrad face_sample_bwd(f3 v0, f3 v1, f3 v2, f2 p, float g_zbuf, f3 g_ba
   const f3 bw = bary_coords<true>(p, a, b, c);
   const f3 bp = perspective_correct ? bary_perspective<true>(bw, v0.z, v1.z, v2.z) : bw;
   const f3 bc = clip_bary ? bary_clip<true>(bp) : bp;
-  const bool inside = bp.x > 0.0f && bp.y > 0.0f && bp.z > 0.0f;
+  const bool inside = (bp.x > 0.0f) & (bp.y > 0.0f) & (bp.z > 0.0f);
   const float sign = inside ? -1.0f : 1.0f;
 
   const TriGrad dd = tri_dist2_bwd(p, a, b, c, sign * g_dist);
