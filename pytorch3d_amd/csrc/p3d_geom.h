@@ -230,6 +230,9 @@ struct EdgeGrad {
 };
 
 P3D_HD EdgeGrad edge_fn_bwd(f2 p, f2 a, f2 b, float g) {
+#if defined(__clang__)
+#pragma clang fp contract(fast)  // gradient-only arithmetic (tolerance-gated): let mul+add fuse into FMA
+#endif
   EdgeGrad r;
   r.dp = mk2(g * (b.y - a.y), g * (a.x - b.x));
   r.da = mk2(g * (p.y - b.y), g * (b.x - p.x));
@@ -244,6 +247,9 @@ struct TriGrad {
 P3D_HD f2 add2(f2 a, f2 b) { return mk2(a.x + b.x, a.y + b.y); }
 
 P3D_HD TriGrad bary_coords_bwd(f2 p, f2 v0, f2 v1, f2 v2, f3 g) {
+#if defined(__clang__)
+#pragma clang fp contract(fast)  // gradient-only arithmetic (tolerance-gated): let mul+add fuse into FMA
+#endif
   const float area = bary_area(v0, v1, v2);
   const float area2 = area * area;
   const float e0 = edge_fn(p, v1, v2);
@@ -286,6 +292,9 @@ struct PerspGrad {
 };
 
 P3D_HD PerspGrad bary_perspective_bwd(f3 b, float z0, float z1, float z2, f3 g) {
+#if defined(__clang__)
+#pragma clang fp contract(fast)  // gradient-only arithmetic (tolerance-gated): let mul+add fuse into FMA
+#endif
   const float t0 = b.x * z1 * z2;
   const float t1 = z0 * b.y * z2;
   const float t2 = z0 * z1 * b.z;
@@ -305,6 +314,9 @@ P3D_HD PerspGrad bary_perspective_bwd(f3 b, float z0, float z1, float z2, f3 g) 
 }
 
 P3D_HD f3 bary_clip_bwd(f3 b, f3 g) {
+#if defined(__clang__)
+#pragma clang fp contract(fast)  // gradient-only arithmetic (tolerance-gated): let mul+add fuse into FMA
+#endif
   const float w0 = b.x > 0.0f ? b.x : 0.0f;
   const float w1 = b.y > 0.0f ? b.y : 0.0f;
   const float w2 = b.z > 0.0f ? b.z : 0.0f;
@@ -331,6 +343,9 @@ struct SegGrad {
 };
 
 P3D_HD SegGrad seg_dist2_bwd(f2 p, f2 a, f2 b, float g) {
+#if defined(__clang__)
+#pragma clang fp contract(fast)  // gradient-only arithmetic (tolerance-gated): let mul+add fuse into FMA
+#endif
   const float bax = b.x - a.x;
   const float bay = b.y - a.y;
   const float bot = bax * bax + bay * bay;
@@ -379,6 +394,9 @@ struct FaceGrad {
 
 P3D_HD FaceGrad face_sample_bwd(f3 v0, f3 v1, f3 v2, f2 p, float g_zbuf, f3 g_bary, float g_dist,
                                 bool perspective_correct, bool clip_bary, bool clip_bwd_on_corrected) {
+#if defined(__clang__)
+#pragma clang fp contract(fast)  // gradient-only arithmetic (tolerance-gated): let mul+add fuse into FMA
+#endif
   const f2 a = mk2(v0.x, v0.y);
   const f2 b = mk2(v1.x, v1.y);
   const f2 c = mk2(v2.x, v2.y);
