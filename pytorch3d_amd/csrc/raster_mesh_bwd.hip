@@ -49,7 +49,7 @@ struct BwdArgs {
   int N, H, W, K;
   int RY, RX;  // regions per image
   int persp, clip;
-  int debug;  // P3D_DEBUG_BWD ablation bits (profiles/ablate.py): 1 no compute, 2 no accumulate, 4 no vertex gathers
+  int debug;  // P3D_DEBUG_BWD ablation bits (profiles/ablate.py): 1 no compute, 2 no accumulate, 4 no vertex gathers, 8 no global atomics in the table flush
 };
 
 // Row loaders: KT contiguous elements starting at a (KT * elemsize)-aligned address.
@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
 
   FaceTable tab;
   tab.init(s_table[w], lane);
+  tab.no_atomics = (a.debug & 8) != 0;
   const bool persp = a.persp != 0, clip = a.clip != 0;
 
 #pragma unroll 1

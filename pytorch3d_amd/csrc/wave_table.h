@@ -32,6 +32,7 @@ struct WaveTable {
   volatile int* owner;  // [SLOTS] scratch for the per-step visitor lists, -1 between steps
   float* vals;          // [NV][SLOTS]
   int used;             // occupied slots (wave-uniform)
+  bool no_atomics = false;  // ablation only (profiles/ablate.py): drop the global atomics of flush()
 
   __device__ __forceinline__ void init(int* lds, int lane) {
     keys = lds;
@@ -59,7 +60,8 @@ struct WaveTable {
       if (f != kEmptyKey) {
         float* o = out + (int64_t)f * NV;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) unsafeAtomicAdd(o + j, vals[j * SLOTS + s]);
+        for (int j = 0; j < NV; ++j)
+          if (!no_atomics) unsafeAtomicAdd(o + j, vals[j * SLOTS + s]);
         keys[s] = kEmptyKey;
       }
     }
