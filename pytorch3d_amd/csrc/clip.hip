@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void convert_fwd_kernel(const int64_t* __restr
   }
 }
 
-using ConvTable = WaveTable<9, 232>;
+using ConvTable = WaveTable<9, 182>;
 
 __global__ __launch_bounds__(256) void convert_bwd_kernel(const int64_t* __restrict__ p2f_c,
                                                           const float* __restrict__ bary_c,
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void convert_bwd_kernel(const int64_t* __restr
                                                           const int64_t* __restrict__ conv_idx,
                                                           const float* __restrict__ g_u, int64_t S, int64_t span,
                                                           float* __restrict__ g_bary_c, float* __restrict__ g_conv) {
-  __shared__ int s_table[4][ConvTable::kLdsInts];
+  __shared__ __align__(16) int s_table[4][ConvTable::kLdsInts];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t begin = ((int64_t)blockIdx.x * 4 + w) * span;
   if (begin >= S) return;  // wave-uniform; no workgroup barrier in this kernel

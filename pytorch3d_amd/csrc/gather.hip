@@ -29,12 +29,12 @@ __global__ __launch_bounds__(256) void gather_faces_kernel(const float* __restri
 // A vertex is shared by ~6 faces that sit close together in the face list, so consecutive corners
 // are merged in a wave-private LDS table (wave_table.h) first: one global atomic per (wave span,
 // vertex, component) instead of one per (corner, component).
-using VertTable = WaveTable<3, 512>;  // 4 waves x 512 x 20 B = 40 KB
+using VertTable = WaveTable<3, 426>;  // 4 waves x 426 x 24 B = 40 KB
 
 __global__ __launch_bounds__(256) void scatter_face_grads_kernel(const float* __restrict__ grad_face_verts,
                                                                  const int64_t* __restrict__ faces, int64_t n_corners,
                                                                  int64_t span, float* __restrict__ grad_verts) {
-  __shared__ int s_table[4][VertTable::kLdsInts];
+  __shared__ __align__(16) int s_table[4][VertTable::kLdsInts];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t begin = ((int64_t)blockIdx.x * 4 + w) * span;
   if (begin >= n_corners) return;  // wave-uniform; no workgroup barrier in this kernel

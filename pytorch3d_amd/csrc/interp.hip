@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void interp_bwd_kernel(const int64_t* __restri
 template <int D>
 struct InterpTable {
   static constexpr int NV = 3 * D;
-  static constexpr int kSlots = NV == 3 ? 512 : NV == 6 ? 320 : NV == 9 ? 232 : 182;  // 4 waves <= 40 KB of LDS
+  static constexpr int kSlots = NV == 3 ? 426 : NV == 6 ? 256 : 182;  // 4 waves x slots x (8 + 4 * stride) B <= 40 KB
   using T = WaveTable<NV, kSlots>;
 };
 
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void interp_bwd_table_kernel(const int64_t* __
                                                                float* __restrict__ gbary, float* __restrict__ gattrs) {
   using Tab = typename InterpTable<D>::T;
   constexpr int NV = 3 * D;
-  __shared__ int s_table[4][Tab::kLdsInts];
+  __shared__ __align__(16) int s_table[4][Tab::kLdsInts];
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
   const int64_t wave = (int64_t)blockIdx.x * 4 + w;

@@ -36,8 +36,8 @@ namespace p3d {
 namespace {
 
 constexpr int kRegion = 32;  // pixels per workgroup-region side (four 16x16 wave areas)
-// 4 waves x 232 slots x (8 + 9*4) B = 40832 B of LDS -> 4 workgroups per CU
-using FaceTable = WaveTable<9, 232>;
+// 4 waves x 182 slots x (8 + 12*4) B = 40768 B of LDS -> 4 workgroups per CU
+using FaceTable = WaveTable<9, 182>;
 
 struct BwdArgs {
   const float* face_verts;
@@ -49,7 +49,7 @@ struct BwdArgs {
   int N, H, W, K;
   int RY, RX;  // regions per image
   int persp, clip;
-  int debug;  // P3D_DEBUG_BWD ablation bits (profiles/ablate.py): 1 no compute, 2 no accumulate, 4 no vertex gathers, 8 no global atomics in the table flush
+  int debug;  // P3D_DEBUG_BWD ablation bits (profiles/ablate.py): 1 no compute, 2 no accumulate, 4 no vertex gathers, 8 no global atomics in the table flush, 16 / 32 see wave_table.h
 };
 
 // Row loaders: KT contiguous elements starting at a (KT * elemsize)-aligned address.
@@ -95,7 +95,7 @@ __device__ __forceinline__ void load_f32_row(const float* p, float (&out)[M]) {
 // KT > 0: K == KT, rows read with vector loads.  KT == 0: any K, per-slot scalar loads.
 template <int KT>
 __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
-  __shared__ int s_table[4][FaceTable::kLdsInts];
+  __shared__ __align__(16) int s_table[4][FaceTable::kLdsInts];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
   FaceTable tab;
   tab.init(s_table[w], lane);
   tab.no_atomics = (a.debug & 8) != 0;
+  tab.dbg = a.debug;
   const bool persp = a.persp != 0, clip = a.clip != 0;
 
 #pragma unroll 1

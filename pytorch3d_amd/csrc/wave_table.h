@@ -11,8 +11,10 @@
 //   2. the visitors of a slot are chained with ONE integer LDS exchange per lane (ds_wrxchg_rtn
 //      returns the previous visitor); the last visitor heads the list;
 //   3. partials are summed along the lists by pointer jumping over ds_bpermute (log2(group) steps);
-//   4. list heads fold their totals into the table with plain LDS loads / stores (distinct
+//   4. list heads fold their totals into the table with plain 16-byte LDS loads / stores (distinct
 //      primitives -> distinct slots within one wave instruction).
+// The callers are bound by LDS instruction issue, so a step in which no two lanes share a primitive (detected
+// from the exchange itself: owners carry a step stamp, nothing is ever reset) skips 2.-3. entirely.
 // The table is flushed with global f32 atomics (NV per occupied slot) when it runs full and at
 // the end.  Everything here must be called by all 64 lanes of the wave (wave-uniform control flow).
 #pragma once
@@ -25,23 +27,27 @@ constexpr int kEmptyKey = -1;
 
 template <int NV, int SLOTS>
 struct WaveTable {
-  static constexpr int kFlushAt = SLOTS - 64;  // a step adds at most 64 primitives: the table cannot overflow
-  static constexpr int kLdsInts = SLOTS * (2 + NV);
+  static constexpr int kStride = (NV + 3) / 4 * 4;  // floats per slot: values are moved as 16-byte chunks
+  static constexpr int kFlushAt = SLOTS - 64;       // a step adds at most 64 primitives: the table cannot overflow
+  static constexpr int kLdsInts = SLOTS * (2 + kStride);
 
   volatile int* keys;   // [SLOTS] primitive id or kEmptyKey (volatile: other lanes write between my store and re-load)
-  volatile int* owner;  // [SLOTS] scratch for the per-step visitor lists, -1 between steps
-  float* vals;          // [NV][SLOTS]
+  volatile int* owner;  // [SLOTS] last visitor of the slot, stamped with the step number (never needs resetting)
+  float* vals;          // [SLOTS][kStride]
   int used;             // occupied slots (wave-uniform)
+  int gen;              // step counter (wave-uniform), > 0
   bool no_atomics = false;  // ablation only (profiles/ablate.py): drop the global atomics of flush()
+  int dbg = 0;              // ablation only (results become wrong): 16 skip the list summation, 32 skip the table update
 
   __device__ __forceinline__ void init(int* lds, int lane) {
-    keys = lds;
-    owner = lds + SLOTS;
-    vals = reinterpret_cast<float*>(lds + 2 * SLOTS);
+    vals = reinterpret_cast<float*>(lds);  // first: keeps the 16-byte alignment of the workgroup's array
+    keys = lds + SLOTS * kStride;
+    owner = lds + SLOTS * kStride + SLOTS;
     used = 0;
+    gen = 0;
     for (int i = lane; i < SLOTS; i += 64) {
       keys[i] = kEmptyKey;
-      owner[i] = -1;
+      owner[i] = 0;
     }
   }
 
@@ -53,7 +59,7 @@ struct WaveTable {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
   }
 
-  // out[f * NV + j] += vals[j][slot] for every occupied slot; empties the table.
+  // out[f * NV + j] += vals[slot][j] for every occupied slot; empties the table.
   __device__ __forceinline__ void flush(float* __restrict__ out, int lane) {
     for (int s = lane; s < SLOTS; s += 64) {
       const int f = keys[s];
@@ -61,7 +67,7 @@ struct WaveTable {
         float* o = out + (int64_t)f * NV;
 #pragma unroll
         for (int j = 0; j < NV; ++j)
-          if (!no_atomics) unsafeAtomicAdd(o + j, vals[j * SLOTS + s]);
+          if (!no_atomics) unsafeAtomicAdd(o + j, vals[s * kStride + j]);
         keys[s] = kEmptyKey;
       }
     }
@@ -69,8 +75,11 @@ struct WaveTable {
   }
 
   // One step: every lane with f >= 0 contributes g[0..NV) to primitive f.  g is clobbered.
+  // LDS instruction count is what bounds the callers, so the common step -- no two lanes share a primitive -- costs
+  // one key load, one exchange and kStride/4 16-byte loads + stores per lane, nothing else.
   __device__ __forceinline__ void add(float* __restrict__ out, int lane, int f, float (&g)[NV]) {
     if (used > kFlushAt) flush(out, lane);
+    ++gen;
     const bool active = f >= 0;
     int slot = -1;
     bool fresh = false;
@@ -93,28 +102,39 @@ struct WaveTable {
         h = (h + 1 == SLOTS) ? 0 : h + 1;
       }
     }
+    // chain the visitors of each slot: prev = the lane that visited before me in THIS step (stamp check)
+    const int stamp = (gen << 6) | lane;
     int prev = -1;
-    if (active) prev = atomicExch(const_cast<int*>(&owner[slot]), lane);
-    const bool head = active && owner[slot] == lane;  // the last visitor heads the list
-    // after step s every lane holds the sum of the 2^s list entries starting at itself
-    while (__ballot(prev >= 0)) {
-      const int src = prev >= 0 ? prev : lane;
-#pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        const float o = lane_read(g[j], src);
-        if (prev >= 0) g[j] += o;
-      }
-      const int pp = __builtin_amdgcn_ds_bpermute(src << 2, prev);
-      prev = prev >= 0 ? pp : -1;
+    if (active) {
+      const int old = atomicExch(const_cast<int*>(&owner[slot]), stamp);
+      prev = (old >> 6) == gen ? (old & 63) : -1;
     }
-    if (head) {
-      owner[slot] = -1;
-      if (fresh) {
+    bool head = active;
+    if (__ballot(prev >= 0)) {  // wave-uniform: some primitive is hit by more than one lane
+      head = active && owner[slot] == stamp;  // the last visitor heads the list
+      // after step s every lane holds the sum of the 2^s list entries starting at itself
+      while (__ballot(prev >= 0) && !(dbg & 16)) {
+        const int src = prev >= 0 ? prev : lane;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) vals[j * SLOTS + slot] = g[j];
-      } else {
+        for (int j = 0; j < NV; ++j) {
+          const float o = lane_read(g[j], src);
+          if (prev >= 0) g[j] += o;
+        }
+        const int pp = __builtin_amdgcn_ds_bpermute(src << 2, prev);
+        prev = prev >= 0 ? pp : -1;
+      }
+    }
+    if (head && !(dbg & 32)) {
+      float4* row = reinterpret_cast<float4*>(vals + slot * kStride);
 #pragma unroll
-        for (int j = 0; j < NV; ++j) vals[j * SLOTS + slot] += g[j];
+      for (int c = 0; c < kStride / 4; ++c) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!fresh) t = row[c];
+        t.x += g[4 * c];
+        if (4 * c + 1 < NV) t.y += g[4 * c + 1];
+        if (4 * c + 2 < NV) t.z += g[4 * c + 2];
+        if (4 * c + 3 < NV) t.w += g[4 * c + 3];
+        row[c] = t;
       }
     }
     used += __popcll(__ballot(head && fresh));
