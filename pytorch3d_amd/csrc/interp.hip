@@ -32,6 +32,37 @@ __global__ __launch_bounds__(256) void interp_fwd_kernel(const int64_t* __restri
   }
 }
 
+// f32, D <= 4: one thread per sample -- pix_to_face (8 B), the barycentrics (12 B) and the D outputs are each read /
+// written once, coalesced; the generic kernel above is one thread per (sample, d) and pays a 64-bit division per
+// element plus D-fold re-reads.
+template <int D>
+__global__ __launch_bounds__(256) void interp_fwd_small_kernel(const int64_t* __restrict__ p2f,
+                                                               const float* __restrict__ bary,
+                                                               const float* __restrict__ attrs, int64_t P,
+                                                               float* __restrict__ out) {
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (int64_t)gridDim.x * 256) {
+    const int64_t f = p2f[p];
+    float v[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) v[d] = 0.0f;
+    if (f >= 0) {
+      const float w0 = bary[p * 3], w1 = bary[p * 3 + 1], w2 = bary[p * 3 + 2];
+      const float* a = attrs + f * 3 * D;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        // same association as the generic kernel: ((0 + w0*a0) + w1*a1) + w2*a2
+        float t = 0.0f;
+        t += w0 * a[d];
+        t += w1 * a[D + d];
+        t += w2 * a[2 * D + d];
+        v[d] = t;
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) out[p * D + d] = v[d];
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void interp_bwd_kernel(const int64_t* __restrict__ p2f, const T* __restrict__ bary,
                                                          const T* __restrict__ attrs, const T* __restrict__ gout,
@@ -146,6 +177,19 @@ P3D_API int p3d_interp_face_attrs_forward(int dtype, const int64_t* p2f, const v
   if (!p2f || !bary || !out || (F > 0 && !attrs)) return P3D_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
   LaunchScope ls("interp_fwd", s);
+  if (dtype == 0 && D >= 1 && D <= 4) {
+    const float* b = (const float*)bary;
+    const float* at = (const float*)attrs;
+    float* o = (float*)out;
+    const unsigned g = pick_grid(P);
+    switch (D) {
+      case 1: interp_fwd_small_kernel<1><<<g, 256, 0, s>>>(p2f, b, at, P, o); break;
+      case 2: interp_fwd_small_kernel<2><<<g, 256, 0, s>>>(p2f, b, at, P, o); break;
+      case 3: interp_fwd_small_kernel<3><<<g, 256, 0, s>>>(p2f, b, at, P, o); break;
+      default: interp_fwd_small_kernel<4><<<g, 256, 0, s>>>(p2f, b, at, P, o); break;
+    }
+    return launch_status();
+  }
   if (dtype == 0)
     interp_fwd_kernel<float><<<pick_grid(P * D), 256, 0, s>>>(p2f, (const float*)bary, (const float*)attrs, P, D,
                                                              (float*)out);
