@@ -232,6 +232,14 @@ int p3d_softmax_rgb_blend_backward(const float* grad_out, const float* colors, c
                                    const float* zfar_per_image, int64_t N, int64_t pix_per_image, int K,
                                    float* grad_colors, float* grad_dists, float* grad_zbuf, p3d_stream_t stream);
 
+/* The same backward when the caller knows that the P samples are image-shaped fragments (N,H,W,K) -- what
+ * interpolate_face_attributes has before it flattens them (pytorch3d/ops/interp_face_attrs.py:57-63): lanes map to
+ * 8x8 pixel tiles instead of 64 consecutive samples.  f32, D <= 4. */
+int p3d_interp_face_attrs_backward_nhwk(const int64_t* pix_to_face, const float* barycentric_coords,
+                                        const float* face_attrs, const float* grad_pix_attrs, int N, int H, int W, int K,
+                                        int64_t F, int D, float* grad_barycentric_coords, float* grad_face_attrs,
+                                        p3d_stream_t stream);
+
 /* ---- built-in per-kernel timing (HIP events on the launch stream) --------------------- */
 
 /* enable != 0: every kernel launch is bracketed by hipEventRecord on its stream. */

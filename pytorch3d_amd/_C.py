@@ -456,8 +456,9 @@ def interp_face_attrs_forward(pix_to_face, barycentric_coords, face_attrs):
     return out
 
 
-def interp_face_attrs_backward(pix_to_face, barycentric_coords, face_attrs, grad_pix_attrs):
-    """InterpFaceAttrsBackward, interp_face_attrs.h:95-116.  Returns (grad_bary (P,3), grad_face_attrs (F,3,D))."""
+def interp_face_attrs_backward(pix_to_face, barycentric_coords, face_attrs, grad_pix_attrs, image_shape=None):
+    """InterpFaceAttrsBackward, interp_face_attrs.h:95-116.  Returns (grad_bary (P,3), grad_face_attrs (F,3,D)).
+    image_shape=(N,H,W,K) (ours, optional): the P samples are image-shaped fragments -> tile-mapped kernel."""
     dev = _same_device(("pix_to_face", pix_to_face), ("barycentric_coords", barycentric_coords),
                        ("face_attributes", face_attrs), ("pix_attrs", grad_pix_attrs))
     if not (barycentric_coords.dtype == face_attrs.dtype == grad_pix_attrs.dtype) or face_attrs.dtype not in _DTYPES:
@@ -478,6 +479,13 @@ def interp_face_attrs_backward(pix_to_face, barycentric_coords, face_attrs, grad
     with torch.cuda.device(dev):
         gb = torch.empty((P, 3), dtype=attrs.dtype, device=dev)
         gf = torch.empty((F, 3, D), dtype=attrs.dtype, device=dev)
+        if (image_shape is not None and attrs.dtype == torch.float32 and 1 <= D <= 4 and F > 0
+                and image_shape[0] * image_shape[1] * image_shape[2] * image_shape[3] == P):
+            n_, h_, w_, k_ = (int(x) for x in image_shape)
+            rc = lib.p3d_interp_face_attrs_backward_nhwk(_ptr(p2f), _ptr(bary), _ptr(attrs), _ptr(g), n_, h_, w_, k_, F, D,
+                                                         _ptr(gb), _ptr(gf), _stream(dev))
+            _lib.check(rc, "interp_face_attrs_backward")
+            return gb, gf
         rc = lib.p3d_interp_face_attrs_backward(_DTYPES[attrs.dtype], _ptr(p2f), _ptr(bary), _ptr(attrs), _ptr(g), P, F,
                                                 D, _ptr(gb), _ptr(gf), _stream(dev))
         _lib.check(rc, "interp_face_attrs_backward")

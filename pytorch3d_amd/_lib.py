@@ -53,6 +53,8 @@ _SIGNATURES = {
     "p3d_interp_face_attrs_forward": (c_int, [c_int, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     "p3d_interp_face_attrs_backward": (c_int, [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr,
                                                c_ptr]),
+    "p3d_interp_face_attrs_backward_nhwk": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_i64, c_int,
+                                                    c_ptr, c_ptr, c_ptr]),
     "p3d_clip_faces_plan_bytes": (c_size, [c_i64]),
     "p3d_clip_faces_plan": (c_int, [c_ptr, c_i64, ctypes.POINTER(c_f32), c_int, c_int, c_int, c_f32, c_ptr, c_size,
                                     c_ptr]),

@@ -158,6 +158,169 @@ void launch_interp_bwd_table(const int64_t* p2f, const float* bary, const float*
   interp_bwd_table_kernel<D><<<(unsigned)blocks, 256, 0, s>>>(p2f, bary, attrs, gout, P, span, gbary, gattrs);
 }
 
+// ---- image-shaped backward: the caller knows that the P samples are (N, H, W, K) fragments ---------------------
+// Lanes then map to the 64 pixels of an 8x8 tile and steps to the K slots (like the mesh backward): same-face lanes
+// are spatial neighbours (more merging per table step), K slots that are empty across the tile are skipped whole, and a
+// lane reads / writes its pixel's K-rows with 16-byte accesses.  2.2 ms -> 1.x ms on the 134M-sample fragments.
+template <int KT>
+__device__ __forceinline__ void ld_idx_row(const int64_t* p, int (&out)[KT]) {
+  if constexpr (KT % 2 == 0) {
+#pragma unroll
+    for (int k = 0; k < KT; k += 2) {
+      const longlong2 t = *reinterpret_cast<const longlong2*>(p + k);
+      out[k] = (int)t.x;
+      out[k + 1] = (int)t.y;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) out[k] = (int)p[k];
+  }
+}
+template <int M>
+__device__ __forceinline__ void ld_f32_row(const float* p, float (&out)[M]) {
+  if constexpr (M % 4 == 0) {
+#pragma unroll
+    for (int k = 0; k < M; k += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(p + k);
+      out[k] = t.x;
+      out[k + 1] = t.y;
+      out[k + 2] = t.z;
+      out[k + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < M; ++k) out[k] = p[k];
+  }
+}
+template <int M>
+__device__ __forceinline__ void st_f32_row(float* p, const float (&v)[M]) {
+  if constexpr (M % 4 == 0) {
+#pragma unroll
+    for (int k = 0; k < M; k += 4) *reinterpret_cast<float4*>(p + k) = make_float4(v[k], v[k + 1], v[k + 2], v[k + 3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < M; ++k) p[k] = v[k];
+  }
+}
+
+struct InterpTiledArgs {
+  const int64_t* p2f;
+  const float* bary;
+  const float* attrs;
+  const float* gout;
+  float* gbary;
+  float* gattrs;
+  int N, H, W, K, RY, RX;
+};
+
+template <int KT, int D>  // KT > 0: K == KT with vector rows; KT == 0: any K
+__global__ __launch_bounds__(256) void interp_bwd_tiled_kernel(InterpTiledArgs a) {
+  using Tab = typename InterpTable<D>::T;
+  constexpr int NV = 3 * D;
+  __shared__ __align__(16) int s_table[4][Tab::kLdsInts];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  long long t = blockIdx.x;
+  const int rx = (int)(t % a.RX);
+  t /= a.RX;
+  const int ry = (int)(t % a.RY);
+  const int n = (int)(t / a.RY);
+  const int ay = ry * 32 + (w >> 1) * 16, ax = rx * 32 + (w & 1) * 16;
+  const int H = a.H, W = a.W, K = a.K;
+  if (ay >= H || ax >= W) return;  // wave-uniform; no workgroup barrier in this kernel
+  Tab tab;
+  tab.init(s_table[w], lane);
+#pragma unroll 1
+  for (int tile = 0; tile < 4; ++tile) {
+    const int yo = ay + (tile >> 1) * 8 + (lane >> 3);
+    const int xo = ax + (tile & 1) * 8 + (lane & 7);
+    const bool ok = yo < H && xo < W;
+    const int64_t base = (((int64_t)n * H + yo) * W + xo) * K;
+    if constexpr (KT > 0) {
+      int f[KT];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) f[k] = -1;
+      if (ok) ld_idx_row<KT>(a.p2f + base, f);
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) any |= f[k] >= 0;
+      float b[3 * KT], go[D * KT], gb[3 * KT];
+#pragma unroll
+      for (int j = 0; j < 3 * KT; ++j) gb[j] = 0.0f;
+      if (any) {
+        ld_f32_row<3 * KT>(a.bary + base * 3, b);
+        ld_f32_row<D * KT>(a.gout + base * D, go);
+      }
+      if (__ballot(any)) {
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+          if (__ballot(f[k] >= 0) == 0) continue;  // wave-uniform
+          float g[NV];
+          if (f[k] >= 0) {
+            const float* at = a.attrs + (int64_t)f[k] * NV;
+            float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+              const float up = go[k * D + d];
+              g0 += at[d] * up;
+              g1 += at[D + d] * up;
+              g2 += at[2 * D + d] * up;
+              g[d] = b[3 * k] * up;
+              g[D + d] = b[3 * k + 1] * up;
+              g[2 * D + d] = b[3 * k + 2] * up;
+            }
+            gb[3 * k] = g0;
+            gb[3 * k + 1] = g1;
+            gb[3 * k + 2] = g2;
+          }
+          tab.add(a.gattrs, lane, f[k], g);
+        }
+      }
+      if (ok) st_f32_row<3 * KT>(a.gbary + base * 3, gb);
+    } else {
+#pragma unroll 1
+      for (int k = 0; k < K; ++k) {
+        const int64_t i = base + k;
+        const int f = ok ? (int)a.p2f[i] : -1;
+        float g[NV];
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        if (f >= 0) {
+          const float* at = a.attrs + (int64_t)f * NV;
+          const float w0 = a.bary[i * 3], w1 = a.bary[i * 3 + 1], w2 = a.bary[i * 3 + 2];
+#pragma unroll
+          for (int d = 0; d < D; ++d) {
+            const float up = a.gout[i * D + d];
+            g0 += at[d] * up;
+            g1 += at[D + d] * up;
+            g2 += at[2 * D + d] * up;
+            g[d] = w0 * up;
+            g[D + d] = w1 * up;
+            g[2 * D + d] = w2 * up;
+          }
+        }
+        if (ok) {
+          a.gbary[i * 3] = g0;
+          a.gbary[i * 3 + 1] = g1;
+          a.gbary[i * 3 + 2] = g2;
+        }
+        if (__ballot(f >= 0) == 0) continue;  // wave-uniform
+        tab.add(a.gattrs, lane, f, g);
+      }
+    }
+  }
+  if (tab.used > 0) tab.flush(a.gattrs, lane);
+}
+
+template <int D>
+void launch_interp_bwd_tiled(const InterpTiledArgs& a, hipStream_t s) {
+  const unsigned grid = (unsigned)((int64_t)a.N * a.RY * a.RX);
+  if (a.K == 8)
+    interp_bwd_tiled_kernel<8, D><<<grid, 256, 0, s>>>(a);
+  else if (a.K == 4)
+    interp_bwd_tiled_kernel<4, D><<<grid, 256, 0, s>>>(a);
+  else
+    interp_bwd_tiled_kernel<0, D><<<grid, 256, 0, s>>>(a);
+}
+
 unsigned pick_grid(int64_t n) {
   int64_t blocks = ceil_div(n, 256);
   if (blocks > 32768) blocks = 32768;
@@ -196,6 +359,42 @@ P3D_API int p3d_interp_face_attrs_forward(int dtype, const int64_t* p2f, const v
   else
     interp_fwd_kernel<double><<<pick_grid(P * D), 256, 0, s>>>(p2f, (const double*)bary, (const double*)attrs, P, D,
                                                               (double*)out);
+  return launch_status();
+}
+
+P3D_API int p3d_interp_face_attrs_backward_nhwk(const int64_t* p2f, const float* bary, const float* attrs,
+                                                const float* gout, int N, int H, int W, int K, int64_t F, int D,
+                                                float* gbary, float* gattrs, p3d_stream_t stream) {
+  if (N < 0 || H < 0 || W < 0 || K < 0 || F < 0 || D < 1 || D > 4) return P3D_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (F > 0) {
+    if (!gattrs) return P3D_ERR_INVALID_ARG;
+    if (hipMemsetAsync(gattrs, 0, (size_t)F * 3 * D * sizeof(float), s) != hipSuccess) return P3D_ERR_LAUNCH;
+  }
+  const int64_t P = (int64_t)N * H * W * K;
+  if (P == 0) return P3D_OK;
+  if (!p2f || !bary || !gout || !gbary || (F > 0 && !attrs)) return P3D_ERR_INVALID_ARG;
+  InterpTiledArgs a;
+  a.p2f = p2f;
+  a.bary = bary;
+  a.attrs = attrs;
+  a.gout = gout;
+  a.gbary = gbary;
+  a.gattrs = gattrs;
+  a.N = N;
+  a.H = H;
+  a.W = W;
+  a.K = K;
+  a.RY = (int)ceil_div(H, 32);
+  a.RX = (int)ceil_div(W, 32);
+  if ((int64_t)N * a.RY * a.RX > 0x7fffffffll) return P3D_ERR_INVALID_ARG;
+  LaunchScope ls("interp_bwd", s);
+  switch (D) {
+    case 1: launch_interp_bwd_tiled<1>(a, s); break;
+    case 2: launch_interp_bwd_tiled<2>(a, s); break;
+    case 3: launch_interp_bwd_tiled<3>(a, s); break;
+    default: launch_interp_bwd_tiled<4>(a, s); break;
+  }
   return launch_status();
 }
 

@@ -318,3 +318,19 @@ def test_interp_properties_at_full_fragment_size():
     gb, ga = _C.interp_face_attrs_backward(p2f, bary, attrs, g)
     assert torch.allclose(gb, br.grad, atol=1e-5, rtol=1e-5)
     assert torch.allclose(ga, ar.grad, atol=2e-3, rtol=2e-3)
+    # the image-shaped variant (what pytorch3d_amd.interpolate_face_attributes uses): same numbers
+    for shape in ((16, 512, 512, 8), (8, 512, 1024, 8), (64, 512, 512, 2), (1, 4096, 4096, 2), (32, 512, 512, 4)):
+        gb2, ga2 = _C.interp_face_attrs_backward(p2f, bary, attrs, g, image_shape=shape)
+        assert torch.allclose(gb2, br.grad, atol=1e-5, rtol=1e-5), shape
+        assert torch.allclose(ga2, ar.grad, atol=2e-3, rtol=2e-3), shape
+    for D2 in (1, 2, 4):  # generic-K path (K = 3) and the other D instantiations, odd image sizes
+        n, h, w, k = 3, 37, 53, 3
+        P2 = n * h * w * k
+        p2 = p2f[:P2].clone()
+        b2 = bary[:P2].clone().requires_grad_(True)
+        a2 = torch.randn(F, 3, D2, generator=gen).to(d).requires_grad_(True)
+        g2 = torch.randn(P2, D2, generator=gen).to(d)
+        ((b2.unsqueeze(-1) * a2[p2.clamp(min=0)]).sum(1) * (p2 >= 0).float().view(-1, 1) * g2).sum().backward()
+        gb3, ga3 = _C.interp_face_attrs_backward(p2, b2.detach(), a2.detach(), g2, image_shape=(n, h, w, k))
+        assert torch.allclose(gb3, b2.grad, atol=1e-5, rtol=1e-5), D2
+        assert torch.allclose(ga3, a2.grad, atol=1e-4, rtol=1e-4), D2
