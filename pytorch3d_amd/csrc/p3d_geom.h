@@ -140,15 +140,16 @@ P3D_HD float seg_dist2(f2 p, f2 a, f2 b) {
   const float bay = b.y - a.y;
   const float l2 = bax * bax + bay * bay;
   float t = (bax * (p.x - a.x) + bay * (p.y - a.y)) / l2;
-  if ((double)l2 <= P3D_KEPS) {
-    const float ex = p.x - b.x;
-    const float ey = p.y - b.y;
-    return ex * ex + ey * ey;
-  }
+  // degenerate edge (geometry_utils.cuh:345): distance to b.  Both results are formed and one is selected --
+  // a branch here costs more than the five operations it would skip, and it sits in the hottest loop.
+  const float ex = p.x - b.x;
+  const float ey = p.y - b.y;
+  const float d_point = ex * ex + ey * ey;
   t = sat01(t);
   const float dx = (a.x + t * bax) - p.x;
   const float dy = (a.y + t * bay) - p.y;
-  return dx * dx + dy * dy;
+  const float d_seg = dx * dx + dy * dy;
+  return ((double)l2 <= P3D_KEPS) ? d_point : d_seg;
 }
 
 // Squared distance to the triangle boundary (geometry_utils.cuh:397-408).
@@ -206,18 +207,15 @@ P3D_HD bool face_hit(f3 v0, f3 v1, f3 v2, f2 p, float blur_radius, bool perspect
   const f3 bp = perspective_correct ? bary_perspective(bw, v0.z, v1.z, v2.z) : bw;
   const f3 bc = clip_bary ? bary_clip(bp) : bp;
   const float pz = bc.x * v0.z + bc.y * v1.z + bc.z * v2.z;
-  if (pz < 0.0f) {
-    return false;
-  }
   const float dist = tri_dist2(p, a, b, c);
   const bool inside = (bp.x > 0.0f) & (bp.y > 0.0f) & (bp.z > 0.0f);
-  if (!inside && dist >= blur_radius) {
-    return false;
-  }
+  // branch-free accept test (rasterize_meshes.cu:162-177): behind the camera, or outside the face and beyond the
+  // blur radius -> no contribution
+  const bool hit = !(pz < 0.0f) & (inside | !(dist >= blur_radius));
   out->z = pz;
   out->dist = inside ? -dist : dist;
   out->bary = bc;
-  return true;
+  return hit;
 }
 
 // ---------------------------------------------------------------------------
