@@ -12,6 +12,7 @@
 // element exactly once; grad_alphas is accumulated in registers and written once, only
 // grad_features (a genuine scatter) uses f32 atomics.
 #include "p3d_common.h"
+#include "wave_table.h"
 
 namespace p3d {
 namespace {
@@ -116,8 +117,134 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs a) {
   }
 }
 
+// Backward, K <= KT: a wave owns an 8x8 pixel tile, a lane one pixel.  grad_alphas is accumulated in registers in
+// the (channel, k) order of a serial loop and written once.  grad_features is a scatter in which neighbouring
+// pixels name the same points (a splat covers ~pi*r^2 pixels), so the per-(pixel, k) terms of four channels at
+// a time are merged per point in a wave-private LDS table (wave_table.h) and reach memory as one atomic per
+// (tile, point, channel) instead of one per (pixel, k, channel).
+using FeatTable = WaveTable<4, 320, true>;  // 4 waves x 320 x 24 B = 30 KB
+
 template <int MODE, int KT>
-__global__ __launch_bounds__(256) void composite_bwd_kernel(CompArgs a) {
+__global__ __launch_bounds__(256) void composite_bwd_tile_kernel(CompArgs a, int tiles_y, int tiles_x) {
+  __shared__ __align__(16) int s_table[4][FeatTable::kLdsInts];
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + w;
+  const int64_t per_image = (int64_t)tiles_y * tiles_x;
+  if (tile >= (int64_t)a.N * per_image) return;  // wave-uniform; no workgroup barrier in this kernel
+  const int n = (int)(tile / per_image);
+  const int t = (int)(tile - (int64_t)n * per_image);
+  const int y = (t / tiles_x) * 8 + (lane >> 3), x = (t % tiles_x) * 8 + (lane & 7);
+  const bool ok = y < a.H && x < a.W;
+  const int K = a.K, C = a.C;
+  const int64_t HW = (int64_t)a.H * a.W;
+  const int64_t yx = (int64_t)y * a.W + x;
+  const int64_t abase = n * a.as[0] + y * a.as[2] + x * a.as[3];
+  const int64_t ibase = n * a.is[0] + y * a.is[2] + x * a.is[3];
+  const float* go_p = a.grad_out + ((int64_t)n * C) * HW + yx;
+  float* ga_p = a.grad_alphas + ((int64_t)n * K) * HW + yx;  // + k*HW
+
+  int id[KT];
+  float al[KT], ga[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) {
+    id[k] = -1;
+    al[k] = 0.0f;
+    ga[k] = 0.0f;
+    if (k < K && ok) {
+      id[k] = (int)a.idx[ibase + k * a.is[1]];
+      al[k] = a.alphas[abase + k * a.as[1]];
+    }
+  }
+  float sum_alpha = 0.0f;
+  if (MODE == P3D_COMPOSITE_NORM_SUM) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+      if (id[k] >= 0) sum_alpha += al[k];
+    if (sum_alpha < kEpsNorm) sum_alpha = kEpsNorm;
+  }
+
+  // grad_alphas: registers only
+  if (ok) {
+    for (int c = 0; c < C; ++c) {
+      const float* f = a.features + (int64_t)c * a.P;
+      const float go = go_p[(int64_t)c * HW];
+      if (MODE == P3D_COMPOSITE_ALPHA) {
+        float cum = 1.0f;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+          if (id[k] >= 0) {
+            const float fv = f[id[k]];
+            ga[k] += cum * fv * go;
+            const float back = -go * fv * cum * al[k];
+#pragma unroll
+            for (int tt = 0; tt < KT; ++tt) {
+              if (tt < k && id[tt] >= 0) ga[tt] += back / (1 - al[tt] + kEpsAlpha);
+            }
+            cum = cum * (1 - al[k]);
+          }
+        }
+      } else if (MODE == P3D_COMPOSITE_NORM_SUM) {
+        float sum_af = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+          if (id[k] >= 0) sum_af += al[k] * f[id[k]];
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+          if (id[k] >= 0) ga[k] += (f[id[k]] * sum_alpha - sum_af) / (sum_alpha * sum_alpha) * go;
+      } else {
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+          if (id[k] >= 0) ga[k] += f[id[k]] * go;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+      if (k < K) ga_p[(int64_t)k * HW] = ga[k];
+  }
+
+  // grad_features: four channels per pass through the table (wave-uniform control flow from here on)
+  FeatTable tab;
+  tab.init(s_table[w], lane);
+  tab.plane = a.P;
+  for (int c0 = 0; c0 < C; c0 += 4) {
+    const int nc = min(4, C - c0);
+    tab.nlive = nc;
+    float* gf = a.grad_features + (int64_t)c0 * a.P;
+    float go[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) go[j] = (ok && j < nc) ? go_p[(int64_t)(c0 + j) * HW] : 0.0f;
+    float cum = 1.0f;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      if (k < K) {
+        float wgt;  // d result[c] / d features[c, id[k]]
+        if (MODE == P3D_COMPOSITE_ALPHA)
+          wgt = cum * al[k];
+        else if (MODE == P3D_COMPOSITE_NORM_SUM)
+          wgt = al[k];
+        else
+          wgt = al[k];
+        float g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (MODE == P3D_COMPOSITE_NORM_SUM)
+            g[j] = wgt * go[j] / sum_alpha;
+          else
+            g[j] = wgt * go[j];
+        }
+        tab.add(gf, lane, id[k], g);
+        if (MODE == P3D_COMPOSITE_ALPHA && id[k] >= 0) cum = cum * (1 - al[k]);
+      }
+    }
+    if (tab.used > 0) tab.flush(gf, lane);
+  }
+}
+
+// Backward, any K: one thread per pixel, nothing cached; this thread owns grad_alphas[n, :, y, x] and accumulates
+// there without atomics.
+template <int MODE>
+__global__ __launch_bounds__(256) void composite_bwd_generic_kernel(CompArgs a) {
   const int64_t npix = (int64_t)a.N * a.H * a.W;
   const int K = a.K, C = a.C;
   const int64_t HW = (int64_t)a.H * a.W;
@@ -129,114 +256,45 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompArgs a) {
     const int64_t ibase = n * a.is[0] + y * a.is[2] + x * a.is[3];
     const float* go_p = a.grad_out + ((int64_t)n * C) * HW + yx;
     float* ga_p = a.grad_alphas + ((int64_t)n * K) * HW + yx;  // + k*HW
-
-    if constexpr (KT > 0) {
-      int id[KT];
-      float al[KT], ga[KT];
-#pragma unroll
-      for (int k = 0; k < KT; ++k) {
-        id[k] = -1;
-        al[k] = 0.0f;
-        ga[k] = 0.0f;
-        if (k < K) {
-          id[k] = (int)a.idx[ibase + k * a.is[1]];
-          al[k] = a.alphas[abase + k * a.as[1]];
-        }
-      }
-      float sum_alpha = 0.0f;
+    for (int k = 0; k < K; ++k) ga_p[(int64_t)k * HW] = 0.0f;
+    float sum_alpha = 0.0f;
+    if (MODE == P3D_COMPOSITE_NORM_SUM) {
+      for (int k = 0; k < K; ++k)
+        if ((int)a.idx[ibase + k * a.is[1]] >= 0) sum_alpha += a.alphas[abase + k * a.as[1]];
+      if (sum_alpha < kEpsNorm) sum_alpha = kEpsNorm;
+    }
+    for (int c = 0; c < C; ++c) {
+      const float* f = a.features + (int64_t)c * a.P;
+      float* gf = a.grad_features + (int64_t)c * a.P;
+      const float go = go_p[(int64_t)c * HW];
+      float cum = 1.0f;
+      float sum_af = 0.0f;
       if (MODE == P3D_COMPOSITE_NORM_SUM) {
-#pragma unroll
-        for (int k = 0; k < KT; ++k)
-          if (id[k] >= 0) sum_alpha += al[k];
-        if (sum_alpha < kEpsNorm) sum_alpha = kEpsNorm;
-      }
-      for (int c = 0; c < C; ++c) {
-        const float* f = a.features + (int64_t)c * a.P;
-        float* gf = a.grad_features + (int64_t)c * a.P;
-        const float go = go_p[(int64_t)c * HW];
-        if (MODE == P3D_COMPOSITE_ALPHA) {
-          float cum = 1.0f;
-#pragma unroll
-          for (int k = 0; k < KT; ++k) {
-            if (id[k] >= 0) {
-              const float fv = f[id[k]];
-              ga[k] += cum * fv * go;
-              unsafeAtomicAdd(gf + id[k], cum * al[k] * go);
-              const float back = -go * fv * cum * al[k];
-#pragma unroll
-              for (int tt = 0; tt < KT; ++tt) {
-                if (tt < k && id[tt] >= 0) ga[tt] += back / (1 - al[tt] + kEpsAlpha);
-              }
-              cum = cum * (1 - al[k]);
-            }
-          }
-        } else if (MODE == P3D_COMPOSITE_NORM_SUM) {
-          float sum_af = 0.0f;
-#pragma unroll
-          for (int k = 0; k < KT; ++k)
-            if (id[k] >= 0) sum_af += al[k] * f[id[k]];
-#pragma unroll
-          for (int k = 0; k < KT; ++k) {
-            if (id[k] >= 0) {
-              ga[k] += (f[id[k]] * sum_alpha - sum_af) / (sum_alpha * sum_alpha) * go;
-              unsafeAtomicAdd(gf + id[k], al[k] * go / sum_alpha);
-            }
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < KT; ++k) {
-            if (id[k] >= 0) {
-              ga[k] += f[id[k]] * go;
-              unsafeAtomicAdd(gf + id[k], al[k] * go);
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < KT; ++k)
-        if (k < K) ga_p[(int64_t)k * HW] = ga[k];
-    } else {
-      // generic K: this thread owns grad_alphas[n, :, y, x]; accumulate there without atomics
-      for (int k = 0; k < K; ++k) ga_p[(int64_t)k * HW] = 0.0f;
-      float sum_alpha = 0.0f;
-      if (MODE == P3D_COMPOSITE_NORM_SUM) {
-        for (int k = 0; k < K; ++k)
-          if ((int)a.idx[ibase + k * a.is[1]] >= 0) sum_alpha += a.alphas[abase + k * a.as[1]];
-        if (sum_alpha < kEpsNorm) sum_alpha = kEpsNorm;
-      }
-      for (int c = 0; c < C; ++c) {
-        const float* f = a.features + (int64_t)c * a.P;
-        float* gf = a.grad_features + (int64_t)c * a.P;
-        const float go = go_p[(int64_t)c * HW];
-        float cum = 1.0f;
-        float sum_af = 0.0f;
-        if (MODE == P3D_COMPOSITE_NORM_SUM) {
-          for (int k = 0; k < K; ++k) {
-            const int id = (int)a.idx[ibase + k * a.is[1]];
-            if (id >= 0) sum_af += a.alphas[abase + k * a.as[1]] * f[id];
-          }
-        }
         for (int k = 0; k < K; ++k) {
           const int id = (int)a.idx[ibase + k * a.is[1]];
-          if (id < 0) continue;
-          const float al = a.alphas[abase + k * a.as[1]];
-          const float fv = f[id];
-          if (MODE == P3D_COMPOSITE_ALPHA) {
-            ga_p[(int64_t)k * HW] += cum * fv * go;
-            unsafeAtomicAdd(gf + id, cum * al * go);
-            const float back = -go * fv * cum * al;
-            for (int tt = 0; tt < k; ++tt) {
-              if ((int)a.idx[ibase + tt * a.is[1]] < 0) continue;
-              ga_p[(int64_t)tt * HW] += back / (1 - a.alphas[abase + tt * a.as[1]] + kEpsAlpha);
-            }
-            cum = cum * (1 - al);
-          } else if (MODE == P3D_COMPOSITE_NORM_SUM) {
-            ga_p[(int64_t)k * HW] += (fv * sum_alpha - sum_af) / (sum_alpha * sum_alpha) * go;
-            unsafeAtomicAdd(gf + id, al * go / sum_alpha);
-          } else {
-            ga_p[(int64_t)k * HW] += fv * go;
-            unsafeAtomicAdd(gf + id, al * go);
+          if (id >= 0) sum_af += a.alphas[abase + k * a.as[1]] * f[id];
+        }
+      }
+      for (int k = 0; k < K; ++k) {
+        const int id = (int)a.idx[ibase + k * a.is[1]];
+        if (id < 0) continue;
+        const float al = a.alphas[abase + k * a.as[1]];
+        const float fv = f[id];
+        if (MODE == P3D_COMPOSITE_ALPHA) {
+          ga_p[(int64_t)k * HW] += cum * fv * go;
+          unsafeAtomicAdd(gf + id, cum * al * go);
+          const float back = -go * fv * cum * al;
+          for (int tt = 0; tt < k; ++tt) {
+            if ((int)a.idx[ibase + tt * a.is[1]] < 0) continue;
+            ga_p[(int64_t)tt * HW] += back / (1 - a.alphas[abase + tt * a.as[1]] + kEpsAlpha);
           }
+          cum = cum * (1 - al);
+        } else if (MODE == P3D_COMPOSITE_NORM_SUM) {
+          ga_p[(int64_t)k * HW] += (fv * sum_alpha - sum_af) / (sum_alpha * sum_alpha) * go;
+          unsafeAtomicAdd(gf + id, al * go / sum_alpha);
+        } else {
+          ga_p[(int64_t)k * HW] += fv * go;
+          unsafeAtomicAdd(gf + id, al * go);
         }
       }
     }
@@ -256,12 +314,15 @@ int launch_fwd(const CompArgs& a, unsigned grid, hipStream_t s) {
 
 template <int MODE>
 int launch_bwd(const CompArgs& a, unsigned grid, hipStream_t s) {
+  const int tiles_y = (int)ceil_div(a.H, 8), tiles_x = (int)ceil_div(a.W, 8);
+  const int64_t tile_blocks = ceil_div((int64_t)a.N * tiles_y * tiles_x, 4);
+  if (a.K <= 16 && tile_blocks > 0x7fffffff) return P3D_ERR_INVALID_ARG;
   if (a.K <= 8)
-    composite_bwd_kernel<MODE, 8><<<grid, 256, 0, s>>>(a);
+    composite_bwd_tile_kernel<MODE, 8><<<(unsigned)tile_blocks, 256, 0, s>>>(a, tiles_y, tiles_x);
   else if (a.K <= 16)
-    composite_bwd_kernel<MODE, 16><<<grid, 256, 0, s>>>(a);
+    composite_bwd_tile_kernel<MODE, 16><<<(unsigned)tile_blocks, 256, 0, s>>>(a, tiles_y, tiles_x);
   else
-    composite_bwd_kernel<MODE, 0><<<grid, 256, 0, s>>>(a);
+    composite_bwd_generic_kernel<MODE><<<grid, 256, 0, s>>>(a);
   return launch_status();
 }
 

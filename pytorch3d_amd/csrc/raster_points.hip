@@ -14,6 +14,7 @@
 #include "chunk_order.h"
 #include "p3d_geom.h"
 #include "topk.h"
+#include "wave_table.h"
 
 namespace p3d {
 
@@ -195,6 +196,10 @@ int launch_point_raster(const PointArgs& a, hipStream_t stream) {
     point_raster_kernel<TopKReg<4, 1>, 4, true, BINNED><<<grid, kStage, 0, stream>>>(a);
   else if (K <= 8)
     point_raster_kernel<TopKReg<8, 1>, 8, true, BINNED><<<grid, kStage, 0, stream>>>(a);
+  else if (K <= 10)  // the insertion is the kernel's dominant VALU cost and scales with the queue length
+    point_raster_kernel<TopKReg<10, 1>, 10, true, BINNED><<<grid, kStage, 0, stream>>>(a);
+  else if (K <= 12)
+    point_raster_kernel<TopKReg<12, 1>, 12, true, BINNED><<<grid, kStage, 0, stream>>>(a);
   else if (K <= 16)
     point_raster_kernel<TopKReg<16, 1>, 16, true, BINNED><<<grid, kStage, 0, stream>>>(a);
   else
@@ -204,29 +209,58 @@ int launch_point_raster(const PointArgs& a, hipStream_t stream) {
 
 void set_tiles(PointArgs* a, int bin_size, int BH, int BW) { a->tm = make_tile_map(a->N, a->H, a->W, bin_size, BH, BW, true); }
 
+// Backward (rasterize_points.cu:366-411): every (pixel, k) entry adds (2*gd*dx, 2*gd*dy, gz) to its point.  A point of
+// radius r is hit by ~pi*r^2 neighbouring pixels, so a wave owns an 8x8 pixel tile, walks its 64*K entries in
+// memory order (rows of 8*K contiguous entries) and merges per point in a wave-private LDS table (wave_table.h):
+// one global atomic triple per (tile, point) instead of one per entry.
+using PointTable = WaveTable<3, 426>;  // 4 waves x 426 x 24 B = 40 KB
+
 __global__ __launch_bounds__(256) void point_backward_kernel(const float* __restrict__ points,
                                                              const int32_t* __restrict__ idxs,
                                                              const float* __restrict__ grad_zbuf,
                                                              const float* __restrict__ grad_dists, int N, int H, int W,
-                                                             int K, float* __restrict__ grad_points) {
-  const int64_t total = (int64_t)N * H * W * K;
-  const int64_t hwk = (int64_t)H * W * K;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int p = idxs[i];
-    if (p < 0) continue;
-    const int64_t yxk = i % hwk;
-    const int yo = (int)(yxk / ((int64_t)W * K));
-    const int xo = (int)((yxk % ((int64_t)W * K)) / K);
-    const float xf = pix_to_ndc(W - 1 - xo, W, H);  // rasterize_points.cu:389-393
-    const float yf = pix_to_ndc(H - 1 - yo, H, W);
-    const float g = grad_dists[i];
-    const float dx = points[(int64_t)p * 3 + 0] - xf;
-    const float dy = points[(int64_t)p * 3 + 1] - yf;
-    float* o = grad_points + (int64_t)p * 3;
-    unsafeAtomicAdd(o + 0, 2.0f * g * dx);
-    unsafeAtomicAdd(o + 1, 2.0f * g * dy);
-    unsafeAtomicAdd(o + 2, grad_zbuf[i]);
+                                                             int K, int tiles_y, int tiles_x, float* __restrict__ grad_points) {
+  __shared__ __align__(16) int s_table[4][PointTable::kLdsInts];
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + w;
+  const int64_t per_image = (int64_t)tiles_y * tiles_x;
+  if (tile >= (int64_t)N * per_image) return;  // wave-uniform; no workgroup barrier in this kernel
+  const int n = (int)(tile / per_image);
+  const int t = (int)(tile - (int64_t)n * per_image);
+  const int y0 = (t / tiles_x) * 8, x0 = (t % tiles_x) * 8;
+  const int rows = min(8, H - y0), cols = min(8, W - x0);
+  const int run = cols * K;         // contiguous entries per tile row
+  const int total = rows * run;
+  const float inv_run = 1.0f / (float)run, inv_k = 1.0f / (float)K;
+  PointTable tab;
+  tab.init(s_table[w], lane);
+  for (int base = 0; base < total; base += 64) {
+    const int e = base + lane;
+    int p = -1;
+    float g[3] = {0.f, 0.f, 0.f};
+    if (e < total) {
+      // exact for these small operands: (e + 0.5) / d is at least 0.5 / d away from an integer
+      const int r = (int)(((float)e + 0.5f) * inv_run);
+      const int ee = e - r * run;
+      const int xo = x0 + (int)(((float)ee + 0.5f) * inv_k);
+      const int yo = y0 + r;
+      const int64_t i = (((int64_t)n * H + yo) * W + x0) * K + ee;
+      p = idxs[i];
+      if (p >= 0) {
+        const float xf = pix_to_ndc(W - 1 - xo, W, H);  // rasterize_points.cu:389-393
+        const float yf = pix_to_ndc(H - 1 - yo, H, W);
+        const float gd = grad_dists[i];
+        const float dx = points[(int64_t)p * 3 + 0] - xf;
+        const float dy = points[(int64_t)p * 3 + 1] - yf;
+        g[0] = 2.0f * gd * dx;
+        g[1] = 2.0f * gd * dy;
+        g[2] = grad_zbuf[i];
+      }
+    }
+    tab.add(grad_points, lane, p, g);
   }
+  if (tab.used > 0) tab.flush(grad_points, lane);
 }
 
 int check_common(int N, int H, int W, int K) {
@@ -360,9 +394,11 @@ P3D_API int p3d_rasterize_points_backward(const float* points, const int32_t* id
   const int64_t total = (int64_t)N * H * W * K;
   if (total == 0) return P3D_OK;
   if (!idxs || !grad_zbuf || !grad_dists) return P3D_ERR_INVALID_ARG;
-  int64_t blocks = ceil_div(total, 256);
-  if (blocks > 65536) blocks = 65536;
+  const int tiles_y = (int)ceil_div(H, 8), tiles_x = (int)ceil_div(W, 8);
+  const int64_t blocks = ceil_div((int64_t)N * tiles_y * tiles_x, 4);
+  if (blocks > 0x7fffffff) return P3D_ERR_INVALID_ARG;
   LaunchScope ls("points_backward", s);
-  point_backward_kernel<<<(unsigned)blocks, 256, 0, s>>>(points, idxs, grad_zbuf, grad_dists, N, H, W, K, grad_points);
+  point_backward_kernel<<<(unsigned)blocks, 256, 0, s>>>(points, idxs, grad_zbuf, grad_dists, N, H, W, K, tiles_y, tiles_x,
+                                                        grad_points);
   return launch_status();
 }

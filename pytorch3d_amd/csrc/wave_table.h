@@ -25,7 +25,9 @@ namespace p3d {
 
 constexpr int kEmptyKey = -1;
 
-template <int NV, int SLOTS>
+// PLANAR: the output is NV planes of `plane` floats (out[j * plane + f], e.g. (C, P) features) instead of (P, NV)
+// rows; only the first `nlive` planes exist.
+template <int NV, int SLOTS, bool PLANAR = false>
 struct WaveTable {
   static constexpr int kStride = (NV + 3) / 4 * 4;  // floats per slot: values are moved as 16-byte chunks
   static constexpr int kFlushAt = SLOTS - 64;       // a step adds at most 64 primitives: the table cannot overflow
@@ -36,6 +38,8 @@ struct WaveTable {
   float* vals;          // [SLOTS][kStride]
   int used;             // occupied slots (wave-uniform)
   int gen;              // step counter (wave-uniform), > 0
+  int64_t plane = 0;        // PLANAR only: floats per output plane
+  int nlive = NV;           // PLANAR only: planes that exist (values of the others are never flushed)
   bool no_atomics = false;  // ablation only (profiles/ablate.py): drop the global atomics of flush()
   int dbg = 0;              // ablation only (results become wrong): 16 skip the list summation, 32 skip the table update
 
@@ -64,10 +68,16 @@ struct WaveTable {
     for (int s = lane; s < SLOTS; s += 64) {
       const int f = keys[s];
       if (f != kEmptyKey) {
-        float* o = out + (int64_t)f * NV;
+        if constexpr (PLANAR) {
 #pragma unroll
-        for (int j = 0; j < NV; ++j)
-          if (!no_atomics) unsafeAtomicAdd(o + j, vals[s * kStride + j]);
+          for (int j = 0; j < NV; ++j)
+            if (j < nlive && !no_atomics) unsafeAtomicAdd(out + j * plane + f, vals[s * kStride + j]);
+        } else {
+          float* o = out + (int64_t)f * NV;
+#pragma unroll
+          for (int j = 0; j < NV; ++j)
+            if (!no_atomics) unsafeAtomicAdd(o + j, vals[s * kStride + j]);
+        }
         keys[s] = kEmptyKey;
       }
     }

@@ -53,7 +53,8 @@ def _format_radius(radius, pointclouds) -> torch.Tensor:
             raise ValueError("radius must be of shape (N, P): got %s" % repr(radius.shape))
         radius = radius.view(-1)[pointclouds.padded_to_packed_idx()]
     elif isinstance(radius, float):
-        radius = torch.full((P_packed,), fill_value=radius).type_as(points_packed)
+        # same values as the reference's CPU-side fill + type_as, without the host buffer and the H2D copy
+        radius = torch.full((P_packed,), radius, dtype=points_packed.dtype, device=points_packed.device)
     else:
         raise ValueError("radius must be a float, list, tuple or tensor; got %s" % type(radius))
     return radius

@@ -61,7 +61,8 @@ def test_points_coarse_and_fine_ops():
         assert all(torch.equal(a.cpu(), b) for a, b in zip(fine, naive))
 
 
-def test_points_backward_and_autograd():
+@pytest.mark.parametrize("size", [(40, 56), (45, 59)])  # whole / ragged 8x8 tiles of the backward kernel
+def test_points_backward_and_autograd(size):
     import pytorch3d_amd as p3d
     from pytorch3d_amd import _C
 
@@ -70,7 +71,7 @@ def test_points_backward_and_autograd():
     P = 2000
     pts = _cloud(P, gen, zlo=0.1)
     clouds = p3d.PackedPointclouds([pts[:900].to(d).requires_grad_(True), pts[900:].to(d).requires_grad_(True)])
-    idx, zbuf, dists = p3d.rasterize_points(clouds, image_size=(40, 56), radius=0.05, points_per_pixel=5)
+    idx, zbuf, dists = p3d.rasterize_points(clouds, image_size=size, radius=0.05, points_per_pixel=5)
     gz = torch.randn(zbuf.shape, generator=gen)
     gd = torch.randn(dists.shape, generator=gen)
     ref = orc.rasterize_points_backward(pts, idx.cpu(), gz, gd, acc64=True)
@@ -93,7 +94,7 @@ def test_points_backward_and_autograd():
         def num_points_per_cloud(self):
             return torch.tensor([900, 1100], device=d)
 
-    out = p3d.rasterize_points(_C2(), image_size=(40, 56), radius=0.05, points_per_pixel=5)
+    out = p3d.rasterize_points(_C2(), image_size=size, radius=0.05, points_per_pixel=5)
     torch.autograd.backward([out[1], out[2]], [gz.to(d), gd.to(d)])
     got = torch.cat([p1.grad, p2.grad], 0).cpu()
     assert torch.allclose(got, ref, rtol=1e-4, atol=5e-6 * max(scale, 1.0))
@@ -107,7 +108,7 @@ def test_compositors(mode, K, permuted):
 
     d = _dev()
     gen = torch.Generator().manual_seed(K)
-    N, C, P, H, W = 2, 5, 300, 13, 17
+    N, C, P, H, W = 2, (5 if K != 10 else 9), 300, 13, 17  # C = 9: three channel passes through the table, the last partial
     feat = torch.rand(C, P, generator=gen)
     if permuted:  # what the renderers pass: permuted views of (N,H,W,K) tensors
         alphas = torch.rand(N, H, W, K, generator=gen).permute(0, 3, 1, 2)
