@@ -144,8 +144,20 @@ def main():
         torch.autograd.backward([zbuf, bary, dists], [g_z, g_b, g_d])
         return zbuf
 
+    def final_gather(z):
+        # the one collective of the job: the final depth images of every rank are gathered on rank 0
+        shard = z[..., 0].detach().contiguous()
+        try:
+            return sharding.gather_batch(shard, [B] * world, dst=0)
+        except (RuntimeError, NotImplementedError):  # a backend without gather: every rank raises alike
+            return sharding.gather_batch(shard, [B] * world)
+
     for _ in range(args.warmup):
         zbuf = step()
+    if dist_on and args.warmup > 0:
+        # part of the warmup: RCCL opens its point-to-point xGMI channels on the first gather (lazily, ~100 ms)
+        del_me = final_gather(zbuf)
+        del del_me
     torch.cuda.synchronize()
     lib.p3d_profile_reset()
     lib.p3d_profile_enable(1)
@@ -156,12 +168,7 @@ def main():
     for _ in range(args.steps):
         zbuf = step()
     if dist_on:
-        # the one collective of the job: the final depth images of every rank are gathered on rank 0
-        shard = zbuf[..., 0].detach().contiguous()
-        try:
-            final = sharding.gather_batch(shard, [B] * world, dst=0)
-        except (RuntimeError, NotImplementedError):  # a backend without gather: every rank raises alike
-            final = sharding.gather_batch(shard, [B] * world)
+        final = final_gather(zbuf)
         del final
     torch.cuda.synchronize()
     if dist_on:
