@@ -240,6 +240,31 @@ int p3d_interp_face_attrs_backward_nhwk(const int64_t* pix_to_face, const float*
                                         int64_t F, int D, float* grad_barycentric_coords, float* grad_face_attrs,
                                         p3d_stream_t stream);
 
+/* ---- per-pixel Phong shading of the fragments ------------------------ */
+
+/* replaces the Python function phong_shading (pytorch3d/renderer/mesh/shading.py:59-112: two
+ * interpolate_face_attributes calls + lights.diffuse / lights.specular, renderer/lighting.py:17-159, + the colour
+ * mix; ~45 torch kernels over (N,H,W,K,3) tensors and their autograd graph) with one kernel each way.
+ *   face_attrs (F,3,D): D = 6 -> [vertex xyz | vertex normal] per face corner and `texels` (N,H,W,K,3) given per
+ *                       sample (the reference's signature);  D = 9 -> [.. | vertex colour], texels interpolated
+ *                       in the kernel (TexturesVertex), `texels` / `grad_texels` unused (may be null).
+ *   params (N, P3D_SHADE_PARAM_FLOATS): light ambient, diffuse, specular colour (3 each), light location
+ *                       (P3D_LIGHT_POINT) or direction (P3D_LIGHT_DIRECTIONAL), material ambient, diffuse,
+ *                       specular colour, shininess, camera centre -- already broadcast to the batch.
+ *                       AmbientLights = directional with zero diffuse and specular colour.
+ *   colors (N,H,W,K,3) fully written.  Backward: grad_bary (N,H,W,K,3) and grad_texels fully written,
+ *   grad_face_attrs (F,3,D) zeroed and accumulated.  Lights, materials and the camera centre get no gradient. */
+#define P3D_SHADE_PARAM_FLOATS 25
+#define P3D_LIGHT_DIRECTIONAL 0
+#define P3D_LIGHT_POINT 1
+int p3d_phong_shade_forward(const int64_t* pix_to_face, const float* bary_coords, const float* face_attrs, int D,
+                            const float* texels, const float* params, int light_kind, int N, int H, int W, int K,
+                            int64_t F, float* colors, p3d_stream_t stream);
+int p3d_phong_shade_backward(const float* grad_colors, const int64_t* pix_to_face, const float* bary_coords,
+                             const float* face_attrs, int D, const float* texels, const float* params, int light_kind,
+                             int N, int H, int W, int K, int64_t F, float* grad_bary_coords, float* grad_face_attrs,
+                             float* grad_texels, p3d_stream_t stream);
+
 /* ---- built-in per-kernel timing (HIP events on the launch stream) --------------------- */
 
 /* enable != 0: every kernel launch is bracketed by hipEventRecord on its stream. */

@@ -256,3 +256,29 @@ def ref_module():
     spec.loader.exec_module(mod)
     _ref_mod = mod
     return mod
+
+
+def phong_shade(pix_to_face, bary, face_attrs, texels, params, point_light):
+    """shading.py:59-112 restated (oracle/p3d_oracle.c: orc_phong_forward).  face_attrs (F,3,6|9), params (N,25)."""
+    p2f, b, fa, pr = _i64(pix_to_face), _f32(bary), _f32(face_attrs), _f32(params)
+    N, H, W, K = p2f.shape
+    D = fa.shape[2]
+    tx = _f32(texels) if texels is not None else None
+    out = torch.zeros((N, H, W, K, 3), dtype=torch.float32)
+    lib().orc_phong_forward(_p(p2f), _p(b), _p(fa), D, _p(tx) if tx is not None else None, _p(pr), int(point_light), N,
+                            ctypes.c_int64(H * W * K), _p(out))
+    return out
+
+
+def phong_shade_backward(grad_colors, pix_to_face, bary, face_attrs, texels, params, point_light):
+    g, p2f, b, fa, pr = _f32(grad_colors), _i64(pix_to_face), _f32(bary), _f32(face_attrs), _f32(params)
+    N, H, W, K = p2f.shape
+    F, _, D = fa.shape
+    tx = _f32(texels) if texels is not None else None
+    gb = torch.zeros((N, H, W, K, 3), dtype=torch.float32)
+    gf = torch.zeros((F, 3, D), dtype=torch.float32)
+    gt = torch.zeros((N, H, W, K, 3), dtype=torch.float32) if D == 6 else None
+    lib().orc_phong_backward(_p(g), _p(p2f), _p(b), _p(fa), D, _p(tx) if tx is not None else None, _p(pr),
+                             int(point_light), N, ctypes.c_int64(H * W * K), ctypes.c_int64(F), _p(gb), _p(gf),
+                             _p(gt) if gt is not None else None)
+    return gb, gf, gt

@@ -5,6 +5,7 @@ AMD MI355X (CDNA4 / gfx950) as hand-written HIP behind a C ABI (include/p3d_amd.
     pytorch3d_amd.shim.install()     register it as pytorch3d._C for the unmodified reference
     rasterize_meshes, rasterize_points, alpha_composite, norm_weighted_sum, weighted_sum,
     interpolate_face_attributes      host-side mirrors of the reference's L2 functions
+    clip_faces, softmax_rgb_blend, sigmoid_alpha_blend, phong_shading   the neighbouring steps, fused
 
 Importing the package does not load the HIP library; the first operator call does, and raises
 if it is missing (no CPU / eager fallback exists).
@@ -15,6 +16,7 @@ from .compositing import alpha_composite, norm_weighted_sum, weighted_sum  # noq
 from .interp_face_attrs import interpolate_face_attributes  # noqa: F401
 from .rasterize_meshes import rasterize_meshes  # noqa: F401
 from .rasterize_points import rasterize_points  # noqa: F401
+from .shading import phong_shading, phong_shading_vertex_colors  # noqa: F401
 from .structures import PackedMeshes, PackedPointclouds  # noqa: F401
 
 __version__ = "0.1.0"

@@ -71,6 +71,10 @@ _SIGNATURES = {
     "p3d_softmax_rgb_blend_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, ctypes.POINTER(c_f32),
                                                c_f32, c_f32, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr, c_ptr,
                                                c_ptr]),
+    "p3d_phong_shade_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_i64,
+                                        c_ptr, c_ptr]),
+    "p3d_phong_shade_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int,
+                                         c_int, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "p3d_profile_enable": (None, [c_int]),
     "p3d_profile_collect": (None, []),
     "p3d_profile_num_entries": (c_int, []),

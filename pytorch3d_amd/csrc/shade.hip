@@ -1,0 +1,387 @@
+// shade.hip -- fused per-pixel Phong shading of rasterization fragments for gfx950.
+//
+// Replaces the torch-op chain of phong_shading (pytorch3d/renderer/mesh/shading.py:17-112):
+//   pixel_coords  = interpolate_face_attributes(pix_to_face, bary, verts[faces])
+//   pixel_normals = interpolate_face_attributes(pix_to_face, bary, verts_normals[faces])
+//   ambient, diffuse, specular = _apply_lighting(...)       (lighting.py:17-159: F.normalize eps 1e-6, relu, pow)
+//   colors = (ambient + diffuse) * texels + specular
+// ~45 elementwise / reduction kernels over (N,H,W,K,3) tensors plus their autograd twins, each re-reading the
+// fragments.  Here: one forward kernel (reads pix_to_face + bary [+ texels], gathers one 72/108-byte face record,
+// writes colors) and one backward kernel that recomputes the forward per sample, applies the chain rule in
+// registers and hands the per-face partials to the same wave-private LDS table as the mesh / interp backward
+// (wave_table.h).  Face records are (F, 3, D): D = 6 [vertex xyz | vertex normal] with texels given per sample
+// (the reference's signature), or D = 9 [.. | vertex colour] with the texture interpolation fused in as well.
+//
+// Per-image parameters (25 floats, `P3D_SHADE_PARAM_FLOATS`): light ambient / diffuse / specular colour,
+// light location (point light) or direction (directional light), material ambient / diffuse / specular colour,
+// shininess, camera centre.  Ambient-only lights are a directional light with zero diffuse and specular colour.
+#include "p3d_common.h"
+#include "wave_table.h"
+
+namespace p3d {
+namespace {
+
+constexpr float kNormEps = 1e-6f;  // lighting.py:76-77,143-144: F.normalize(..., eps=1e-6)
+
+struct ShadeConst {
+  float la[3], ld[3], ls[3], lvec[3], ma[3], md[3], ms[3], shin, cam[3];
+};
+
+__device__ __forceinline__ ShadeConst load_params(const float* __restrict__ p) {
+  ShadeConst c;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    c.la[j] = p[j];
+    c.ld[j] = p[3 + j];
+    c.ls[j] = p[6 + j];
+    c.lvec[j] = p[9 + j];
+    c.ma[j] = p[12 + j];
+    c.md[j] = p[15 + j];
+    c.ms[j] = p[18 + j];
+    c.cam[j] = p[22 + j];
+  }
+  c.shin = p[21];
+  return c;
+}
+
+__device__ __forceinline__ float dot3(const float (&a)[3], const float (&b)[3]) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+
+// x / max(|x|, eps); returns |x|
+__device__ __forceinline__ float normalize3(const float (&x)[3], float (&out)[3]) {
+  const float len = sqrtf(dot3(x, x));
+  const float d = fmaxf(len, kNormEps);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) out[j] = x[j] / d;
+  return len;
+}
+
+// gradient of normalize3 at x (xh = its output, len = |x|) for an upstream dxh
+__device__ __forceinline__ void normalize3_bwd(const float (&xh)[3], float len, const float (&dxh)[3], float (&dx)[3]) {
+  if (len >= kNormEps) {  // clamp_min passes the gradient of the norm through
+    const float t = dot3(xh, dxh);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dx[j] = (dxh[j] - xh[j] * t) / len;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dx[j] = dxh[j] / kNormEps;
+  }
+}
+
+// Everything the backward needs again from the lighting of one sample.
+struct Lit {
+  float nh[3], lh[3], vh[3], R[3];
+  float nlen, llen, vlen, cosv, d, alpha, angle, pw;
+};
+
+template <bool POINT>
+__device__ __forceinline__ Lit light_sample(const ShadeConst& c, const float (&P)[3], const float (&Nn)[3]) {
+  Lit s;
+  s.nlen = normalize3(Nn, s.nh);
+  float L[3], V[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    L[j] = POINT ? c.lvec[j] - P[j] : c.lvec[j];  // lighting.py:283-285 / :196-204
+    V[j] = c.cam[j] - P[j];                       // lighting.py:151
+  }
+  s.llen = normalize3(L, s.lh);
+  s.vlen = normalize3(V, s.vh);
+  s.cosv = dot3(s.nh, s.lh);
+  s.angle = fmaxf(s.cosv, 0.0f);  // lighting.py:78
+#pragma unroll
+  for (int j = 0; j < 3; ++j) s.R[j] = -s.lh[j] + 2.0f * (s.cosv * s.nh[j]);  // lighting.py:153
+  s.d = dot3(s.vh, s.R);
+  s.alpha = s.cosv > 0.0f ? fmaxf(s.d, 0.0f) : 0.0f;  // lighting.py:147,156
+  s.pw = powf(s.alpha, c.shin);                        // lighting.py:157
+  return s;
+}
+
+struct ShadeArgs {
+  const int64_t* p2f;
+  const float* bary;
+  const float* attrs;    // (F, 3, D)
+  const float* texels;   // (N,H,W,K,3) when D == 6
+  const float* params;   // (N, 25)
+  const float* gcolors;  // (N,H,W,K,3)
+  float* colors;         // (N,H,W,K,3)
+  float* gbary;          // (N,H,W,K,3)
+  float* gattrs;         // (F, 3, D)
+  float* gtexels;        // (N,H,W,K,3) when D == 6
+  int N, H, W, K, RY, RX;
+  int64_t HWK;
+};
+
+// ---- forward: one thread per sample, blockIdx.y = image ----------------------------------------------------------
+template <int D, bool POINT>
+__global__ __launch_bounds__(256) void phong_fwd_kernel(ShadeArgs a) {
+  const int n = blockIdx.y;
+  const ShadeConst c = load_params(a.params + (int64_t)n * P3D_SHADE_PARAM_FLOATS);
+  float amb[3], kd[3], ks[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    amb[j] = c.ma[j] * c.la[j];  // shading.py:41
+    kd[j] = c.md[j] * c.ld[j];
+    ks[j] = c.ms[j] * c.ls[j];
+  }
+  const int64_t img = (int64_t)n * a.HWK;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.HWK; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = img + i;
+    const int f = (int)a.p2f[p];
+    float P[3] = {0.f, 0.f, 0.f}, Nn[3] = {0.f, 0.f, 0.f}, tex[3] = {0.f, 0.f, 0.f};
+    if (f >= 0) {
+      const float b0 = a.bary[p * 3], b1 = a.bary[p * 3 + 1], b2 = a.bary[p * 3 + 2];
+      const float* r = a.attrs + (int64_t)f * 3 * D;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        // interp_face_attrs.cu:39-41: (w0*a0 + w1*a1) + w2*a2
+        P[j] = (b0 * r[j] + b1 * r[D + j]) + b2 * r[2 * D + j];
+        Nn[j] = (b0 * r[3 + j] + b1 * r[D + 3 + j]) + b2 * r[2 * D + 3 + j];
+        if (D == 9) tex[j] = (b0 * r[6 + j] + b1 * r[D + 6 + j]) + b2 * r[2 * D + 6 + j];
+      }
+    }
+    if (D == 6) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) tex[j] = a.texels[p * 3 + j];
+    }
+    // background samples interpolate to P = N = 0 in the reference and go through the same arithmetic
+    const Lit s = light_sample<POINT>(c, P, Nn);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) a.colors[p * 3 + j] = (amb[j] + kd[j] * s.angle) * tex[j] + ks[j] * s.pw;  // shading.py:96
+  }
+}
+
+// ---- backward: wave per 16x16 pixel area (four 8x8 tiles), lane per pixel, step per k --------------------------------
+template <int D>
+struct ShadeTable {
+  static constexpr int NV = 3 * D;
+  static constexpr int kSlots = D == 6 ? 182 : 136;  // 4 waves x slots x (8 + 4 * stride) B: 64 KB / 65 KB
+  using T = WaveTable<NV, kSlots>;
+};
+
+template <int D, bool POINT>
+__global__ __launch_bounds__(256) void phong_bwd_kernel(ShadeArgs a) {
+  using Tab = typename ShadeTable<D>::T;
+  constexpr int NV = 3 * D;
+  __shared__ __align__(16) int s_table[4][Tab::kLdsInts];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  long long t = blockIdx.x;
+  const int rx = (int)(t % a.RX);
+  t /= a.RX;
+  const int ry = (int)(t % a.RY);
+  const int n = (int)(t / a.RY);
+  const int ay = ry * 32 + (w >> 1) * 16, ax = rx * 32 + (w & 1) * 16;
+  const int H = a.H, W = a.W, K = a.K;
+  if (ay >= H || ax >= W) return;  // wave-uniform; no workgroup barrier in this kernel
+  const ShadeConst c = load_params(a.params + (int64_t)n * P3D_SHADE_PARAM_FLOATS);
+  float amb[3], kd[3], ks[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    amb[j] = c.ma[j] * c.la[j];
+    kd[j] = c.md[j] * c.ld[j];
+    ks[j] = c.ms[j] * c.ls[j];
+  }
+  Tab tab;
+  tab.init(s_table[w], lane);
+#pragma unroll 1
+  for (int tile = 0; tile < 4; ++tile) {
+    const int yo = ay + (tile >> 1) * 8 + (lane >> 3);
+    const int xo = ax + (tile & 1) * 8 + (lane & 7);
+    const bool ok = yo < H && xo < W;
+    const int64_t base = (((int64_t)n * H + yo) * W + xo) * K;
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) {
+      const int64_t p = base + k;
+      const int f = ok ? (int)a.p2f[p] : -1;
+      float g[NV];
+      float gb[3] = {0.f, 0.f, 0.f};
+      float go[3] = {0.f, 0.f, 0.f};
+      if (ok) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) go[j] = a.gcolors[p * 3 + j];
+      }
+      if (D == 6 && ok && f < 0) {
+        // background sample with caller-supplied texels: colour = ambient * texel (+ a constant)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a.gtexels[p * 3 + j] = amb[j] * go[j];
+      }
+      if (f >= 0) {
+        const float b[3] = {a.bary[p * 3], a.bary[p * 3 + 1], a.bary[p * 3 + 2]};
+        float r[NV];
+        const float* rp = a.attrs + (int64_t)f * NV;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) r[j] = rp[j];
+        float P[3], Nn[3], tex[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          P[j] = (b[0] * r[j] + b[1] * r[D + j]) + b[2] * r[2 * D + j];
+          Nn[j] = (b[0] * r[3 + j] + b[1] * r[D + 3 + j]) + b[2] * r[2 * D + 3 + j];
+          if (D == 9)
+            tex[j] = (b[0] * r[6 + j] + b[1] * r[D + 6 + j]) + b[2] * r[2 * D + 6 + j];
+          else
+            tex[j] = a.texels[p * 3 + j];
+        }
+        const Lit s = light_sample<POINT>(c, P, Nn);
+        // colour_j = (amb_j + kd_j * angle) * tex_j + ks_j * pw
+        float dtex[3];
+        float dangle = 0.0f, dpw = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          dtex[j] = (amb[j] + kd[j] * s.angle) * go[j];
+          dangle += kd[j] * tex[j] * go[j];
+          dpw += ks[j] * go[j];
+        }
+        // pow backward (torch: 0 where the exponent is 0), relu and the cos > 0 mask
+        const float dalpha = c.shin == 0.0f ? 0.0f : c.shin * powf(s.alpha, c.shin - 1.0f) * dpw;
+        const float dd = (s.cosv > 0.0f && s.d > 0.0f) ? dalpha : 0.0f;
+        float dvh[3], dR[3], dlh[3], dnh[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          dvh[j] = dd * s.R[j];
+          dR[j] = dd * s.vh[j];
+        }
+        const float dcos = (s.cosv > 0.0f ? dangle : 0.0f) + 2.0f * dot3(dR, s.nh);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          dnh[j] = 2.0f * s.cosv * dR[j] + dcos * s.lh[j];
+          dlh[j] = -dR[j] + dcos * s.nh[j];
+        }
+        float dNn[3], dL[3], dV[3], dP[3];
+        normalize3_bwd(s.nh, s.nlen, dnh, dNn);
+        normalize3_bwd(s.lh, s.llen, dlh, dL);
+        normalize3_bwd(s.vh, s.vlen, dvh, dV);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dP[j] = (POINT ? -dL[j] : 0.0f) - dV[j];
+        // interpolation backward (interp_face_attrs.cu:100-118)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          float acc = 0.0f;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            g[i * D + j] = b[i] * dP[j];
+            g[i * D + 3 + j] = b[i] * dNn[j];
+            acc += r[i * D + j] * dP[j];
+            acc += r[i * D + 3 + j] * dNn[j];
+            if (D == 9) {
+              g[i * D + 6 + j] = b[i] * dtex[j];
+              acc += r[i * D + 6 + j] * dtex[j];
+            }
+          }
+          gb[i] = acc;
+        }
+        if (D == 6) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) a.gtexels[p * 3 + j] = dtex[j];
+        }
+      }
+      if (ok) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a.gbary[p * 3 + j] = gb[j];
+      }
+      if (__ballot(f >= 0) == 0) continue;  // wave-uniform
+      tab.add(a.gattrs, lane, f, g);
+    }
+  }
+  if (tab.used > 0) tab.flush(a.gattrs, lane);
+}
+
+int check_shape(int N, int H, int W, int K, int64_t F, int D, int light_kind) {
+  if (N < 0 || H < 0 || W < 0 || K < 0 || F < 0) return P3D_ERR_INVALID_ARG;
+  if (D != 6 && D != 9) return P3D_ERR_INVALID_ARG;
+  if (light_kind != P3D_LIGHT_DIRECTIONAL && light_kind != P3D_LIGHT_POINT) return P3D_ERR_INVALID_ARG;
+  return P3D_OK;
+}
+
+}  // namespace
+}  // namespace p3d
+
+using namespace p3d;
+
+P3D_API int p3d_phong_shade_forward(const int64_t* pix_to_face, const float* bary, const float* face_attrs, int D,
+                                    const float* texels, const float* params, int light_kind, int N, int H, int W, int K,
+                                    int64_t F, float* colors, p3d_stream_t stream) {
+  const int rc = check_shape(N, H, W, K, F, D, light_kind);
+  if (rc != P3D_OK) return rc;
+  const int64_t HWK = (int64_t)H * W * K;
+  if ((int64_t)N * HWK == 0) return P3D_OK;
+  if (!pix_to_face || !bary || !params || !colors || (F > 0 && !face_attrs) || (D == 6 && !texels)) return P3D_ERR_INVALID_ARG;
+  if (N > 65535) return P3D_ERR_INVALID_ARG;
+  ShadeArgs a{};
+  a.p2f = pix_to_face;
+  a.bary = bary;
+  a.attrs = face_attrs;
+  a.texels = texels;
+  a.params = params;
+  a.colors = colors;
+  a.N = N;
+  a.H = H;
+  a.W = W;
+  a.K = K;
+  a.HWK = HWK;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t bx = ceil_div(HWK, 256 * 4);  // four samples per thread
+  if (bx > 65535) bx = 65535;
+  const dim3 grid((unsigned)bx, (unsigned)N);
+  LaunchScope ls("phong_fwd", s);
+  const bool point = light_kind == P3D_LIGHT_POINT;
+  if (D == 6) {
+    if (point)
+      phong_fwd_kernel<6, true><<<grid, 256, 0, s>>>(a);
+    else
+      phong_fwd_kernel<6, false><<<grid, 256, 0, s>>>(a);
+  } else {
+    if (point)
+      phong_fwd_kernel<9, true><<<grid, 256, 0, s>>>(a);
+    else
+      phong_fwd_kernel<9, false><<<grid, 256, 0, s>>>(a);
+  }
+  return launch_status();
+}
+
+P3D_API int p3d_phong_shade_backward(const float* grad_colors, const int64_t* pix_to_face, const float* bary,
+                                     const float* face_attrs, int D, const float* texels, const float* params,
+                                     int light_kind, int N, int H, int W, int K, int64_t F, float* grad_bary,
+                                     float* grad_face_attrs, float* grad_texels, p3d_stream_t stream) {
+  const int rc = check_shape(N, H, W, K, F, D, light_kind);
+  if (rc != P3D_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (F > 0) {
+    if (!grad_face_attrs) return P3D_ERR_INVALID_ARG;
+    if (hipMemsetAsync(grad_face_attrs, 0, (size_t)F * 3 * D * sizeof(float), s) != hipSuccess) return P3D_ERR_LAUNCH;
+  }
+  const int64_t HWK = (int64_t)H * W * K;
+  if ((int64_t)N * HWK == 0) return P3D_OK;
+  if (!grad_colors || !pix_to_face || !bary || !params || !grad_bary || (F > 0 && !face_attrs)) return P3D_ERR_INVALID_ARG;
+  if (D == 6 && (!texels || !grad_texels)) return P3D_ERR_INVALID_ARG;
+  ShadeArgs a{};
+  a.gcolors = grad_colors;
+  a.p2f = pix_to_face;
+  a.bary = bary;
+  a.attrs = face_attrs;
+  a.texels = texels;
+  a.params = params;
+  a.gbary = grad_bary;
+  a.gattrs = grad_face_attrs;
+  a.gtexels = grad_texels;
+  a.N = N;
+  a.H = H;
+  a.W = W;
+  a.K = K;
+  a.HWK = HWK;
+  a.RY = (int)ceil_div(H, 32);
+  a.RX = (int)ceil_div(W, 32);
+  const int64_t blocks = (int64_t)N * a.RY * a.RX;
+  if (blocks > 0x7fffffff) return P3D_ERR_INVALID_ARG;
+  LaunchScope ls("phong_bwd", s);
+  const bool point = light_kind == P3D_LIGHT_POINT;
+  if (D == 6) {
+    if (point)
+      phong_bwd_kernel<6, true><<<(unsigned)blocks, 256, 0, s>>>(a);
+    else
+      phong_bwd_kernel<6, false><<<(unsigned)blocks, 256, 0, s>>>(a);
+  } else {
+    if (point)
+      phong_bwd_kernel<9, true><<<(unsigned)blocks, 256, 0, s>>>(a);
+    else
+      phong_bwd_kernel<9, false><<<(unsigned)blocks, 256, 0, s>>>(a);
+  }
+  return launch_status();
+}

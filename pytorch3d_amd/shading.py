@@ -1,0 +1,162 @@
+"""Host-side mirror of pytorch3d/renderer/mesh/shading.py:17-112 over the C ABI.
+
+`phong_shading(meshes, fragments, lights, cameras, materials, texels)` has the reference's signature and return
+value.  The reference runs two `interpolate_face_attributes` calls, `lights.diffuse`, `lights.specular`
+(renderer/lighting.py:17-159) and the colour mix as ~45 torch kernels over (N,H,W,K,3) tensors plus their autograd
+twins; here it is ONE kernel forward and ONE backward (include/p3d_amd.h: p3d_phong_shade_forward / _backward).
+`phong_shading_vertex_colors` additionally fuses the `TexturesVertex` texel interpolation
+(renderer/mesh/textures.py: sample_textures = interpolate_face_attributes of the per-face vertex colours).
+
+`lights`, `cameras`, `materials` are duck-typed: any object with the reference's attribute names works
+(`PointLights.location`, `DirectionalLights.direction`, `*.ambient_color / diffuse_color / specular_color`,
+`Materials.shininess`, `cameras.get_camera_center()`), each (1, 3) or (N, 3).  Gradients flow to the mesh
+vertices, vertex normals, texels / vertex colours and barycentric coordinates; lights, materials and the camera
+centre are constants of the fused kernels (a tensor among them that requires grad raises).
+"""
+from typing import NamedTuple, Optional
+
+import torch
+
+from . import _C, _lib
+from .rasterize_meshes import gather_face_verts
+
+PARAM_FLOATS = 25  # include/p3d_amd.h: P3D_SHADE_PARAM_FLOATS
+LIGHT_DIRECTIONAL, LIGHT_POINT = 0, 1
+
+
+class Lights(NamedTuple):
+    """Minimal stand-in for renderer/lighting.py's PointLights / DirectionalLights / AmbientLights (out of scope,
+    used unmodified when the reference is installed): set `location` for a point light, `direction` for a
+    directional one, neither for ambient-only."""
+
+    ambient_color: torch.Tensor
+    diffuse_color: Optional[torch.Tensor] = None
+    specular_color: Optional[torch.Tensor] = None
+    location: Optional[torch.Tensor] = None
+    direction: Optional[torch.Tensor] = None
+
+
+class Materials(NamedTuple):
+    """renderer/materials.py:15-60."""
+
+    ambient_color: torch.Tensor
+    diffuse_color: torch.Tensor
+    specular_color: torch.Tensor
+    shininess: torch.Tensor
+
+
+def _rows(v, N, C, device, name):
+    t = v if torch.is_tensor(v) else torch.tensor(v, dtype=torch.float32)
+    if t.requires_grad:
+        raise NotImplementedError(f"phong_shading: {name} requires grad; the fused kernels treat lights, materials and "
+                                  "the camera centre as constants")
+    t = t.detach().to(device=device, dtype=torch.float32)
+    if C == 1:
+        t = t.reshape(-1, 1)
+    if t.ndim == 1:
+        t = t[None]
+    if t.ndim != 2 or t.shape[1] != C or t.shape[0] not in (1, N):
+        raise ValueError(f"phong_shading: {name} must have shape (1, {C}) or ({N}, {C}); got {tuple(t.shape)}")
+    return t.expand(N, C)
+
+
+def pack_shade_params(lights, cameras, materials, N, device):
+    """-> ((N, 25) float32 parameter block, light kind) as p3d_phong_shade_* take them."""
+    if getattr(lights, "location", None) is not None:
+        kind, vec = LIGHT_POINT, lights.location
+    elif getattr(lights, "direction", None) is not None:
+        kind, vec = LIGHT_DIRECTIONAL, lights.direction
+    else:  # AmbientLights: diffuse() and specular() return zeros (lighting.py:339-352)
+        kind, vec = LIGHT_DIRECTIONAL, ((0.0, 0.0, 0.0),)
+    zero = ((0.0, 0.0, 0.0),)
+    ldiff = getattr(lights, "diffuse_color", None)
+    lspec = getattr(lights, "specular_color", None)
+    if getattr(lights, "location", None) is None and getattr(lights, "direction", None) is None:
+        ldiff = lspec = None
+    cols = [
+        _rows(lights.ambient_color, N, 3, device, "lights.ambient_color"),
+        _rows(ldiff if ldiff is not None else zero, N, 3, device, "lights.diffuse_color"),
+        _rows(lspec if lspec is not None else zero, N, 3, device, "lights.specular_color"),
+        _rows(vec, N, 3, device, "lights.location / direction"),
+        _rows(materials.ambient_color, N, 3, device, "materials.ambient_color"),
+        _rows(materials.diffuse_color, N, 3, device, "materials.diffuse_color"),
+        _rows(materials.specular_color, N, 3, device, "materials.specular_color"),
+        _rows(materials.shininess, N, 1, device, "materials.shininess"),
+        _rows(cameras.get_camera_center(), N, 3, device, "cameras.get_camera_center()"),
+    ]
+    return torch.cat(cols, 1).contiguous(), kind
+
+
+class _PhongShade(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pix_to_face, bary, face_attrs, texels, params, kind):
+        N, H, W, K = pix_to_face.shape
+        dev = bary.device
+        p2f, b, fa = pix_to_face.contiguous(), bary.contiguous(), face_attrs.contiguous()
+        tx = texels.contiguous() if texels is not None else None
+        F, _, D = fa.shape
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            colors = torch.empty((N, H, W, K, 3), dtype=torch.float32, device=dev)
+            if colors.numel():
+                rc = lib.p3d_phong_shade_forward(_C._ptr(p2f), _C._ptr(b), _C._ptr(fa), D, _C._ptr(tx), _C._ptr(params),
+                                                 kind, N, H, W, K, F, _C._ptr(colors), _C._stream(dev))
+                _lib.check(rc, "phong_shading")
+        ctx.save_for_backward(p2f, b, fa, tx if tx is not None else torch.empty(0, device=dev), params)
+        ctx.kind = kind
+        ctx.has_texels = tx is not None
+        return colors
+
+    @staticmethod
+    def backward(ctx, grad_colors):
+        p2f, b, fa, tx, params = ctx.saved_tensors
+        N, H, W, K = p2f.shape
+        F, _, D = fa.shape
+        dev = b.device
+        g = grad_colors.contiguous()
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            gb = torch.empty((N, H, W, K, 3), dtype=torch.float32, device=dev)
+            gfa = torch.empty((F, 3, D), dtype=torch.float32, device=dev)
+            gt = torch.empty((N, H, W, K, 3), dtype=torch.float32, device=dev) if ctx.has_texels else None
+            rc = lib.p3d_phong_shade_backward(_C._ptr(g), _C._ptr(p2f), _C._ptr(b), _C._ptr(fa), D,
+                                              _C._ptr(tx if ctx.has_texels else None), _C._ptr(params), ctx.kind, N, H, W,
+                                              K, F, _C._ptr(gb), _C._ptr(gfa), _C._ptr(gt), _C._stream(dev))
+            _lib.check(rc, "phong_shading_backward")
+        return None, gb, gfa, gt, None, None
+
+
+def _check(fragments, *named):
+    _C._need_gpu(fragments.pix_to_face, "pix_to_face")
+    _C._need_gpu(fragments.bary_coords, "bary_coords")
+    for name, t in named:
+        _C._need_gpu(t, name)
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"phong_shading: {name} must be float32")
+
+
+def _face_records(meshes, extra=None):
+    """(F, 3, 6|9): per face corner [vertex xyz | vertex normal | extra], differentiable (shading.py:84-88)."""
+    faces = meshes.faces_packed()
+    fv = gather_face_verts(meshes.verts_packed(), faces)
+    fn = gather_face_verts(meshes.verts_normals_packed(), faces)
+    parts = [fv, fn] + ([extra] if extra is not None else [])
+    return torch.cat(parts, 2)
+
+
+def phong_shading(meshes, fragments, lights, cameras, materials, texels) -> torch.Tensor:
+    """shading.py:99-112.  texels (N,H,W,K,3) -> colors (N,H,W,K,3)."""
+    _check(fragments, ("texels", texels))
+    N = fragments.pix_to_face.shape[0]
+    params, kind = pack_shade_params(lights, cameras, materials, N, texels.device)
+    return _PhongShade.apply(fragments.pix_to_face, fragments.bary_coords, _face_records(meshes), texels, params, kind)
+
+
+def phong_shading_vertex_colors(meshes, fragments, lights, cameras, materials, verts_colors_packed) -> torch.Tensor:
+    """phong_shading(..., texels=TexturesVertex(verts_colors).sample_textures(fragments)) with the texel interpolation
+    (textures.py sample_textures -> interpolate_face_attributes) fused into the same kernel.  verts_colors_packed (V,3)."""
+    _check(fragments, ("verts_colors_packed", verts_colors_packed))
+    N = fragments.pix_to_face.shape[0]
+    params, kind = pack_shade_params(lights, cameras, materials, N, verts_colors_packed.device)
+    fc = gather_face_verts(verts_colors_packed, meshes.faces_packed())
+    return _PhongShade.apply(fragments.pix_to_face, fragments.bary_coords, _face_records(meshes, fc), None, params, kind)

@@ -66,6 +66,17 @@ class PackedMeshes:
     def num_verts_per_mesh(self):
         return self._num_verts
 
+    def verts_normals_packed(self):
+        """Area-weighted vertex normals as Meshes._compute_vertex_normals (structures/meshes.py:884-927): plain
+        torch ops, differentiable; computed on every call (this container caches nothing that depends on verts)."""
+        verts, faces = self._verts_packed, self._faces_packed
+        fv = verts[faces]
+        fn = torch.cross(fv[:, 2] - fv[:, 1], fv[:, 0] - fv[:, 1], dim=1)
+        vn = torch.zeros_like(verts)
+        for c in range(3):
+            vn = vn.index_add(0, faces[:, c], fn)
+        return torch.nn.functional.normalize(vn, eps=1e-6, dim=1)
+
     def update_verts_packed(self, new_verts_packed):
         """Same topology, new vertex positions (like Meshes.update_padded, for camera transforms)."""
         out = object.__new__(PackedMeshes)

@@ -215,3 +215,41 @@ def sort_bins(b):
     big = torch.where(b < 0, torch.full_like(b, 2 ** 30), b)
     s = big.sort(-1).values
     return torch.where(s == 2 ** 30, torch.full_like(s, -1), s)
+
+
+# ---- shading fixtures (tests/golden/shading_ref.npz) --------------------------------------------------------
+def shading_golden():
+    g = np.load(os.path.join(GOLDEN, "shading_ref.npz"))
+    return {k: torch.from_numpy(g[k]) for k in g.files}
+
+
+def shading_case(g, tag, kind):
+    """-> (face_attrs (F,3,6|9), texels or None, params (N,25), point_light) of fixture case tag/kind, built with plain
+    torch indexing (independent of the package's own packing code)."""
+    N = g["pix_to_face"].shape[0]
+    faces = g["faces"]
+    parts = [g["verts"][faces], g["normals"][faces]]
+    if kind == "vcol":
+        parts.append(g["verts_colors"][faces])
+    fa = torch.cat(parts, 2).contiguous()
+
+    def rows(name, C=3, default=0.0):
+        t = g.get(name)
+        if t is None:
+            t = torch.full((1, C), default)
+        return t.reshape(-1, C).float().expand(N, C)
+
+    vec = g.get(f"{tag}_light_location", g.get(f"{tag}_light_direction"))
+    params = torch.cat([
+        rows(f"{tag}_light_ambient_color"), rows(f"{tag}_light_diffuse_color"), rows(f"{tag}_light_specular_color"),
+        (vec if vec is not None else torch.zeros(1, 3)).expand(N, 3), rows(f"{tag}_mat_ambient_color"),
+        rows(f"{tag}_mat_diffuse_color"), rows(f"{tag}_mat_specular_color"), rows(f"{tag}_mat_shininess", 1),
+        g["camera_center"]], 1).contiguous()
+    return fa, (g["texels"] if kind == "texels" else None), params, tag == "point"
+
+
+def scatter_face_grads(gfa, faces, V, lo, hi):
+    """grad of `x[faces]` wrt x for the columns lo:hi of a (F,3,D) face-record gradient (double accumulation)."""
+    out = torch.zeros(V, hi - lo, dtype=torch.float64)
+    out.index_add_(0, faces.reshape(-1), gfa[:, :, lo:hi].reshape(-1, hi - lo).double())
+    return out.float()
