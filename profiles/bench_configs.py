@@ -183,6 +183,93 @@ def main():
     torch.cuda.synchronize()
     row["torch_elementwise_same_gpu_ms_scaled_from_16_images"] = (time.perf_counter() - t0) / 3 * 1e3 * (64 / nb)
     out.append(row)
+    # ---- Phong shading on config-3 fragments ----------------------------------------
+    del colors, dg, zg, g_img
+    import pytorch3d_amd.shading as sh
+
+    class _Cam:
+        def __init__(self, c):
+            self.c = c
+
+        def get_camera_center(self):
+            return self.c
+
+    class _Mesh:
+        def __init__(self, v, f, n):
+            self.v, self.f, self.n = v, f, n
+
+        def verts_packed(self):
+            return self.v
+
+        def faces_packed(self):
+            return self.f
+
+        def verts_normals_packed(self):
+            return self.n
+
+    FragS = namedtuple("FragS", "pix_to_face bary_coords")
+    bary3 = p3d.rasterize_meshes(m3, image_size=512, blur_radius=blur, faces_per_pixel=8, perspective_correct=True,
+                                 clip_barycentric_coords=True)[2].detach()
+    v3 = m3.verts_packed().detach().clone().requires_grad_(True)
+    n3 = m3.verts_normals_packed().detach().clone().requires_grad_(True)
+    tex3 = torch.rand(64, 512, 512, 8, 3, generator=gen).to(d).requires_grad_(True)
+    bary_s = bary3.clone().requires_grad_(True)
+    g_col = torch.randn(64, 512, 512, 8, 3, generator=gen).to(d)
+    lights = sh.Lights(torch.rand(64, 3, generator=gen).to(d), torch.rand(64, 3, generator=gen).to(d),
+                       torch.rand(64, 3, generator=gen).to(d), location=(torch.randn(64, 3, generator=gen) * 2).to(d))
+    mats = sh.Materials(torch.rand(1, 3, generator=gen).to(d), torch.rand(1, 3, generator=gen).to(d),
+                        torch.rand(1, 3, generator=gen).to(d), torch.tensor([32.0], device=d))
+    cam = _Cam((torch.randn(64, 3, generator=gen) - torch.tensor([0.0, 0.0, 3.0])).to(d))
+    fp3 = m3.faces_packed()
+
+    def cs():
+        v3.grad = n3.grad = tex3.grad = bary_s.grad = None
+        col = p3d.phong_shading(_Mesh(v3, fp3, n3), FragS(p2f, bary_s), lights, cam, mats, tex3)
+        col.backward(g_col)
+
+    wall, k = timed(lib, _lib, cs, iters=3, warm=1)
+    Pn = p2f.numel()
+    # per sample: pix_to_face 8 + bary 12 + texel 12 (+ colour 12 out); backward adds grad_colors 12 in and
+    # grad_bary 12 + grad_texels 12 out; face records 72 B read (+ 72 B gradient written) per face
+    alg = {"phong_fwd": Pn * (8 + 12 + 12 + 12) + F * 72, "phong_bwd": Pn * (8 + 12 + 12 + 12 + 12 + 12) + 2 * F * 72}
+    row = {"config": "phong_shading fwd+bwd (fused) on config-3 fragments, N=64 512x512 K=8, point lights", "wall_ms": wall,
+           "kernels_ms": k, "algorithmic_bytes": alg, "GBps": {n: alg[n] / k[n] / 1e6 for n in alg if n in k},
+           "frac_of_hbm_peak": {n: alg[n] / k[n] / 1e6 / PEAK for n in alg if n in k}}
+
+    def torch_phong(nb):
+        import torch.nn.functional as Fn
+
+        pf, bb = p2f[:nb], bary_s[:nb].detach().requires_grad_(True)
+        vv, nn_ = v3.detach().requires_grad_(True), n3.detach().requires_grad_(True)
+        tt = tex3[:nb].detach().requires_grad_(True)
+        e = lambda t: t[:nb, None, None, None, :]
+        pts = p3d.interpolate_face_attributes(pf, bb, vv[fp3])
+        nrm = p3d.interpolate_face_attributes(pf, bb, nn_[fp3])
+        direction = e(lights.location) - pts
+        n_ = Fn.normalize(nrm, p=2, dim=-1, eps=1e-6)
+        d_ = Fn.normalize(direction, p=2, dim=-1, eps=1e-6)
+        cos = (n_ * d_).sum(-1)
+        ldiff = e(lights.diffuse_color) * torch.relu(cos)[..., None]
+        mask = (cos > 0).float()
+        view = Fn.normalize(e(cam.c) - pts, p=2, dim=-1, eps=1e-6)
+        refl = -d_ + 2 * (cos[..., None] * n_)
+        alpha = torch.relu((view * refl).sum(-1)) * mask
+        lspec = e(lights.specular_color) * torch.pow(alpha, mats.shininess)[..., None]
+        col = (e(mats.ambient_color * lights.ambient_color) + mats.diffuse_color * ldiff) * tt + mats.specular_color * lspec
+        col.backward(g_col[:nb])
+
+    # the reference's formulation (shading.py:59-96 + lighting.py:17-159 as torch ops + autograd, with THIS package's
+    # interpolate_face_attributes kernels inside) on the same GPU, on 8 images scaled by 8
+    nb = 8
+    torch_phong(nb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        torch_phong(nb)
+    torch.cuda.synchronize()
+    row["torch_op_chain_same_gpu_ms_scaled_from_8_images"] = (time.perf_counter() - t0) / 3 * 1e3 * (64 / nb)
+    out.append(row)
+    del v3, n3, tex3, bary_s, g_col, bary3
     # ---- clipping on the config-3 batch ------------------------------------------------
     from pytorch3d_amd import clip as pclip
 

@@ -15,6 +15,8 @@
 // Per-image parameters (25 floats, `P3D_SHADE_PARAM_FLOATS`): light ambient / diffuse / specular colour,
 // light location (point light) or direction (directional light), material ambient / diffuse / specular colour,
 // shininess, camera centre.  Ambient-only lights are a directional light with zero diffuse and specular colour.
+#include <stdlib.h>
+
 #include "p3d_common.h"
 #include "wave_table.h"
 
@@ -55,16 +57,15 @@ __device__ __forceinline__ float normalize3(const float (&x)[3], float (&out)[3]
   return len;
 }
 
-// gradient of normalize3 at x (xh = its output, len = |x|) for an upstream dxh
+// gradient of normalize3 at x (xh = its output, len = |x|) for an upstream dxh.  Gradient arithmetic is
+// tolerance-gated (rtol 1e-3): v_rcp_f32 instead of the IEEE division sequence.
 __device__ __forceinline__ void normalize3_bwd(const float (&xh)[3], float len, const float (&dxh)[3], float (&dx)[3]) {
-  if (len >= kNormEps) {  // clamp_min passes the gradient of the norm through
-    const float t = dot3(xh, dxh);
+  // clamp_min passes the gradient of the norm through only when the norm is the larger operand
+  const bool thru = len >= kNormEps;
+  const float t = thru ? dot3(xh, dxh) : 0.0f;
+  const float inv = __builtin_amdgcn_rcpf(thru ? len : kNormEps);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) dx[j] = (dxh[j] - xh[j] * t) / len;
-  } else {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) dx[j] = dxh[j] / kNormEps;
-  }
+  for (int j = 0; j < 3; ++j) dx[j] = (dxh[j] - xh[j] * t) * inv;
 }
 
 // Everything the backward needs again from the lighting of one sample.
@@ -73,25 +74,39 @@ struct Lit {
   float nlen, llen, vlen, cosv, d, alpha, angle, pw;
 };
 
-template <bool POINT>
+// FAST (backward only): reciprocal-multiply normalisation and exp2(s * log2(alpha)) for the power.
+template <bool FAST>
+__device__ __forceinline__ float normalize3_any(const float (&x)[3], float (&out)[3]) {
+  if constexpr (!FAST) return normalize3(x, out);
+  // v_rsq_f32 (1 ulp) instead of the IEEE sqrt + division sequences
+  const float d2 = dot3(x, x);
+  const float rs = __builtin_amdgcn_rsqf(d2);
+  const float len = d2 > 0.0f ? d2 * rs : 0.0f;
+  const float inv = len >= kNormEps ? rs : 1.0f / kNormEps;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) out[j] = x[j] * inv;
+  return len;
+}
+
+template <bool POINT, bool FAST = false>
 __device__ __forceinline__ Lit light_sample(const ShadeConst& c, const float (&P)[3], const float (&Nn)[3]) {
   Lit s;
-  s.nlen = normalize3(Nn, s.nh);
+  s.nlen = normalize3_any<FAST>(Nn, s.nh);
   float L[3], V[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     L[j] = POINT ? c.lvec[j] - P[j] : c.lvec[j];  // lighting.py:283-285 / :196-204
     V[j] = c.cam[j] - P[j];                       // lighting.py:151
   }
-  s.llen = normalize3(L, s.lh);
-  s.vlen = normalize3(V, s.vh);
+  s.llen = normalize3_any<FAST>(L, s.lh);
+  s.vlen = normalize3_any<FAST>(V, s.vh);
   s.cosv = dot3(s.nh, s.lh);
   s.angle = fmaxf(s.cosv, 0.0f);  // lighting.py:78
 #pragma unroll
   for (int j = 0; j < 3; ++j) s.R[j] = -s.lh[j] + 2.0f * (s.cosv * s.nh[j]);  // lighting.py:153
   s.d = dot3(s.vh, s.R);
   s.alpha = s.cosv > 0.0f ? fmaxf(s.d, 0.0f) : 0.0f;  // lighting.py:147,156
-  s.pw = powf(s.alpha, c.shin);                        // lighting.py:157
+  if constexpr (!FAST) s.pw = powf(s.alpha, c.shin);  // lighting.py:157
   return s;
 }
 
@@ -106,8 +121,9 @@ struct ShadeArgs {
   float* gbary;          // (N,H,W,K,3)
   float* gattrs;         // (F, 3, D)
   float* gtexels;        // (N,H,W,K,3) when D == 6
-  int N, H, W, K, RY, RX;
+  int N, H, W, K, RY, RX, AW;
   int64_t HWK;
+  int debug;  // P3D_DEBUG_SHADE ablation bits (profiles/shade_bench.py): 1 no table accumulation, 2 no lighting math, 4 no gbary / gtexels stores
 };
 
 // ---- forward: one thread per sample, blockIdx.y = image ----------------------------------------------------------
@@ -149,28 +165,43 @@ __global__ __launch_bounds__(256) void phong_fwd_kernel(ShadeArgs a) {
   }
 }
 
-// ---- backward: wave per 16x16 pixel area (four 8x8 tiles), lane per pixel, step per k --------------------------------
+// ---- backward: wave per area of 16 rows x AW pixels, lanes over consecutive (pixel, k) samples ------------------------
 template <int D>
 struct ShadeTable {
   static constexpr int NV = 3 * D;
-  static constexpr int kSlots = D == 6 ? 182 : 136;  // 4 waves x slots x (8 + 4 * stride) B: 64 KB / 65 KB
-  using T = WaveTable<NV, kSlots>;
+  // LDS per workgroup = 4 waves x slots x (8 + 4 * stride) B and the kernel is latency-bound, so the tables are sized
+  // for 4 (D = 6: 37 KB) / 3 (D = 9: 53 KB) workgroups per CU rather than for the worst case of a step (64 consecutive
+  // samples can name 64 faces): they run in SPILL mode (wave_table.h).  Measured on the config-3 fragments, D = 6:
+  // 182 slots (2 WG/CU) 4.3 ms, 144 (3 WG/CU) 3.3 ms, 106 (4 WG/CU) 2.9 ms.
+#ifndef P3D_SHADE_SLOTS6
+#define P3D_SHADE_SLOTS6 106
+#endif
+#ifndef P3D_SHADE_SLOTS9
+#define P3D_SHADE_SLOTS9 110
+#endif
+  static constexpr int kSlots = D == 6 ? P3D_SHADE_SLOTS6 : P3D_SHADE_SLOTS9;
+  using T = WaveTable<NV, kSlots, false, true>;
 };
 
 template <int D, bool POINT>
 __global__ __launch_bounds__(256) void phong_bwd_kernel(ShadeArgs a) {
+#pragma clang fp contract(fast)  // gradient-only arithmetic (tolerance-gated): let mul+add fuse into FMA
   using Tab = typename ShadeTable<D>::T;
   constexpr int NV = 3 * D;
   __shared__ __align__(16) int s_table[4][Tab::kLdsInts];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  long long t = blockIdx.x;
-  const int rx = (int)(t % a.RX);
-  t /= a.RX;
-  const int ry = (int)(t % a.RY);
-  const int n = (int)(t / a.RY);
-  const int ay = ry * 32 + (w >> 1) * 16, ax = rx * 32 + (w & 1) * 16;
+  // wave -> (image, strip of 16 rows, span of AW pixels); RY strips x RX spans per image
+  const int64_t wid = (int64_t)blockIdx.x * 4 + w;
+  const int64_t per_image = (int64_t)a.RY * a.RX;
+  if (wid >= (int64_t)a.N * per_image) return;  // wave-uniform; no workgroup barrier in this kernel
+  const int n = (int)(wid / per_image);
+  const int t = (int)(wid - (int64_t)n * per_image);
   const int H = a.H, W = a.W, K = a.K;
-  if (ay >= H || ax >= W) return;  // wave-uniform; no workgroup barrier in this kernel
+  const int y0 = (t / a.RX) * 16, x0 = (t % a.RX) * a.AW;
+  const int rows = min(16, H - y0), cols = min(a.AW, W - x0);
+  const int run = cols * K;        // contiguous samples per row of the area
+  const int total = rows * run;
+  const float inv_run = 1.0f / (float)run;
   const ShadeConst c = load_params(a.params + (int64_t)n * P3D_SHADE_PARAM_FLOATS);
   float amb[3], kd[3], ks[3];
 #pragma unroll
@@ -181,16 +212,19 @@ __global__ __launch_bounds__(256) void phong_bwd_kernel(ShadeArgs a) {
   }
   Tab tab;
   tab.init(s_table[w], lane);
+  // Lanes take 64 consecutive samples of a row ((pixel, k) pairs in memory order): every load and store of the
+  // per-sample arrays is then one contiguous 768-byte piece per wave instruction, for any K.  (A lane per pixel
+  // stepping through k writes 12 bytes at a stride of 12*K: measured 2.9 ms of 5.5 on partial-line stores.)
+  {
 #pragma unroll 1
-  for (int tile = 0; tile < 4; ++tile) {
-    const int yo = ay + (tile >> 1) * 8 + (lane >> 3);
-    const int xo = ax + (tile & 1) * 8 + (lane & 7);
-    const bool ok = yo < H && xo < W;
-    const int64_t base = (((int64_t)n * H + yo) * W + xo) * K;
-#pragma unroll 1
-    for (int k = 0; k < K; ++k) {
-      const int64_t p = base + k;
-      const int f = ok ? (int)a.p2f[p] : -1;
+    for (int e0 = 0; e0 < total; e0 += 64) {
+      const int e = e0 + lane;
+      const bool ok = e < total;
+      // exact for these small operands: (e + 0.5) / run is at least 0.5 / run away from an integer
+      const int r = (int)(((float)e + 0.5f) * inv_run);
+      const int64_t p = (((int64_t)n * H + y0 + r) * W + x0) * K + (e - r * run);
+      int f = ok ? (int)a.p2f[p] : -1;
+      if (a.debug & 2) f = -1;
       float g[NV];
       float gb[3] = {0.f, 0.f, 0.f};
       float go[3] = {0.f, 0.f, 0.f};
@@ -198,7 +232,7 @@ __global__ __launch_bounds__(256) void phong_bwd_kernel(ShadeArgs a) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) go[j] = a.gcolors[p * 3 + j];
       }
-      if (D == 6 && ok && f < 0) {
+      if (D == 6 && ok && f < 0 && !(a.debug & 4)) {
         // background sample with caller-supplied texels: colour = ambient * texel (+ a constant)
 #pragma unroll
         for (int j = 0; j < 3; ++j) a.gtexels[p * 3 + j] = amb[j] * go[j];
@@ -219,7 +253,7 @@ __global__ __launch_bounds__(256) void phong_bwd_kernel(ShadeArgs a) {
           else
             tex[j] = a.texels[p * 3 + j];
         }
-        const Lit s = light_sample<POINT>(c, P, Nn);
+        const Lit s = light_sample<POINT, true>(c, P, Nn);
         // colour_j = (amb_j + kd_j * angle) * tex_j + ks_j * pw
         float dtex[3];
         float dangle = 0.0f, dpw = 0.0f;
@@ -230,7 +264,10 @@ __global__ __launch_bounds__(256) void phong_bwd_kernel(ShadeArgs a) {
           dpw += ks[j] * go[j];
         }
         // pow backward (torch: 0 where the exponent is 0), relu and the cos > 0 mask
-        const float dalpha = c.shin == 0.0f ? 0.0f : c.shin * powf(s.alpha, c.shin - 1.0f) * dpw;
+        // alpha^(s-1) as exp2((s-1) * log2(alpha)): alpha = 0 gives exp2(-+inf) = 0 / inf and 0^0 = exp2(NaN) needs the select
+        const float em1 = c.shin - 1.0f;
+        const float apow = em1 == 0.0f ? 1.0f : __builtin_amdgcn_exp2f(em1 * __builtin_amdgcn_logf(s.alpha));
+        const float dalpha = c.shin == 0.0f ? 0.0f : c.shin * apow * dpw;
         const float dd = (s.cosv > 0.0f && s.d > 0.0f) ? dalpha : 0.0f;
         float dvh[3], dR[3], dlh[3], dnh[3];
 #pragma unroll
@@ -267,16 +304,16 @@ __global__ __launch_bounds__(256) void phong_bwd_kernel(ShadeArgs a) {
           }
           gb[i] = acc;
         }
-        if (D == 6) {
+        if (D == 6 && !(a.debug & 4)) {
 #pragma unroll
           for (int j = 0; j < 3; ++j) a.gtexels[p * 3 + j] = dtex[j];
         }
       }
-      if (ok) {
+      if (ok && !(a.debug & 4)) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) a.gbary[p * 3 + j] = gb[j];
       }
-      if (__ballot(f >= 0) == 0) continue;  // wave-uniform
+      if (__ballot(f >= 0) == 0 || (a.debug & 1)) continue;  // wave-uniform
       tab.add(a.gattrs, lane, f, g);
     }
   }
@@ -366,9 +403,14 @@ P3D_API int p3d_phong_shade_backward(const float* grad_colors, const int64_t* pi
   a.W = W;
   a.K = K;
   a.HWK = HWK;
-  a.RY = (int)ceil_div(H, 32);
-  a.RX = (int)ceil_div(W, 32);
-  const int64_t blocks = (int64_t)N * a.RY * a.RX;
+  a.AW = K >= 4 ? 16 : (K == 3 ? 24 : (K == 2 ? 32 : 64));  // >= 64 samples per row of the area
+  a.RY = (int)ceil_div(H, 16);
+  a.RX = (int)ceil_div(W, a.AW);
+  {
+    const char* e = getenv("P3D_DEBUG_SHADE");
+    a.debug = e ? atoi(e) : 0;
+  }
+  const int64_t blocks = ceil_div((int64_t)N * a.RY * a.RX, 4);
   if (blocks > 0x7fffffff) return P3D_ERR_INVALID_ARG;
   LaunchScope ls("phong_bwd", s);
   const bool point = light_kind == P3D_LIGHT_POINT;

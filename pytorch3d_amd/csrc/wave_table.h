@@ -27,10 +27,16 @@ constexpr int kEmptyKey = -1;
 
 // PLANAR: the output is NV planes of `plane` floats (out[j * plane + f], e.g. (C, P) features) instead of (P, NV)
 // rows; only the first `nlive` planes exist.
-template <int NV, int SLOTS, bool PLANAR = false>
+// SPILL: see kFlushAt.
+template <int NV, int SLOTS, bool PLANAR = false, bool SPILL = false>
 struct WaveTable {
   static constexpr int kStride = (NV + 3) / 4 * 4;  // floats per slot: values are moved as 16-byte chunks
-  static constexpr int kFlushAt = SLOTS - 64;       // a step adds at most 64 primitives: the table cannot overflow
+  // The table is emptied before a step when it is fuller than this.  A step adds up to 64 primitives, so by default 64
+  // slots stay in reserve and the table cannot overflow.  SPILL: no reserve -- the table fills up to 3/4 between
+  // steps, a lane that finds no free slot for its primitive during a step sends its values straight to memory with
+  // atomics, and the table is flushed after that step.  For small tables (3*D = 18..27 values per slot, ~100 slots in
+  // the LDS budget of 4 workgroups per CU) that doubles the usable capacity.
+  static constexpr int kFlushAt = SPILL ? SLOTS * 3 / 4 : SLOTS - 64;
   static constexpr int kLdsInts = SLOTS * (2 + kStride);
 
   volatile int* keys;   // [SLOTS] primitive id or kEmptyKey (volatile: other lanes write between my store and re-load)
@@ -93,8 +99,10 @@ struct WaveTable {
     const bool active = f >= 0;
     int slot = -1;
     bool fresh = false;
+    bool spill = false;  // no free slot left for this lane's primitive
     if (active) {
       int h = hash(f);
+      int tries = 0;
       for (;;) {
         const int cur = keys[h];
         if (cur == f) {
@@ -110,18 +118,33 @@ struct WaveTable {
           }
         }
         h = (h + 1 == SLOTS) ? 0 : h + 1;
+        if (SPILL && ++tries == SLOTS) {
+          spill = true;
+          break;
+        }
       }
     }
+    if (SPILL && spill) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        if constexpr (PLANAR) {
+          if (j < nlive && !no_atomics) unsafeAtomicAdd(out + j * plane + f, g[j]);
+        } else {
+          if (!no_atomics) unsafeAtomicAdd(out + (int64_t)f * NV + j, g[j]);
+        }
+      }
+    }
+    const bool linked = active && !spill;
     // chain the visitors of each slot: prev = the lane that visited before me in THIS step (stamp check)
     const int stamp = (gen << 6) | lane;
     int prev = -1;
-    if (active) {
+    if (linked) {
       const int old = atomicExch(const_cast<int*>(&owner[slot]), stamp);
       prev = (old >> 6) == gen ? (old & 63) : -1;
     }
-    bool head = active;
+    bool head = linked;
     if (__ballot(prev >= 0)) {  // wave-uniform: some primitive is hit by more than one lane
-      head = active && owner[slot] == stamp;  // the last visitor heads the list
+      head = linked && owner[slot] == stamp;  // the last visitor heads the list
       // after step s every lane holds the sum of the 2^s list entries starting at itself
       while (__ballot(prev >= 0) && !(dbg & 16)) {
         const int src = prev >= 0 ? prev : lane;
@@ -148,6 +171,7 @@ struct WaveTable {
       }
     }
     used += __popcll(__ballot(head && fresh));
+    if (SPILL && __ballot(spill)) flush(out, lane);
   }
 };
 
