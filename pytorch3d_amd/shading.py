@@ -6,6 +6,9 @@ value.  The reference runs two `interpolate_face_attributes` calls, `lights.diff
 twins; here it is ONE kernel forward and ONE backward (include/p3d_amd.h: p3d_phong_shade_forward / _backward).
 `phong_shading_vertex_colors` additionally fuses the `TexturesVertex` texel interpolation
 (renderer/mesh/textures.py: sample_textures = interpolate_face_attributes of the per-face vertex colours).
+`flat_shading` (shading.py:178-225) runs on the same kernels with per-face records (face centre, face normal);
+`gouraud_shading` (shading.py:125-175) lights the V vertices with plain torch ops (V-sized, not the hot part) and
+interpolates the shaded colours with the fused interpolate_face_attributes kernels.
 
 `lights`, `cameras`, `materials` are duck-typed: any object with the reference's attribute names works
 (`PointLights.location`, `DirectionalLights.direction`, `*.ambient_color / diffuse_color / specular_color`,
@@ -16,8 +19,10 @@ centre are constants of the fused kernels (a tensor among them that requires gra
 from typing import NamedTuple, Optional
 
 import torch
+import torch.nn.functional as Fn
 
 from . import _C, _lib
+from .interp_face_attrs import interpolate_face_attributes
 from .rasterize_meshes import gather_face_verts
 
 PARAM_FLOATS = 25  # include/p3d_amd.h: P3D_SHADE_PARAM_FLOATS
@@ -160,3 +165,51 @@ def phong_shading_vertex_colors(meshes, fragments, lights, cameras, materials, v
     params, kind = pack_shade_params(lights, cameras, materials, N, verts_colors_packed.device)
     fc = gather_face_verts(verts_colors_packed, meshes.faces_packed())
     return _PhongShade.apply(fragments.pix_to_face, fragments.bary_coords, _face_records(meshes, fc), None, params, kind)
+
+
+def flat_shading(meshes, fragments, lights, cameras, materials, texels) -> torch.Tensor:
+    """shading.py:178-225: lighting at the face centre with the face normal, same for every pixel of the face.  Runs the
+    Phong kernels on records whose three corners are identical; the barycentric coordinates (which sum to 1) then only
+    select the face, and get no gradient -- as in the reference, where pixels gather per-face values by index."""
+    _check(fragments, ("texels", texels))
+    N = fragments.pix_to_face.shape[0]
+    params, kind = pack_shade_params(lights, cameras, materials, N, texels.device)
+    fv = gather_face_verts(meshes.verts_packed(), meshes.faces_packed())
+    rec = torch.cat([fv.mean(dim=-2), meshes.faces_normals_packed()], 1)  # (F, 6): face centre | face normal
+    rec = rec[:, None, :].expand(rec.shape[0], 3, 6)
+    return _PhongShade.apply(fragments.pix_to_face, fragments.bary_coords.detach(), rec, texels, params, kind)
+
+
+def _light_points(points, normals, rows, kind):
+    """_apply_lighting (shading.py:17-56, lighting.py:17-159) for packed (P,3) points with one parameter row (P,25) each,
+    as torch ops: the V-sized vertex stage of Gouraud shading."""
+    la, ld, ls, vec = rows[:, 0:3], rows[:, 3:6], rows[:, 6:9], rows[:, 9:12]
+    ma, md, ms, shin, cam = rows[:, 12:15], rows[:, 15:18], rows[:, 18:21], rows[:, 21], rows[:, 22:25]
+    direction = vec - points if kind == LIGHT_POINT else vec
+    n = Fn.normalize(normals, p=2, dim=-1, eps=1e-6)
+    d = Fn.normalize(direction, p=2, dim=-1, eps=1e-6)
+    cos = (n * d).sum(-1)
+    light_diffuse = ld * torch.relu(cos)[:, None]
+    view = Fn.normalize(cam - points, p=2, dim=-1, eps=1e-6)
+    reflect = -d + 2 * (cos[:, None] * n)
+    alpha = torch.relu((view * reflect).sum(-1)) * (cos > 0).to(torch.float32)
+    light_specular = ls * torch.pow(alpha, shin)[:, None]
+    return ma * la, md * light_diffuse, ms * light_specular
+
+
+def gouraud_shading(meshes, fragments, lights, cameras, materials, verts_colors_packed=None) -> torch.Tensor:
+    """shading.py:125-175: light the vertices, interpolate the shaded vertex colours.  verts_colors_packed defaults to
+    meshes.textures.verts_features_packed() (the reference accepts TexturesVertex only)."""
+    if verts_colors_packed is None:
+        tex = getattr(meshes, "textures", None)
+        if tex is None or not hasattr(tex, "verts_features_packed"):
+            raise ValueError("Mesh textures must be an instance of TexturesVertex")
+        verts_colors_packed = tex.verts_features_packed()
+    _check(fragments, ("verts_colors_packed", verts_colors_packed))
+    verts, faces = meshes.verts_packed(), meshes.faces_packed()
+    N = fragments.pix_to_face.shape[0]
+    params, kind = pack_shade_params(lights, cameras, materials, N, verts.device)
+    rows = params[meshes.verts_packed_to_mesh_idx()]  # gather_props(vert_to_mesh_idx), shading.py:158-161
+    ambient, diffuse, specular = _light_points(verts, meshes.verts_normals_packed(), rows, kind)
+    shaded = verts_colors_packed * (ambient + diffuse) + specular
+    return interpolate_face_attributes(fragments.pix_to_face, fragments.bary_coords, gather_face_verts(shaded, faces))

@@ -77,6 +77,16 @@ class PackedMeshes:
             vn = vn.index_add(0, faces[:, c], fn)
         return torch.nn.functional.normalize(vn, eps=1e-6, dim=1)
 
+    def faces_normals_packed(self):
+        """Unit face normals cross(v1 - v0, v2 - v0) / max(|.|, 1e-6) as mesh_face_areas_normals
+        (csrc/face_areas_normals/face_areas_normals_cpu.cpp:44-62), with torch ops."""
+        fv = self._verts_packed[self._faces_packed]
+        c = torch.cross(fv[:, 1] - fv[:, 0], fv[:, 2] - fv[:, 0], dim=1)
+        return c / c.norm(dim=1, keepdim=True).clamp_min(1e-6)
+
+    def verts_packed_to_mesh_idx(self):
+        return torch.repeat_interleave(torch.arange(self._N, device=self.device), self._num_verts)
+
     def update_verts_packed(self, new_verts_packed):
         """Same topology, new vertex positions (like Meshes.update_padded, for camera transforms)."""
         out = object.__new__(PackedMeshes)

@@ -34,10 +34,22 @@ class MeshStub:
     def verts_normals_packed(self):
         return self.n
 
+    def faces_normals_packed(self):  # Meshes.faces_normals_packed needs _C.face_areas_normals (not a hot-path operator):
+        fv = self.v[self.f]          # face_areas_normals_cpu.cpp:44-62 restated with torch ops
+        c = torch.cross(fv[:, 1] - fv[:, 0], fv[:, 2] - fv[:, 0], dim=1)
+        return c / c.norm(dim=1, keepdim=True).clamp_min(1e-6)
+
 
 class CamStub:
     def __init__(self, c):
         self.c = c
+
+    def clone(self):
+        return CamStub(self.c.clone())
+
+    def gather_props(self, idx):  # TensorProperties.gather_props for the one property phong / gouraud shading read
+        self.c = self.c[idx]
+        return self
 
     def get_camera_center(self):
         return self.c
@@ -51,7 +63,8 @@ def main():
     from pytorch3d.ops import interpolate_face_attributes
     from pytorch3d.renderer.lighting import AmbientLights, DirectionalLights, PointLights
     from pytorch3d.renderer.materials import Materials
-    from pytorch3d.renderer.mesh.shading import phong_shading
+    from pytorch3d.renderer.mesh.shading import flat_shading, gouraud_shading, phong_shading
+    from pytorch3d.renderer.mesh.textures import TexturesVertex
     from pytorch3d.structures import Meshes
 
     gen = torch.Generator().manual_seed(404)
@@ -107,6 +120,28 @@ def main():
                 out[f"{tag}_light_{n_}"] = getattr(L, n_)
         for n_ in ("ambient_color", "diffuse_color", "specular_color", "shininess"):
             out[f"{tag}_mat_{n_}"] = getattr(M, n_)
+    # flat shading (shading.py:178-225) and Gouraud shading (shading.py:125-175, through the real Meshes + TexturesVertex)
+    nv = [int(x) for x in real.num_verts_per_mesh()]
+    for tag in ("point", "dir"):
+        L, M = lights[tag], mats[tag]
+        v = verts.clone().requires_grad_(True)
+        t_in = texels0.clone().requires_grad_(True)
+        col = flat_shading(MeshStub(v, faces, None), Frag(p2f, bary), L, CamStub(cam), M, t_in)
+        g = torch.randn(col.shape, generator=gen)
+        (col * g).sum().backward()
+        out.update({f"{tag}_flat_colors": col, f"{tag}_flat_grad_colors": g, f"{tag}_flat_grad_verts": v.grad,
+                    f"{tag}_flat_grad_tex": t_in.grad})
+        vl = [x.clone().requires_grad_(True) for x in verts.split(nv)]
+        cl = [x.clone().requires_grad_(True) for x in colors_v.split(nv)]
+        b = bary.clone().requires_grad_(True)
+        gm = Meshes(verts=vl, faces=faces_l, textures=TexturesVertex(verts_features=cl))
+        col = gouraud_shading(gm, Frag(p2f, b), L, CamStub(cam), M)
+        g = torch.randn(col.shape, generator=gen)
+        (col * g).sum().backward()
+        out.update({f"{tag}_gouraud_colors": col, f"{tag}_gouraud_grad_colors": g,
+                    f"{tag}_gouraud_grad_verts": torch.cat([x.grad for x in vl]),
+                    f"{tag}_gouraud_grad_tex": torch.cat([x.grad for x in cl]), f"{tag}_gouraud_grad_bary": b.grad})
+    out["num_verts_per_mesh"] = torch.tensor(nv)
     mg.save("shading_ref", **out)
     print({k: tuple(v.shape) for k, v in out.items() if k.startswith("point_texels")})
     print("coverage", float((p2f >= 0).float().mean()))

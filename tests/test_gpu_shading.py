@@ -83,6 +83,49 @@ def test_phong_shading_mirror_vs_reference_fixture(tag, kind):
             assert got is None or got.abs().max() == 0, name
 
 
+@pytest.mark.parametrize("tag", ["point", "dir"])
+def test_flat_and_gouraud_mirrors_vs_reference_fixture(tag):
+    import pytorch3d_amd as p3d
+
+    g = U.shading_golden()
+    d = torch.device("cuda:0")
+    L, M = _lights_of(g, tag, d)
+    cam = Cam(g["camera_center"].to(d))
+    nv = [int(x) for x in g["num_verts_per_mesh"]]
+    faces = g["faces"].to(d)
+    off = 0
+    faces_l = []
+    for n_ in nv:  # back to per-mesh vertex indices
+        sel = (g["faces"][:, 0] >= off) & (g["faces"][:, 0] < off + n_)
+        faces_l.append((g["faces"][sel] - off).to(d))
+        off += n_
+    # flat: per-face lighting
+    vl = [x.to(d).requires_grad_(True) for x in g["verts"].split(nv)]
+    m = p3d.PackedMeshes(vl, faces_l)
+    assert torch.equal(m.faces_packed(), faces)
+    t_in = g["texels"].to(d).requires_grad_(True)
+    b = g["bary"].to(d).requires_grad_(True)
+    col = p3d.flat_shading(m, Frag(g["pix_to_face"].to(d), b), L, cam, M, t_in)
+    ref = g[f"{tag}_flat_colors"]
+    assert torch.allclose(col.cpu(), ref, atol=1e-5, rtol=1e-5), (col.cpu() - ref).abs().max()
+    col.backward(g[f"{tag}_flat_grad_colors"].to(d))
+    assert _close(torch.cat([x.grad for x in vl]).cpu(), g[f"{tag}_flat_grad_verts"])
+    assert _close(t_in.grad.cpu(), g[f"{tag}_flat_grad_tex"])
+    assert b.grad is None or b.grad.abs().max() == 0  # per-face values: no gradient to the barycentrics
+    # Gouraud: per-vertex lighting, interpolated
+    vl = [x.to(d).requires_grad_(True) for x in g["verts"].split(nv)]
+    m = p3d.PackedMeshes(vl, faces_l)
+    vc = g["verts_colors"].to(d).requires_grad_(True)
+    b = g["bary"].to(d).requires_grad_(True)
+    col = p3d.gouraud_shading(m, Frag(g["pix_to_face"].to(d), b), L, cam, M, verts_colors_packed=vc)
+    ref = g[f"{tag}_gouraud_colors"]
+    assert torch.allclose(col.cpu(), ref, atol=1e-5, rtol=1e-5), (col.cpu() - ref).abs().max()
+    col.backward(g[f"{tag}_gouraud_grad_colors"].to(d))
+    assert _close(torch.cat([x.grad for x in vl]).cpu(), g[f"{tag}_gouraud_grad_verts"])
+    assert _close(vc.grad.cpu(), g[f"{tag}_gouraud_grad_tex"])
+    assert _close(b.grad.cpu(), g[f"{tag}_gouraud_grad_bary"])
+
+
 @pytest.mark.parametrize("K,size", [(1, (16, 16)), (3, (45, 37)), (8, (33, 64)), (10, (20, 50))])
 @pytest.mark.parametrize("point", [True, False])
 @pytest.mark.parametrize("D", [6, 9])
