@@ -339,3 +339,32 @@ def test_backward_with_unused_outputs():
     gv = torch.zeros_like(verts[0])
     gv.index_add_(0, faces[0].reshape(-1), ref.reshape(-1, 3))
     assert torch.allclose(vg[0].grad.cpu(), gv, rtol=5e-3, atol=5e-4 * max(1.0, gv.abs().max().item()))
+
+
+def test_rasterize_meshes_is_hip_graph_capturable():
+    """The C ABI launches are asynchronous on the caller's stream, allocate nothing and never synchronise: a
+    torch.cuda.graph capture of the operator replays bit-identical results (profiles/graph_c2.py)."""
+    from pytorch3d_amd import _C
+
+    d = torch.device("cuda:0")
+    v, f = U.ico_sphere(3)
+    fv = U.to_ndc(v)[f].to(d).contiguous()
+    F = fv.shape[0]
+    first = torch.zeros(1, dtype=torch.int64, device=d)
+    cnt = torch.tensor([F], dtype=torch.int64, device=d)
+    nbr = torch.full((F,), -1, dtype=torch.int64, device=d)
+    args = (fv, first, cnt, nbr, (96, 128), 1e-4, 4, 16, 2000, True, True, False)
+    ref = _C.rasterize_meshes(*args)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        _C.rasterize_meshes(*args)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = _C.rasterize_meshes(*args)
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
