@@ -155,6 +155,87 @@ __device__ __forceinline__ void write_pixel(const MeshArgs& a, const Queue& q, i
   }
 }
 
+// Output of one wave's 8x8 sub-tile when K has no vector-row path (K != KT, or the queue lives in memory).
+// A lane writing its own pixel's K-row dword by dword stores 4 bytes at a stride of 4*K: every store is a partial
+// line and the kernel spends its time there (measured at K = 100: 9.5 of 11.5 ms; K = 16: 1.2 of 1.7 ms).  Instead:
+//   (A) all 64 lanes fill the sub-tile's rows of the four outputs with -1 in memory order (each instruction one
+//       contiguous 256-byte piece) -- at most K of a row's entries are ever valid, usually far fewer;
+//   (B) once those stores have been acknowledged, every lane patches in its pixel's valid entries.
+// `have` = false: background, (A) only.
+template <typename Queue, int KT, bool IN_REGS>
+__device__ __forceinline__ void write_subtile_fill_patch(const MeshArgs& a, const Queue& q, bool have, int n, int sy0,
+                                                         int sx0, int y_end, int x_end, int lane, bool pix_ok, int yi,
+                                                         int xi) {
+  const int H = a.H, W = a.W, K = a.K;
+  const int rows = min(8, y_end - sy0), cols = min(8, x_end - sx0);
+  const int seg = cols * K;             // contiguous entries per sub-tile row (outputs are stored flipped: x_out = W-1-x)
+  const int64_t col0 = W - sx0 - cols;  // first output column of the sub-tile
+  const bool patch = have && !(a.debug & 1024);
+  for (int r = 0; r < rows; ++r) {
+    // ---- (A) fill row r of the sub-tile: one contiguous piece of each output ----
+    const int64_t px = ((int64_t)n * H + (H - 1 - (sy0 + r))) * W + col0;
+    if ((K & 3) == 0) {
+      // every pixel's K-row starts on a 16-byte boundary in all four outputs: 16-byte stores
+      const int q4 = seg >> 2;  // float4 pieces of this row in zbuf / dists; p2f has 2x, bary 3x as many
+      const float4 m1 = make_float4(-1.0f, -1.0f, -1.0f, -1.0f);
+      longlong2 i1;
+      i1.x = -1;
+      i1.y = -1;
+      float4* zb = reinterpret_cast<float4*>(a.zbuf + px * K);
+      float4* db = reinterpret_cast<float4*>(a.dists + px * K);
+      float4* bb = reinterpret_cast<float4*>(a.bary + px * K * 3);
+      longlong2* ib = reinterpret_cast<longlong2*>(a.p2f + px * K);
+      for (int e = lane; e < 3 * q4; e += 64) {
+        bb[e] = m1;
+        if (e < 2 * q4) ib[e] = i1;
+        if (e < q4) {
+          zb[e] = m1;
+          db[e] = m1;
+        }
+      }
+    } else {
+      for (int e = lane; e < 3 * seg; e += 64) {
+        a.bary[px * K * 3 + e] = -1.0f;
+        if (e < seg) {
+          a.p2f[px * K + e] = -1;
+          a.zbuf[px * K + e] = -1.0f;
+          a.dists[px * K + e] = -1.0f;
+        }
+      }
+    }
+    if (!patch) continue;
+    // ---- (B) the 8 lanes that own the pixels of row r patch in their valid entries, while the lines are still in
+    // L2.  It must land after (A) although other lanes issued (A)'s stores to these addresses: wait until this wave's
+    // stores have been acknowledged (same wave, same cache hierarchy: no cache write-back needed, only the counter).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!pix_ok || (lane >> 3) != r) continue;
+    const int64_t base = (((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi)) * K;
+    if constexpr (IN_REGS) {
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        if (k < K && q.valid(k)) {
+          a.p2f[base + k] = (int64_t)q.idx[k];
+          a.zbuf[base + k] = q.z[k];
+          a.dists[base + k] = q.pl[0][k];
+          a.bary[(base + k) * 3 + 0] = q.pl[1][k];
+          a.bary[(base + k) * 3 + 1] = q.pl[2][k];
+          a.bary[(base + k) * 3 + 2] = q.pl[3][k];
+        }
+      }
+    } else {
+      for (int k = 0; k < K; ++k) {
+        if (!q.valid(k)) break;
+        a.p2f[base + k] = (int64_t)q.idx[k];
+        a.zbuf[base + k] = q.z[k];
+        a.dists[base + k] = q.pl[0][k];
+        a.bary[(base + k) * 3 + 0] = q.pl[1][k];
+        a.bary[(base + k) * 3 + 1] = q.pl[2][k];
+        a.bary[(base + k) * 3 + 2] = q.pl[3][k];
+      }
+    }
+  }
+}
+
 template <typename Queue, int KT, bool IN_REGS, bool BINNED>
 __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_kernel(MeshArgs a) {
   __shared__ float4 s_box[kStage];       // xlo, xhi, ylo, yhi (blur-expanded)
@@ -198,10 +279,14 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
   }
   if (count <= 0) {
     // background tile (4 of 5 at the bench workload): nothing but the -1 stores; skip the NDC set-up below
-    if (pix_ok && !(a.debug & 4)) {
+    if (!(a.debug & 4)) {
       Queue e;
       e.init();
-      write_pixel<Queue, KT, IN_REGS>(a, e, ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi));
+      if (IN_REGS && a.K == KT) {
+        if (pix_ok) write_pixel<Queue, KT, IN_REGS>(a, e, ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi));
+      } else if (wave_ok) {
+        write_subtile_fill_patch<Queue, KT, IN_REGS>(a, e, false, n, sy0, sx0, y_end, x_end, lane, pix_ok, yi, xi);
+      }
     }
     return;
   }
@@ -369,9 +454,12 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
     atomicAdd(&a.counters[7], c_ins);
   }
 #endif
-  if (pix_ok && !(a.debug & 4)) {
-    const int64_t opix = ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi);
-    write_pixel<Queue, KT, IN_REGS>(a, q, opix);
+  if (!(a.debug & 4)) {
+    if (IN_REGS && K == KT) {
+      if (pix_ok) write_pixel<Queue, KT, IN_REGS>(a, q, ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi));
+    } else if (wave_ok) {
+      write_subtile_fill_patch<Queue, KT, IN_REGS>(a, q, true, n, sy0, sx0, y_end, x_end, lane, pix_ok, yi, xi);
+    }
   }
 }
 

@@ -165,21 +165,47 @@ __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
         tab.add(a.grad_fv, lane, f[k], r.g);
       }
     } else {
+      // any K: pix_to_face is read four slots (one 32-byte sector) at a time -- a lane per pixel reading 8 bytes at a
+      // stride of 8*K fetches a whole sector per slot (K = 100: 3.3 ms, most of it this) -- and chunks without a face,
+      // i.e. nearly all of a row's -1 padding, are skipped whole
+      const bool vec = (K & 1) == 0;  // K-rows start on 16-byte boundaries
 #pragma unroll 1
-      for (int k = 0; k < K; ++k) {
-        const int64_t i = base + k;
-        const int f = ok ? (int)a.p2f[i] : -1;
-        if (__ballot(f >= 0) == 0) continue;
-        FaceGrad r;
-        if (f >= 0) {
-          const float* g = a.face_verts + (int64_t)f * 9;
-          const f3 v0 = mk3(g[0], g[1], g[2]);
-          const f3 v1 = mk3(g[3], g[4], g[5]);
-          const f3 v2 = mk3(g[6], g[7], g[8]);
-          const f3 gb = mk3(a.grad_bary[i * 3 + 0], a.grad_bary[i * 3 + 1], a.grad_bary[i * 3 + 2]);
-          r = face_sample_bwd(v0, v1, v2, p, a.grad_zbuf[i], gb, a.grad_dists[i], persp, clip, false);
+      for (int k0 = 0; k0 < K; k0 += 4) {
+        int f4[4] = {-1, -1, -1, -1};
+        if (ok) {
+          const int64_t* src = a.p2f + base + k0;
+          if (vec) {
+            const longlong2 t0 = *reinterpret_cast<const longlong2*>(src);
+            f4[0] = (int)t0.x;
+            f4[1] = (int)t0.y;
+            if (k0 + 2 < K) {
+              const longlong2 t1 = *reinterpret_cast<const longlong2*>(src + 2);
+              f4[2] = (int)t1.x;
+              f4[3] = (int)t1.y;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (k0 + j < K) f4[j] = (int)src[j];
+          }
         }
-        tab.add(a.grad_fv, lane, f, r.g);
+        if (__ballot((f4[0] >= 0) | (f4[1] >= 0) | (f4[2] >= 0) | (f4[3] >= 0)) == 0) continue;  // wave-uniform
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+          const int f = j == 0 ? f4[0] : (j == 1 ? f4[1] : (j == 2 ? f4[2] : f4[3]));
+          if (__ballot(f >= 0) == 0) continue;  // wave-uniform
+          const int64_t i = base + k0 + j;
+          FaceGrad r;
+          if (f >= 0) {
+            const float* g = a.face_verts + (int64_t)f * 9;
+            const f3 v0 = mk3(g[0], g[1], g[2]);
+            const f3 v1 = mk3(g[3], g[4], g[5]);
+            const f3 v2 = mk3(g[6], g[7], g[8]);
+            const f3 gb = mk3(a.grad_bary[i * 3 + 0], a.grad_bary[i * 3 + 1], a.grad_bary[i * 3 + 2]);
+            r = face_sample_bwd(v0, v1, v2, p, a.grad_zbuf[i], gb, a.grad_dists[i], persp, clip, false);
+          }
+          tab.add(a.grad_fv, lane, f, r.g);
+        }
       }
     }
   }
