@@ -32,6 +32,31 @@ __global__ __launch_bounds__(256) void interp_fwd_kernel(const int64_t* __restri
   }
 }
 
+// f32, D % 4 == 0 (feature textures): one thread per (sample, four channels) -- 16-byte attribute reads and output
+// writes, a 32-bit division by D/4 instead of a 64-bit one per element.  Same association per element as above.
+__global__ __launch_bounds__(256) void interp_fwd_vec4_kernel(const int64_t* __restrict__ p2f, const float* __restrict__ bary,
+                                                              const float* __restrict__ attrs, int64_t P, int D4,
+                                                              float* __restrict__ out) {
+  const int64_t total = P * D4;
+  const int D = D4 * 4;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = q / D4;
+    const int c = (int)(q - p * D4);
+    const int64_t f = p2f[p];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f >= 0) {
+      const float w0 = bary[p * 3], w1 = bary[p * 3 + 1], w2 = bary[p * 3 + 2];
+      const float4* a = reinterpret_cast<const float4*>(attrs + f * 3 * D) + c;
+      const float4 a0 = a[0], a1 = a[D4], a2 = a[2 * D4];
+      v.x = ((0.0f + w0 * a0.x) + w1 * a1.x) + w2 * a2.x;
+      v.y = ((0.0f + w0 * a0.y) + w1 * a1.y) + w2 * a2.y;
+      v.z = ((0.0f + w0 * a0.z) + w1 * a1.z) + w2 * a2.z;
+      v.w = ((0.0f + w0 * a0.w) + w1 * a1.w) + w2 * a2.w;
+    }
+    reinterpret_cast<float4*>(out)[q] = v;
+  }
+}
+
 // f32, D <= 4: one thread per sample -- pix_to_face (8 B), the barycentrics (12 B) and the D outputs are each read /
 // written once, coalesced; the generic kernel above is one thread per (sample, d) and pays a 64-bit division per
 // element plus D-fold re-reads.
@@ -156,6 +181,93 @@ void launch_interp_bwd_table(const int64_t* p2f, const float* bary, const float*
   const int64_t blocks = ceil_div(waves, 4);
   const int64_t span = ceil_div(ceil_div(P, blocks * 4), 64) * 64;
   interp_bwd_table_kernel<D><<<(unsigned)blocks, 256, 0, s>>>(p2f, bary, attrs, gout, P, span, gbary, gattrs);
+}
+
+// f32, D > 4 (feature textures): one launch per chunk of four channels [c0, c0 + 4).  A sample's 3*D partials do not
+// fit a table slot, and per-sample atomics (the reference's design) run at ~70 GB/s of algorithmic traffic (D = 8:
+// 28 ms on 34 M samples); per chunk the kernel is the small-D one: p2f and bary are re-read (20 B), the chunk of
+// grad_pix_attrs is read once (16 B), grad_bary is written by the first chunk and accumulated by the others.
+using ChunkTable = WaveTable<12, 182, kChunk>;  // 4 waves x 182 x 56 B = 40 KB
+
+__global__ __launch_bounds__(256) void interp_bwd_chunk_kernel(const int64_t* __restrict__ p2f, const float* __restrict__ bary,
+                                                               const float* __restrict__ attrs,
+                                                               const float* __restrict__ gout, int64_t P, int64_t span, int D,
+                                                               int c0, int nc, int first, float* __restrict__ gbary,
+                                                               float* __restrict__ gattrs) {
+  __shared__ __align__(16) int s_table[4][ChunkTable::kLdsInts];
+  const int lane = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + w;
+  const int64_t begin = wave * span;
+  if (begin >= P) return;  // wave-uniform; the kernel has no workgroup barrier
+  const int64_t end = begin + span < P ? begin + span : P;
+  ChunkTable tab;
+  tab.init(s_table[w], lane);
+  tab.plane = 3 * (int64_t)D;
+  tab.pitch = D;
+  tab.nlive = nc;
+  float* out = gattrs + c0;
+  const bool vec = (D & 3) == 0;  // a sample's chunk of grad_pix_attrs is 16-byte aligned
+  for (int64_t base = begin; base < end; base += 64) {
+    const int64_t p = base + lane;
+    const bool ok = p < end;
+    const int f = ok ? (int)p2f[p] : -1;
+    float g[12];
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (f >= 0) {
+      const float w0 = bary[p * 3 + 0], w1 = bary[p * 3 + 1], w2 = bary[p * 3 + 2];
+      const float* a = attrs + (int64_t)f * 3 * D + c0;
+      float up[4] = {0.f, 0.f, 0.f, 0.f};
+      if (vec) {
+        const float4 t = *reinterpret_cast<const float4*>(gout + p * D + c0);
+        up[0] = t.x;
+        up[1] = t.y;
+        up[2] = t.z;
+        up[3] = t.w;
+      } else {
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+          if (d < nc) up[d] = gout[p * D + c0 + d];
+      }
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const bool live = d < nc;
+        g0 += live ? a[d] * up[d] : 0.0f;
+        g1 += live ? a[D + d] * up[d] : 0.0f;
+        g2 += live ? a[2 * D + d] * up[d] : 0.0f;
+        g[d] = w0 * up[d];
+        g[4 + d] = w1 * up[d];
+        g[8 + d] = w2 * up[d];
+      }
+    }
+    if (ok) {
+      if (first) {
+        gbary[p * 3 + 0] = g0;
+        gbary[p * 3 + 1] = g1;
+        gbary[p * 3 + 2] = g2;
+      } else if (f >= 0) {
+        gbary[p * 3 + 0] += g0;
+        gbary[p * 3 + 1] += g1;
+        gbary[p * 3 + 2] += g2;
+      }
+    }
+    if (__ballot(f >= 0) == 0) continue;  // wave-uniform
+    tab.add(out, lane, f, g);
+  }
+  if (tab.used > 0) tab.flush(out, lane);
+}
+
+void launch_interp_bwd_chunks(const int64_t* p2f, const float* bary, const float* attrs, const float* gout, int64_t P, int D,
+                              float* gbary, float* gattrs, hipStream_t s) {
+  int64_t waves = ceil_div(P, 4096);
+  if (waves > 4 * 8192) waves = 4 * 8192;
+  if (waves < 1) waves = 1;
+  const int64_t blocks = ceil_div(waves, 4);
+  const int64_t span = ceil_div(ceil_div(P, blocks * 4), 64) * 64;
+  for (int c0 = 0; c0 < D; c0 += 4) {
+    const int nc = D - c0 < 4 ? D - c0 : 4;
+    interp_bwd_chunk_kernel<<<(unsigned)blocks, 256, 0, s>>>(p2f, bary, attrs, gout, P, span, D, c0, nc, c0 == 0, gbary, gattrs);
+  }
 }
 
 // ---- image-shaped backward: the caller knows that the P samples are (N, H, W, K) fragments ---------------------
@@ -353,6 +465,11 @@ P3D_API int p3d_interp_face_attrs_forward(int dtype, const int64_t* p2f, const v
     }
     return launch_status();
   }
+  if (dtype == 0 && D % 4 == 0 && D <= (1 << 20)) {
+    interp_fwd_vec4_kernel<<<pick_grid(P * (D / 4)), 256, 0, s>>>(p2f, (const float*)bary, (const float*)attrs, P,
+                                                                  (int)(D / 4), (float*)out);
+    return launch_status();
+  }
   if (dtype == 0)
     interp_fwd_kernel<float><<<pick_grid(P * D), 256, 0, s>>>(p2f, (const float*)bary, (const float*)attrs, P, D,
                                                              (float*)out);
@@ -435,6 +552,11 @@ P3D_API int p3d_interp_face_attrs_backward(int dtype, const int64_t* p2f, const 
       case 3: launch_interp_bwd_table<3>(p2f, b, at, go, P, gb, ga, s); break;
       default: launch_interp_bwd_table<4>(p2f, b, at, go, P, gb, ga, s); break;
     }
+    return launch_status();
+  }
+  if (dtype == 0 && D > 4 && F > 0) {
+    launch_interp_bwd_chunks(p2f, (const float*)bary, (const float*)attrs, (const float*)gout, P, (int)D, (float*)gbary,
+                             (float*)gattrs, s);
     return launch_status();
   }
   if (dtype == 0)

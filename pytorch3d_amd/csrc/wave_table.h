@@ -25,10 +25,14 @@ namespace p3d {
 
 constexpr int kEmptyKey = -1;
 
-// PLANAR: the output is NV planes of `plane` floats (out[j * plane + f], e.g. (C, P) features) instead of (P, NV)
-// rows; only the first `nlive` planes exist.
+// LAYOUT of the output the table is flushed to:
+//   kRows   out[f * NV + j]                                   (P, NV) rows
+//   kPlanar out[j * plane + f], j < nlive                     NV planes of `plane` floats, e.g. (C, P) features
+//   kChunk  out[f * plane + (j / 4) * pitch + j % 4], j % 4 < nlive
+//           a 4-wide column chunk of (P, NV/4, pitch) records, e.g. channels c0..c0+3 of (F, 3, D) face attributes
 // SPILL: see kFlushAt.
-template <int NV, int SLOTS, bool PLANAR = false, bool SPILL = false>
+enum { kRows = 0, kPlanar = 1, kChunk = 2 };
+template <int NV, int SLOTS, int LAYOUT = kRows, bool SPILL = false>
 struct WaveTable {
   static constexpr int kStride = (NV + 3) / 4 * 4;  // floats per slot: values are moved as 16-byte chunks
   // The table is emptied before a step when it is fuller than this.  A step adds up to 64 primitives, so by default 64
@@ -44,8 +48,16 @@ struct WaveTable {
   float* vals;          // [SLOTS][kStride]
   int used;             // occupied slots (wave-uniform)
   int gen;              // step counter (wave-uniform), > 0
-  int64_t plane = 0;        // PLANAR only: floats per output plane
-  int nlive = NV;           // PLANAR only: planes that exist (values of the others are never flushed)
+  int64_t plane = 0;        // kPlanar: floats per output plane; kChunk: floats per primitive record
+  int pitch = 0;            // kChunk: floats between the NV/4 sub-rows of a record
+  int nlive = NV;           // kPlanar: planes that exist; kChunk: live columns of the chunk (others are never flushed)
+
+  // address of value j of primitive f, or nullptr when that value has no destination
+  __device__ __forceinline__ float* dest(float* __restrict__ out, int f, int j) const {
+    if constexpr (LAYOUT == kPlanar) return j < nlive ? out + j * plane + f : nullptr;
+    if constexpr (LAYOUT == kChunk) return (j & 3) < nlive ? out + (int64_t)f * plane + (j >> 2) * pitch + (j & 3) : nullptr;
+    return out + (int64_t)f * NV + j;
+  }
   bool no_atomics = false;  // ablation only (profiles/ablate.py): drop the global atomics of flush()
   int dbg = 0;              // ablation only (results become wrong): 16 skip the list summation, 32 skip the table update
 
@@ -74,15 +86,10 @@ struct WaveTable {
     for (int s = lane; s < SLOTS; s += 64) {
       const int f = keys[s];
       if (f != kEmptyKey) {
-        if constexpr (PLANAR) {
 #pragma unroll
-          for (int j = 0; j < NV; ++j)
-            if (j < nlive && !no_atomics) unsafeAtomicAdd(out + j * plane + f, vals[s * kStride + j]);
-        } else {
-          float* o = out + (int64_t)f * NV;
-#pragma unroll
-          for (int j = 0; j < NV; ++j)
-            if (!no_atomics) unsafeAtomicAdd(o + j, vals[s * kStride + j]);
+        for (int j = 0; j < NV; ++j) {
+          float* o = dest(out, f, j);
+          if (o && !no_atomics) unsafeAtomicAdd(o, vals[s * kStride + j]);
         }
         keys[s] = kEmptyKey;
       }
@@ -127,11 +134,8 @@ struct WaveTable {
     if (SPILL && spill) {
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
-        if constexpr (PLANAR) {
-          if (j < nlive && !no_atomics) unsafeAtomicAdd(out + j * plane + f, g[j]);
-        } else {
-          if (!no_atomics) unsafeAtomicAdd(out + (int64_t)f * NV + j, g[j]);
-        }
+        float* o = dest(out, f, j);
+        if (o && !no_atomics) unsafeAtomicAdd(o, g[j]);
       }
     }
     const bool linked = active && !spill;

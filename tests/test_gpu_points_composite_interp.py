@@ -150,7 +150,7 @@ def test_compositor_autograd_mirror():
         assert torch.allclose(alphas.grad.cpu(), rga, atol=1e-4, rtol=1e-4)
 
 
-@pytest.mark.parametrize("D", [1, 3, 4, 7, 32])
+@pytest.mark.parametrize("D", [1, 3, 4, 7, 8, 32])
 def test_interp_face_attrs(D):
     from pytorch3d_amd import _C
 
