@@ -202,6 +202,10 @@ int launch_point_raster(const PointArgs& a, hipStream_t stream) {
     point_raster_kernel<TopKReg<12, 1>, 12, true, BINNED><<<grid, kStage, 0, stream>>>(a);
   else if (K <= 16)
     point_raster_kernel<TopKReg<16, 1>, 16, true, BINNED><<<grid, kStage, 0, stream>>>(a);
+  else if (K <= 24)  // 3 registers per entry: still cheaper than a queue in private memory, which a dense cloud keeps full
+    point_raster_kernel<TopKReg<24, 1>, 24, true, BINNED><<<grid, kStage, 0, stream>>>(a);
+  else if (K <= 32)
+    point_raster_kernel<TopKReg<32, 1>, 32, true, BINNED><<<grid, kStage, 0, stream>>>(a);
   else
     point_raster_kernel<TopKMem<P3D_MAX_K, 1>, P3D_MAX_K, false, BINNED><<<grid, kStage, 0, stream>>>(a);
   return launch_status();
