@@ -63,3 +63,34 @@ def test_soft_phong_render_matches_reference_renderer():
     img.backward(t("grad_image").to(d))
     rg = t("grad_verts_colors")
     assert torch.allclose(vcol.grad.cpu(), rg, rtol=2e-3, atol=2e-4 * rg.abs().max().item())
+
+
+@pytest.mark.parametrize("tag", ["alpha", "norm"])
+def test_points_render_matches_reference_renderer(tag):
+    """rasterize_points -> (1 - d2 / r2) weights -> compositor, against the reference's PointsRenderer(PointsRasterizer,
+    AlphaCompositor | NormWeightedCompositor) on CPU (tests/golden/make_golden_render_points.py)."""
+    import pytorch3d_amd as p3d
+
+    g = np.load(os.path.join(U.GOLDEN, "render_points_ref.npz"))
+    t = lambda k: torch.from_numpy(g[k])
+    d = torch.device("cuda:0")
+    npts = [int(x) for x in g["num_points"]]
+    pc = p3d.PackedPointclouds([p.to(d) for p in t("points_ndc").split(npts)])
+    H, W = (int(x) for x in g["image_size"])
+    r, K = float(g["radius"]), int(g["K"])
+    idx, zbuf, dists = p3d.rasterize_points(pc, image_size=(H, W), radius=r, points_per_pixel=K)
+    assert (idx.cpu() == t("idx")).float().mean().item() > 0.999
+    assert torch.allclose(zbuf.cpu(), t("zbuf"), atol=1e-5) or (zbuf.cpu() - t("zbuf")).abs().gt(1e-5).float().mean() < 1e-3
+    feats = t("features").to(d).requires_grad_(True)
+    weights = 1 - dists.permute(0, 3, 1, 2) / (r * r)  # points/renderer.py:64-65
+    fn = p3d.alpha_composite if tag == "alpha" else p3d.norm_weighted_sum
+    img = fn(idx.long().permute(0, 3, 1, 2), weights, feats.permute(1, 0))
+    if tag == "alpha":  # compositor.py:66-110 (_add_background_color_to_images), plain torch glue
+        bg = torch.tensor([0.1, 0.2, 0.3, 1.0], device=d)
+        img = torch.where((idx[..., 0] < 0)[:, None], bg[None, :, None, None], img)
+    img = img.permute(0, 2, 3, 1)
+    ref = t(f"{tag}_image")
+    assert ((img.cpu() - ref).abs() > 1e-5).float().mean() < 2e-3, (img.cpu() - ref).abs().max()
+    img.backward(t(f"{tag}_grad_image").to(d))
+    rg = t(f"{tag}_grad_features")
+    assert torch.allclose(feats.grad.cpu(), rg, rtol=2e-3, atol=2e-4 * rg.abs().max().item())
