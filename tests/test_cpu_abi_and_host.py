@@ -178,3 +178,43 @@ def test_packed_containers_match_reference_accessors():
     assert m.mesh_to_faces_packed_first_idx().tolist() == [0, 2]
     assert m.num_faces_per_mesh().tolist() == [2, 1]
     assert m._F == 2
+
+
+def test_shading_host_logic_packs_broadcasts_and_refuses():
+    """pytorch3d_amd/shading.py host side (no GPU): the (N, 25) parameter block of p3d_phong_shade_*, light-kind
+    detection, (1,3)/(N,3) broadcasting, loud refusals."""
+    from collections import namedtuple
+
+    import pytorch3d_amd as p3d
+    import pytorch3d_amd.shading as sh
+
+    class Cam:
+        def get_camera_center(self):
+            return torch.tensor([[0.0, 0.0, -3.0]])
+
+    M = sh.Materials(torch.ones(1, 3), torch.full((1, 3), 0.5), torch.full((1, 3), 0.25), torch.tensor([64.0]))
+    point = sh.Lights(torch.tensor([[0.1, 0.2, 0.3]]), torch.rand(3, 3), torch.rand(1, 3), location=torch.rand(3, 3))
+    params, kind = sh.pack_shade_params(point, Cam(), M, 3, torch.device("cpu"))
+    assert params.shape == (3, sh.PARAM_FLOATS) and params.is_contiguous() and kind == sh.LIGHT_POINT
+    assert torch.equal(params[:, 0:3], torch.tensor([[0.1, 0.2, 0.3]]).expand(3, 3))
+    assert torch.equal(params[:, 3:6], point.diffuse_color) and torch.equal(params[:, 9:12], point.location)
+    assert torch.equal(params[:, 21], torch.full((3,), 64.0)) and torch.equal(params[:, 22:25], torch.tensor([[0.0, 0.0, -3.0]]).expand(3, 3))
+    direc = sh.Lights(torch.ones(1, 3), torch.ones(1, 3), torch.ones(1, 3), direction=torch.tensor([[0.0, 1.0, 0.0]]))
+    assert sh.pack_shade_params(direc, Cam(), M, 2, torch.device("cpu"))[1] == sh.LIGHT_DIRECTIONAL
+    amb = sh.Lights(torch.full((1, 3), 0.7), diffuse_color=torch.ones(1, 3))  # ambient-only: diffuse / specular ignored
+    pa, ka = sh.pack_shade_params(amb, Cam(), M, 2, torch.device("cpu"))
+    assert ka == sh.LIGHT_DIRECTIONAL and pa[:, 3:12].abs().max() == 0 and torch.all(pa[:, 0:3] == 0.7)
+    with pytest.raises(ValueError, match="must have shape"):
+        sh.pack_shade_params(point, Cam(), M, 2, torch.device("cpu"))  # (3,3) lights against a batch of 2
+    with pytest.raises(NotImplementedError, match="requires grad"):
+        sh.pack_shade_params(point._replace(location=torch.rand(3, 3, requires_grad=True)), Cam(), M, 3, torch.device("cpu"))
+    # no CPU emulation of the fused kernels
+    Frag = namedtuple("Frag", "pix_to_face bary_coords")
+    m = p3d.PackedMeshes([torch.rand(4, 3)], [torch.tensor([[0, 1, 2], [1, 2, 3]])])
+    frag = Frag(torch.zeros(1, 2, 2, 1, dtype=torch.int64), torch.rand(1, 2, 2, 1, 3))
+    with pytest.raises(RuntimeError, match="GPU path only"):
+        p3d.phong_shading(m, frag, direc, Cam(), M, torch.rand(1, 2, 2, 1, 3))
+    # the container's normals follow Meshes._compute_vertex_normals / mesh_face_areas_normals
+    assert torch.allclose(m.verts_normals_packed().norm(dim=1), torch.ones(4), atol=1e-6)
+    assert torch.allclose(m.faces_normals_packed().norm(dim=1), torch.ones(2), atol=1e-6)
+    assert m.verts_packed_to_mesh_idx().tolist() == [0, 0, 0, 0]
