@@ -253,7 +253,8 @@ int p3d_interp_face_attrs_backward_nhwk(const int64_t* pix_to_face, const float*
  *                       specular colour, shininess, camera centre -- already broadcast to the batch.
  *                       AmbientLights = directional with zero diffuse and specular colour.
  *   colors (N,H,W,K,3) fully written.  Backward: grad_bary (N,H,W,K,3) and grad_texels fully written,
- *   grad_face_attrs (F,3,D) zeroed and accumulated.  Lights, materials and the camera centre get no gradient. */
+ *   grad_face_attrs (F,3,D) zeroed and accumulated; grad_params (N, P3D_SHADE_PARAM_FLOATS), the gradient of the
+ *   lights / materials / camera centre, zeroed and accumulated when non-null (null: not computed). */
 #define P3D_SHADE_PARAM_FLOATS 25
 #define P3D_LIGHT_DIRECTIONAL 0
 #define P3D_LIGHT_POINT 1
@@ -263,7 +264,7 @@ int p3d_phong_shade_forward(const int64_t* pix_to_face, const float* bary_coords
 int p3d_phong_shade_backward(const float* grad_colors, const int64_t* pix_to_face, const float* bary_coords,
                              const float* face_attrs, int D, const float* texels, const float* params, int light_kind,
                              int N, int H, int W, int K, int64_t F, float* grad_bary_coords, float* grad_face_attrs,
-                             float* grad_texels, p3d_stream_t stream);
+                             float* grad_texels, float* grad_params, p3d_stream_t stream);
 
 /* ---- built-in per-kernel timing (HIP events on the launch stream) --------------------- */
 

@@ -270,7 +270,7 @@ def phong_shade(pix_to_face, bary, face_attrs, texels, params, point_light):
     return out
 
 
-def phong_shade_backward(grad_colors, pix_to_face, bary, face_attrs, texels, params, point_light):
+def phong_shade_backward(grad_colors, pix_to_face, bary, face_attrs, texels, params, point_light, with_params=False):
     g, p2f, b, fa, pr = _f32(grad_colors), _i64(pix_to_face), _f32(bary), _f32(face_attrs), _f32(params)
     N, H, W, K = p2f.shape
     F, _, D = fa.shape
@@ -278,7 +278,8 @@ def phong_shade_backward(grad_colors, pix_to_face, bary, face_attrs, texels, par
     gb = torch.zeros((N, H, W, K, 3), dtype=torch.float32)
     gf = torch.zeros((F, 3, D), dtype=torch.float32)
     gt = torch.zeros((N, H, W, K, 3), dtype=torch.float32) if D == 6 else None
+    gp = torch.zeros((N, 25), dtype=torch.float32)
     lib().orc_phong_backward(_p(g), _p(p2f), _p(b), _p(fa), D, _p(tx) if tx is not None else None, _p(pr),
                              int(point_light), N, ctypes.c_int64(H * W * K), ctypes.c_int64(F), _p(gb), _p(gf),
-                             _p(gt) if gt is not None else None)
-    return gb, gf, gt
+                             _p(gt) if gt is not None else None, _p(gp))
+    return (gb, gf, gt, gp) if with_params else (gb, gf, gt)

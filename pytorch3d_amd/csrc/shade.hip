@@ -121,6 +121,7 @@ struct ShadeArgs {
   float* gbary;          // (N,H,W,K,3)
   float* gattrs;         // (F, 3, D)
   float* gtexels;        // (N,H,W,K,3) when D == 6
+  float* gparams;        // (N, 25) or null: gradient of the per-image parameters (zeroed by the launcher, accumulated)
   int N, H, W, K, RY, RX, AW;
   int64_t HWK;
   int debug;  // P3D_DEBUG_SHADE ablation bits (profiles/shade_bench.py): 1 no table accumulation, 2 no lighting math, 4 no gbary / gtexels stores
@@ -183,7 +184,9 @@ struct ShadeTable {
   using T = WaveTable<NV, kSlots, false, true>;
 };
 
-template <int D, bool POINT>
+// PG: also accumulate the gradient of the per-image parameters (lights, materials, camera centre): 25 per-lane sums over
+// the wave's samples, one butterfly reduction and 25 global atomics per wave at the end.
+template <int D, bool POINT, bool PG>
 __global__ __launch_bounds__(256) void phong_bwd_kernel(ShadeArgs a) {
 #pragma clang fp contract(fast)  // gradient-only arithmetic (tolerance-gated): let mul+add fuse into FMA
   using Tab = typename ShadeTable<D>::T;
@@ -212,6 +215,10 @@ __global__ __launch_bounds__(256) void phong_bwd_kernel(ShadeArgs a) {
   }
   Tab tab;
   tab.init(s_table[w], lane);
+  float pg[PG ? P3D_SHADE_PARAM_FLOATS : 1];
+#pragma unroll
+  for (int j = 0; j < (PG ? P3D_SHADE_PARAM_FLOATS : 1); ++j) pg[j] = 0.0f;
+  const float pw0 = c.shin == 0.0f ? 1.0f : 0.0f;  // pow(0, shininess): the specular term of samples without a highlight
   // Lanes take 64 consecutive samples of a row ((pixel, k) pairs in memory order): every load and store of the
   // per-sample arrays is then one contiguous 768-byte piece per wave instruction, for any K.  (A lane per pixel
   // stepping through k writes 12 bytes at a stride of 12*K: measured 2.9 ms of 5.5 on partial-line stores.)
@@ -236,6 +243,17 @@ __global__ __launch_bounds__(256) void phong_bwd_kernel(ShadeArgs a) {
         // background sample with caller-supplied texels: colour = ambient * texel (+ a constant)
 #pragma unroll
         for (int j = 0; j < 3; ++j) a.gtexels[p * 3 + j] = amb[j] * go[j];
+      }
+      if (PG && ok && f < 0) {
+        // colour_j = ma_j * la_j * tex_j + ms_j * ls_j * pow(0, shininess)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const float tg = D == 6 ? a.texels[p * 3 + j] * go[j] : 0.0f;
+          pg[j] += c.ma[j] * tg;
+          pg[12 + j] += c.la[j] * tg;
+          pg[6 + j] += c.ms[j] * pw0 * go[j];
+          pg[18 + j] += c.ls[j] * pw0 * go[j];
+        }
       }
       if (f >= 0) {
         const float b[3] = {a.bary[p * 3], a.bary[p * 3 + 1], a.bary[p * 3 + 2]};
@@ -268,6 +286,21 @@ __global__ __launch_bounds__(256) void phong_bwd_kernel(ShadeArgs a) {
         const float em1 = c.shin - 1.0f;
         const float apow = em1 == 0.0f ? 1.0f : __builtin_amdgcn_exp2f(em1 * __builtin_amdgcn_logf(s.alpha));
         const float dalpha = c.shin == 0.0f ? 0.0f : c.shin * apow * dpw;
+        if constexpr (PG) {
+          const float pw = s.alpha > 0.0f ? apow * s.alpha : pw0;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const float tg = tex[j] * go[j];
+            pg[j] += c.ma[j] * tg;                 // light ambient
+            pg[12 + j] += c.la[j] * tg;            // material ambient
+            pg[3 + j] += c.md[j] * s.angle * tg;   // light diffuse
+            pg[15 + j] += c.ld[j] * s.angle * tg;  // material diffuse
+            pg[6 + j] += c.ms[j] * pw * go[j];     // light specular
+            pg[18 + j] += c.ls[j] * pw * go[j];    // material specular
+          }
+          // d pow(alpha, s) / d s = pow * ln(alpha), 0 at alpha = 0 (torch's pow backward for s >= 0)
+          if (s.alpha > 0.0f) pg[21] += dpw * pw * (__builtin_amdgcn_logf(s.alpha) * 0.6931471805599453f);
+        }
         const float dd = (s.cosv > 0.0f && s.d > 0.0f) ? dalpha : 0.0f;
         float dvh[3], dR[3], dlh[3], dnh[3];
 #pragma unroll
@@ -287,6 +320,13 @@ __global__ __launch_bounds__(256) void phong_bwd_kernel(ShadeArgs a) {
         normalize3_bwd(s.vh, s.vlen, dvh, dV);
 #pragma unroll
         for (int j = 0; j < 3; ++j) dP[j] = (POINT ? -dL[j] : 0.0f) - dV[j];
+        if constexpr (PG) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            pg[9 + j] += dL[j];   // light location / direction
+            pg[22 + j] += dV[j];  // camera centre
+          }
+        }
         // interpolation backward (interp_face_attrs.cu:100-118)
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -318,6 +358,15 @@ __global__ __launch_bounds__(256) void phong_bwd_kernel(ShadeArgs a) {
     }
   }
   if (tab.used > 0) tab.flush(a.gattrs, lane);
+  if constexpr (PG) {
+#pragma unroll
+    for (int j = 0; j < P3D_SHADE_PARAM_FLOATS; ++j) {
+      float v = pg[j];
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+      if (lane == 0) unsafeAtomicAdd(a.gparams + (int64_t)n * P3D_SHADE_PARAM_FLOATS + j, v);
+    }
+  }
 }
 
 int check_shape(int N, int H, int W, int K, int64_t F, int D, int light_kind) {
@@ -376,7 +425,8 @@ P3D_API int p3d_phong_shade_forward(const int64_t* pix_to_face, const float* bar
 P3D_API int p3d_phong_shade_backward(const float* grad_colors, const int64_t* pix_to_face, const float* bary,
                                      const float* face_attrs, int D, const float* texels, const float* params,
                                      int light_kind, int N, int H, int W, int K, int64_t F, float* grad_bary,
-                                     float* grad_face_attrs, float* grad_texels, p3d_stream_t stream) {
+                                     float* grad_face_attrs, float* grad_texels, float* grad_params,
+                                     p3d_stream_t stream) {
   const int rc = check_shape(N, H, W, K, F, D, light_kind);
   if (rc != P3D_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
@@ -384,6 +434,9 @@ P3D_API int p3d_phong_shade_backward(const float* grad_colors, const int64_t* pi
     if (!grad_face_attrs) return P3D_ERR_INVALID_ARG;
     if (hipMemsetAsync(grad_face_attrs, 0, (size_t)F * 3 * D * sizeof(float), s) != hipSuccess) return P3D_ERR_LAUNCH;
   }
+  if (grad_params && N > 0 &&
+      hipMemsetAsync(grad_params, 0, (size_t)N * P3D_SHADE_PARAM_FLOATS * sizeof(float), s) != hipSuccess)
+    return P3D_ERR_LAUNCH;
   const int64_t HWK = (int64_t)H * W * K;
   if ((int64_t)N * HWK == 0) return P3D_OK;
   if (!grad_colors || !pix_to_face || !bary || !params || !grad_bary || (F > 0 && !face_attrs)) return P3D_ERR_INVALID_ARG;
@@ -398,6 +451,7 @@ P3D_API int p3d_phong_shade_backward(const float* grad_colors, const int64_t* pi
   a.gbary = grad_bary;
   a.gattrs = grad_face_attrs;
   a.gtexels = grad_texels;
+  a.gparams = grad_params;
   a.N = N;
   a.H = H;
   a.W = W;
@@ -414,16 +468,25 @@ P3D_API int p3d_phong_shade_backward(const float* grad_colors, const int64_t* pi
   if (blocks > 0x7fffffff) return P3D_ERR_INVALID_ARG;
   LaunchScope ls("phong_bwd", s);
   const bool point = light_kind == P3D_LIGHT_POINT;
-  if (D == 6) {
-    if (point)
-      phong_bwd_kernel<6, true><<<(unsigned)blocks, 256, 0, s>>>(a);
-    else
-      phong_bwd_kernel<6, false><<<(unsigned)blocks, 256, 0, s>>>(a);
-  } else {
-    if (point)
-      phong_bwd_kernel<9, true><<<(unsigned)blocks, 256, 0, s>>>(a);
-    else
-      phong_bwd_kernel<9, false><<<(unsigned)blocks, 256, 0, s>>>(a);
-  }
+  const unsigned grid = (unsigned)blocks;
+#define P3D_LAUNCH_PHONG_BWD(DD)                                                 \
+  do {                                                                           \
+    if (grad_params) {                                                           \
+      if (point)                                                                 \
+        phong_bwd_kernel<DD, true, true><<<grid, 256, 0, s>>>(a);                \
+      else                                                                       \
+        phong_bwd_kernel<DD, false, true><<<grid, 256, 0, s>>>(a);               \
+    } else {                                                                     \
+      if (point)                                                                 \
+        phong_bwd_kernel<DD, true, false><<<grid, 256, 0, s>>>(a);               \
+      else                                                                       \
+        phong_bwd_kernel<DD, false, false><<<grid, 256, 0, s>>>(a);              \
+    }                                                                            \
+  } while (0)
+  if (D == 6)
+    P3D_LAUNCH_PHONG_BWD(6);
+  else
+    P3D_LAUNCH_PHONG_BWD(9);
+#undef P3D_LAUNCH_PHONG_BWD
   return launch_status();
 }

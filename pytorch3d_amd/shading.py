@@ -13,8 +13,9 @@ interpolates the shaded colours with the fused interpolate_face_attributes kerne
 `lights`, `cameras`, `materials` are duck-typed: any object with the reference's attribute names works
 (`PointLights.location`, `DirectionalLights.direction`, `*.ambient_color / diffuse_color / specular_color`,
 `Materials.shininess`, `cameras.get_camera_center()`), each (1, 3) or (N, 3).  Gradients flow to the mesh
-vertices, vertex normals, texels / vertex colours and barycentric coordinates; lights, materials and the camera
-centre are constants of the fused kernels (a tensor among them that requires grad raises).
+vertices, vertex normals, texels / vertex colours and barycentric coordinates, and -- when one of them requires grad --
+to the lights, materials and camera centre (the backward kernel then also reduces the gradient of the (N, 25)
+parameter block, which torch's autograd distributes over the tensors it was packed from).
 """
 from typing import NamedTuple, Optional
 
@@ -52,10 +53,7 @@ class Materials(NamedTuple):
 
 def _rows(v, N, C, device, name):
     t = v if torch.is_tensor(v) else torch.tensor(v, dtype=torch.float32)
-    if t.requires_grad:
-        raise NotImplementedError(f"phong_shading: {name} requires grad; the fused kernels treat lights, materials and "
-                                  "the camera centre as constants")
-    t = t.detach().to(device=device, dtype=torch.float32)
+    t = t.to(device=device, dtype=torch.float32)  # differentiable: the kernels return the gradient of the packed block
     if C == 1:
         t = t.reshape(-1, 1)
     if t.ndim == 1:
@@ -89,7 +87,7 @@ def pack_shade_params(lights, cameras, materials, N, device):
         _rows(materials.shininess, N, 1, device, "materials.shininess"),
         _rows(cameras.get_camera_center(), N, 3, device, "cameras.get_camera_center()"),
     ]
-    return torch.cat(cols, 1).contiguous(), kind
+    return torch.cat(cols, 1), kind
 
 
 class _PhongShade(torch.autograd.Function):
@@ -99,6 +97,7 @@ class _PhongShade(torch.autograd.Function):
         dev = bary.device
         p2f, b, fa = pix_to_face.contiguous(), bary.contiguous(), face_attrs.contiguous()
         tx = texels.contiguous() if texels is not None else None
+        params = params.contiguous()
         F, _, D = fa.shape
         lib = _lib.load()
         with torch.cuda.device(dev):
@@ -124,11 +123,12 @@ class _PhongShade(torch.autograd.Function):
             gb = torch.empty((N, H, W, K, 3), dtype=torch.float32, device=dev)
             gfa = torch.empty((F, 3, D), dtype=torch.float32, device=dev)
             gt = torch.empty((N, H, W, K, 3), dtype=torch.float32, device=dev) if ctx.has_texels else None
+            gp = torch.empty((N, PARAM_FLOATS), dtype=torch.float32, device=dev) if ctx.needs_input_grad[4] else None
             rc = lib.p3d_phong_shade_backward(_C._ptr(g), _C._ptr(p2f), _C._ptr(b), _C._ptr(fa), D,
                                               _C._ptr(tx if ctx.has_texels else None), _C._ptr(params), ctx.kind, N, H, W,
-                                              K, F, _C._ptr(gb), _C._ptr(gfa), _C._ptr(gt), _C._stream(dev))
+                                              K, F, _C._ptr(gb), _C._ptr(gfa), _C._ptr(gt), _C._ptr(gp), _C._stream(dev))
             _lib.check(rc, "phong_shading_backward")
-        return None, gb, gfa, gt, None, None
+        return None, gb, gfa, gt, gp, None
 
 
 def _check(fragments, *named):

@@ -142,6 +142,22 @@ def main():
                     f"{tag}_gouraud_grad_verts": torch.cat([x.grad for x in vl]),
                     f"{tag}_gouraud_grad_tex": torch.cat([x.grad for x in cl]), f"{tag}_gouraud_grad_bary": b.grad})
     out["num_verts_per_mesh"] = torch.tensor(nv)
+    # gradients wrt the lights, the materials and the camera centre (phong_shading, texels given)
+    for tag, cls, vec_name in (("point", PointLights, "location"), ("dir", DirectionalLights, "direction")):
+        L0, M0 = lights[tag], mats[tag]
+        leaf = lambda t: t.detach().clone().requires_grad_(True)
+        lt = {n_: leaf(getattr(L0, n_)) for n_ in ("ambient_color", "diffuse_color", "specular_color", vec_name)}
+        mt = {n_: leaf(getattr(M0, n_)) for n_ in ("ambient_color", "diffuse_color", "specular_color", "shininess")}
+        camt = leaf(cam)
+        L = cls(**lt)
+        M = Materials(**mt)
+        col = phong_shading(MeshStub(verts, faces, normals), Frag(p2f, bary), L, CamStub(camt), M, texels0)
+        g = torch.randn(col.shape, generator=gen)
+        (col * g).sum().backward()
+        pre = f"{tag}_pg_"
+        out.update({pre + "colors": col, pre + "grad_colors": g, pre + "grad_camera": camt.grad})
+        out.update({pre + "grad_light_" + k: v.grad for k, v in lt.items()})
+        out.update({pre + "grad_mat_" + k: v.grad for k, v in mt.items()})
     mg.save("shading_ref", **out)
     print({k: tuple(v.shape) for k, v in out.items() if k.startswith("point_texels")})
     print("coverage", float((p2f >= 0).float().mean()))

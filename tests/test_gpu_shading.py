@@ -84,6 +84,34 @@ def test_phong_shading_mirror_vs_reference_fixture(tag, kind):
 
 
 @pytest.mark.parametrize("tag", ["point", "dir"])
+def test_light_material_camera_gradients_vs_reference_autograd(tag):
+    """Lights, materials and the camera centre that require grad: the backward kernel reduces the gradient of the packed
+    (N,25) block, torch's autograd distributes it over the tensors it was packed from."""
+    import pytorch3d_amd as p3d
+    import pytorch3d_amd.shading as sh
+
+    g = U.shading_golden()
+    d = torch.device("cuda:0")
+    vec = "location" if tag == "point" else "direction"
+    leaf = lambda k: g[k].to(d).requires_grad_(True)
+    lt = {n: leaf(f"{tag}_light_{n}") for n in ("ambient_color", "diffuse_color", "specular_color", vec)}
+    mt = {n: leaf(f"{tag}_mat_{n}") for n in ("ambient_color", "diffuse_color", "specular_color", "shininess")}
+    camt = leaf("camera_center")
+    L = sh.Lights(lt["ambient_color"], lt["diffuse_color"], lt["specular_color"], **{vec: lt[vec]})
+    M = sh.Materials(mt["ambient_color"], mt["diffuse_color"], mt["specular_color"], mt["shininess"])
+    mesh = MeshView(g["verts"].to(d), g["faces"].to(d), g["normals"].to(d))
+    col = p3d.phong_shading(mesh, Frag(g["pix_to_face"].to(d), g["bary"].to(d)), L, Cam(camt), M, g["texels"].to(d))
+    pre = f"{tag}_pg_"
+    assert torch.allclose(col.cpu(), g[pre + "colors"], atol=1e-5, rtol=1e-5)
+    col.backward(g[pre + "grad_colors"].to(d))
+    checks = [(camt.grad, "grad_camera")] + [(v.grad, "grad_light_" + k) for k, v in lt.items()] + \
+             [(v.grad, "grad_mat_" + k) for k, v in mt.items()]
+    for got, name in checks:
+        ref = g[pre + name]
+        assert _close(got.cpu().reshape(ref.shape), ref), (name, got, ref)
+
+
+@pytest.mark.parametrize("tag", ["point", "dir"])
 def test_flat_and_gouraud_mirrors_vs_reference_fixture(tag):
     import pytorch3d_amd as p3d
 
@@ -159,11 +187,16 @@ def test_phong_kernels_vs_oracle(K, size, point, D):
     assert torch.allclose(col.cpu(), ref, atol=1e-5, rtol=1e-5), (col.cpu() - ref).abs().max()
     go = torch.randn(N, H, W, K, 3, generator=gen)
     col.backward(go.to(d))
-    rb, rf, rt = orc.phong_shade_backward(go, p2f, bary, fa, texels, params, point)
+    rb, rf, rt, rp = orc.phong_shade_backward(go, p2f, bary, fa, texels, params, point, with_params=True)
     assert _close(b_g.grad.cpu(), rb)
     assert _close(fa_g.grad.cpu(), rf)
     if D == 6:
         assert _close(t_g.grad.cpu(), rt)
+    # the same backward with the parameter gradient requested (sums over all samples of an image: scaled tolerance)
+    p_g = params.to(d).requires_grad_(True)
+    _PhongShade.apply(p2f.to(d), bary.to(d), fa.to(d), texels.to(d) if texels is not None else None, p_g,
+                      int(point)).backward(go.to(d))
+    assert torch.allclose(p_g.grad.cpu(), rp, rtol=2e-3, atol=2e-4 * rp.abs().max().item()), (p_g.grad.cpu() - rp).abs().max()
 
 
 def test_phong_background_empty_and_errors():
@@ -188,9 +221,6 @@ def test_phong_background_empty_and_errors():
     assert (col == 0).all()
     e = p3d.phong_shading(mesh, Frag(p2f[:0], bary[:0]), L, cam, M, tex[:0])
     assert e.shape == (0, 5, 7, 2, 3)
-    with pytest.raises(NotImplementedError):
-        Lg = L._replace(location=torch.tensor([[0.0, 1.0, 0.0]], requires_grad=True))
-        p3d.phong_shading(mesh, Frag(p2f, bary), Lg, cam, M, tex)
     with pytest.raises(ValueError):
         p3d.phong_shading(mesh, Frag(p2f, bary), L._replace(ambient_color=torch.ones(3, 3)), cam, M, tex)
     with pytest.raises(RuntimeError):
