@@ -206,8 +206,11 @@ def test_shading_host_logic_packs_broadcasts_and_refuses():
     assert ka == sh.LIGHT_DIRECTIONAL and pa[:, 3:12].abs().max() == 0 and torch.all(pa[:, 0:3] == 0.7)
     with pytest.raises(ValueError, match="must have shape"):
         sh.pack_shade_params(point, Cam(), M, 2, torch.device("cpu"))  # (3,3) lights against a batch of 2
-    with pytest.raises(NotImplementedError, match="requires grad"):
-        sh.pack_shade_params(point._replace(location=torch.rand(3, 3, requires_grad=True)), Cam(), M, 3, torch.device("cpu"))
+    # the packing is differentiable: a light / material / camera tensor that requires grad gets its gradient through it
+    loc = torch.rand(3, 3, requires_grad=True)
+    pg, _ = sh.pack_shade_params(point._replace(location=loc), Cam(), M, 3, torch.device("cpu"))
+    pg[:, 9:12].sum().backward()
+    assert torch.equal(loc.grad, torch.ones(3, 3))
     # no CPU emulation of the fused kernels
     Frag = namedtuple("Frag", "pix_to_face bary_coords")
     m = p3d.PackedMeshes([torch.rand(4, 3)], [torch.tensor([[0, 1, 2], [1, 2, 3]])])
