@@ -139,6 +139,7 @@ __global__ __launch_bounds__(256) void phong_fwd_kernel(ShadeArgs a) {
     kd[j] = c.md[j] * c.ld[j];
     ks[j] = c.ms[j] * c.ls[j];
   }
+  const float pw0 = powf(0.0f, c.shin);
   const int64_t img = (int64_t)n * a.HWK;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.HWK; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t p = img + i;
@@ -159,10 +160,16 @@ __global__ __launch_bounds__(256) void phong_fwd_kernel(ShadeArgs a) {
 #pragma unroll
       for (int j = 0; j < 3; ++j) tex[j] = a.texels[p * 3 + j];
     }
-    // background samples interpolate to P = N = 0 in the reference and go through the same arithmetic
-    const Lit s = light_sample<POINT>(c, P, Nn);
+    // Background samples interpolate to P = N = 0 in the reference and go through the same arithmetic; its outcome is
+    // known: normalize(0) = 0, so the cosine is 0, there is no diffuse term and alpha = 0, pow(0, shininess) = pw0.
+    float angle = 0.0f, pw = pw0;
+    if (f >= 0) {
+      const Lit s = light_sample<POINT>(c, P, Nn);
+      angle = s.angle;
+      pw = s.pw;
+    }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) a.colors[p * 3 + j] = (amb[j] + kd[j] * s.angle) * tex[j] + ks[j] * s.pw;  // shading.py:96
+    for (int j = 0; j < 3; ++j) a.colors[p * 3 + j] = (amb[j] + kd[j] * angle) * tex[j] + ks[j] * pw;  // shading.py:96
   }
 }
 
