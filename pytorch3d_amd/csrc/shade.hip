@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void phong_bwd_kernel(ShadeArgs a) {
       float g[NV];
       float gb[3] = {0.f, 0.f, 0.f};
       float go[3] = {0.f, 0.f, 0.f};
-      if (ok) {
+      if (ok && (D == 6 || PG || f >= 0)) {  // with vertex colours a background sample's colour gradient goes nowhere
 #pragma unroll
         for (int j = 0; j < 3; ++j) go[j] = a.gcolors[p * 3 + j];
       }
