@@ -479,9 +479,9 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
     ~Stats() {
       if (!dev) return;
       unsigned long long h[8];
-      hipStreamSynchronize(s);
-      hipMemcpy(h, dev, sizeof(h), hipMemcpyDeviceToHost);
-      hipFree(dev);
+      (void)hipStreamSynchronize(s);
+      (void)hipMemcpy(h, dev, sizeof(h), hipMemcpyDeviceToHost);
+      (void)hipFree(dev);
       fprintf(stderr,
               "[p3d fwd stats] waves %llu | staged faces/wave %.1f | groups/wave %.2f | candidate iters/wave %.1f | body "
               "iters/wave %.1f | lanes per body %.1f | hits/lane %.2f | inserts/lane %.2f\n",
@@ -492,8 +492,9 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
   stats.s = stream;
   a.counters = nullptr;
   if (a.debug & 64) {
-    hipMalloc(&stats.dev, 8 * sizeof(unsigned long long));
-    hipMemsetAsync(stats.dev, 0, 8 * sizeof(unsigned long long), stream);
+    // ablation only (P3D_DEBUG_FWD bit 64 in a -DP3D_FWD_STATS build): the one place that allocates and synchronises
+    if (hipMalloc(&stats.dev, 8 * sizeof(unsigned long long)) != hipSuccess) stats.dev = nullptr;
+    if (stats.dev) (void)hipMemsetAsync(stats.dev, 0, 8 * sizeof(unsigned long long), stream);
     a.counters = stats.dev;
   }
   LaunchScope ls(name, stream);
