@@ -266,6 +266,24 @@ int p3d_phong_shade_backward(const float* grad_colors, const int64_t* pix_to_fac
                              int N, int H, int W, int K, int64_t F, float* grad_bary_coords, float* grad_face_attrs,
                              float* grad_texels, float* grad_params, p3d_stream_t stream);
 
+/* replaces TexturesUV.sample_textures (pytorch3d/renderer/mesh/textures.py:1190-1268, one map per mesh):
+ * interpolate_face_attributes of the per-face uvs + torch.lerp to grid coordinates + F.grid_sample on K expanded
+ * NCHW copies of the maps + permutes, and their autograd graph, with one kernel each way reading the maps in their
+ * own (N, Hm, Wm, C) layout.  face_uvs (F,3,2) = verts_uvs[faces_uvs]; texels (N,H,W,K,C) fully written.
+ * Backward: grad_bary (N,H,W,K,3) fully written; grad_face_uvs (F,3,2) and grad_maps (N,Hm,Wm,C) zeroed and
+ * accumulated.  padding "reflection" is not provided. */
+#define P3D_PAD_ZEROS 0
+#define P3D_PAD_BORDER 1
+#define P3D_SAMPLE_BILINEAR 0
+#define P3D_SAMPLE_NEAREST 1
+int p3d_sample_uv_forward(const int64_t* pix_to_face, const float* bary_coords, const float* face_uvs, const float* maps,
+                          int N, int H, int W, int K, int64_t F, int Hm, int Wm, int C, int align_corners,
+                          int padding_mode, int sampling_mode, float* texels, p3d_stream_t stream);
+int p3d_sample_uv_backward(const float* grad_texels, const int64_t* pix_to_face, const float* bary_coords,
+                           const float* face_uvs, const float* maps, int N, int H, int W, int K, int64_t F, int Hm, int Wm,
+                           int C, int align_corners, int padding_mode, int sampling_mode, float* grad_bary_coords,
+                           float* grad_face_uvs, float* grad_maps, p3d_stream_t stream);
+
 /* ---- built-in per-kernel timing (HIP events on the launch stream) --------------------- */
 
 /* enable != 0: every kernel launch is bracketed by hipEventRecord on its stream. */

@@ -283,3 +283,32 @@ def phong_shade_backward(grad_colors, pix_to_face, bary, face_attrs, texels, par
                              int(point_light), N, ctypes.c_int64(H * W * K), ctypes.c_int64(F), _p(gb), _p(gf),
                              _p(gt) if gt is not None else None, _p(gp))
     return (gb, gf, gt, gp) if with_params else (gb, gf, gt)
+
+
+_PAD = {"zeros": 0, "border": 1}
+_SMODE = {"bilinear": 0, "nearest": 1}
+
+
+def sample_uv(pix_to_face, bary, face_uvs, maps, align_corners=True, padding_mode="border", sampling_mode="bilinear"):
+    """TexturesUV.sample_textures restated (oracle/p3d_oracle.c: orc_sample_uv_forward)."""
+    p2f, b, fu, mp = _i64(pix_to_face), _f32(bary), _f32(face_uvs), _f32(maps)
+    N, H, W, K = p2f.shape
+    _, Hm, Wm, C = mp.shape
+    out = torch.zeros((N, H, W, K, C), dtype=torch.float32)
+    lib().orc_sample_uv_forward(_p(p2f), _p(b), _p(fu), _p(mp), N, ctypes.c_int64(H * W * K), Hm, Wm, C, int(align_corners),
+                                _PAD[padding_mode], _SMODE[sampling_mode], _p(out))
+    return out
+
+
+def sample_uv_backward(grad_texels, pix_to_face, bary, face_uvs, maps, align_corners=True, padding_mode="border",
+                       sampling_mode="bilinear"):
+    g, p2f, b, fu, mp = _f32(grad_texels), _i64(pix_to_face), _f32(bary), _f32(face_uvs), _f32(maps)
+    N, H, W, K = p2f.shape
+    _, Hm, Wm, C = mp.shape
+    F = fu.shape[0]
+    gb = torch.zeros((N, H, W, K, 3), dtype=torch.float32)
+    gfu = torch.zeros((F, 3, 2), dtype=torch.float32)
+    gm = torch.zeros_like(mp)
+    lib().orc_sample_uv_backward(_p(g), _p(p2f), _p(b), _p(fu), _p(mp), N, ctypes.c_int64(H * W * K), ctypes.c_int64(F), Hm,
+                                 Wm, C, int(align_corners), _PAD[padding_mode], _SMODE[sampling_mode], _p(gb), _p(gfu), _p(gm))
+    return gb, gfu, gm

@@ -18,5 +18,6 @@ from .rasterize_meshes import rasterize_meshes  # noqa: F401
 from .rasterize_points import rasterize_points  # noqa: F401
 from .shading import flat_shading, gouraud_shading, phong_shading, phong_shading_vertex_colors  # noqa: F401
 from .structures import PackedMeshes, PackedPointclouds  # noqa: F401
+from .textures import sample_textures_uv  # noqa: F401
 
 __version__ = "0.1.0"

@@ -75,6 +75,10 @@ _SIGNATURES = {
                                         c_ptr, c_ptr]),
     "p3d_phong_shade_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int,
                                          c_int, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "p3d_sample_uv_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_i64, c_int, c_int, c_int,
+                                      c_int, c_int, c_int, c_ptr, c_ptr]),
+    "p3d_sample_uv_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_i64, c_int, c_int,
+                                       c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
     "p3d_profile_enable": (None, [c_int]),
     "p3d_profile_collect": (None, []),
     "p3d_profile_num_entries": (c_int, []),

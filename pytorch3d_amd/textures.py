@@ -1,0 +1,72 @@
+"""Host-side mirror of TexturesUV.sample_textures (pytorch3d/renderer/mesh/textures.py:1190-1268)
+over the C ABI: uv interpolation + grid_sample fused into one kernel each way (include/p3d_amd.h:
+p3d_sample_uv_forward / _backward).  One texture map per mesh (`maps_ids` is not provided); padding "zeros" or
+"border", sampling "bilinear" or "nearest", as F.grid_sample defines them.  Gradients flow to the maps, the per-face uvs
+and the barycentric coordinates.
+"""
+import torch
+
+from . import _C, _lib
+
+_PAD = {"zeros": 0, "border": 1}
+_MODE = {"bilinear": 0, "nearest": 1}
+
+
+class _SampleUV(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pix_to_face, bary, face_uvs, maps, align, pad, mode):
+        N, H, W, K = pix_to_face.shape
+        dev = bary.device
+        p2f, b, fu, mp = pix_to_face.contiguous(), bary.contiguous(), face_uvs.contiguous(), maps.contiguous()
+        Nm, Hm, Wm, C = mp.shape
+        F = fu.shape[0]
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            out = torch.empty((N, H, W, K, C), dtype=torch.float32, device=dev)
+            if out.numel():
+                rc = lib.p3d_sample_uv_forward(_C._ptr(p2f), _C._ptr(b), _C._ptr(fu), _C._ptr(mp), N, H, W, K, F, Hm, Wm, C,
+                                               align, pad, mode, _C._ptr(out), _C._stream(dev))
+                _lib.check(rc, "sample_textures")
+        ctx.save_for_backward(p2f, b, fu, mp)
+        ctx.cfg = (align, pad, mode)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_texels):
+        p2f, b, fu, mp = ctx.saved_tensors
+        align, pad, mode = ctx.cfg
+        N, H, W, K = p2f.shape
+        Nm, Hm, Wm, C = mp.shape
+        F = fu.shape[0]
+        dev = b.device
+        g = grad_texels.contiguous()
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            gb = torch.empty((N, H, W, K, 3), dtype=torch.float32, device=dev)
+            gfu = torch.empty((F, 3, 2), dtype=torch.float32, device=dev)
+            gm = torch.empty((Nm, Hm, Wm, C), dtype=torch.float32, device=dev)
+            rc = lib.p3d_sample_uv_backward(_C._ptr(g), _C._ptr(p2f), _C._ptr(b), _C._ptr(fu), _C._ptr(mp), N, H, W, K, F, Hm,
+                                            Wm, C, align, pad, mode, _C._ptr(gb), _C._ptr(gfu), _C._ptr(gm), _C._stream(dev))
+            _lib.check(rc, "sample_textures_backward")
+        return None, gb, gfu, gm, None, None, None
+
+
+def sample_textures_uv(fragments, faces_verts_uvs, maps, align_corners: bool = True, padding_mode: str = "border",
+                       sampling_mode: str = "bilinear") -> torch.Tensor:
+    """TexturesUV.sample_textures(fragments) for faces_verts_uvs = cat(verts_uvs_list[i][faces_uvs_list[i]]) (F,3,2) and
+    maps = maps_padded() (N,Hm,Wm,C) -> texels (N,H,W,K,C).  Defaults as TexturesUV.__init__ (textures.py:716-718)."""
+    if padding_mode not in _PAD:
+        raise NotImplementedError(f"sample_textures_uv: padding_mode {padding_mode!r} (only 'zeros' and 'border')")
+    if sampling_mode not in _MODE:
+        raise ValueError(f"sample_textures_uv: sampling_mode {sampling_mode!r}")
+    for name, t in (("pix_to_face", fragments.pix_to_face), ("bary_coords", fragments.bary_coords),
+                    ("faces_verts_uvs", faces_verts_uvs), ("maps", maps)):
+        _C._need_gpu(t, name)
+    if faces_verts_uvs.dim() != 3 or faces_verts_uvs.shape[1:] != (3, 2):
+        raise ValueError("faces_verts_uvs must have shape (F, 3, 2)")
+    if maps.dim() != 4 or maps.shape[0] != fragments.pix_to_face.shape[0]:
+        raise ValueError("maps must have shape (N, H, W, C) with one map per batch element")
+    if faces_verts_uvs.dtype != torch.float32 or maps.dtype != torch.float32:
+        raise RuntimeError("sample_textures_uv: faces_verts_uvs and maps must be float32")
+    return _SampleUV.apply(fragments.pix_to_face, fragments.bary_coords, faces_verts_uvs, maps, int(bool(align_corners)),
+                           _PAD[padding_mode], _MODE[sampling_mode])
