@@ -29,7 +29,11 @@ def main():
                                            perspective_correct=True, clip_barycentric_coords=True)
     gen = torch.Generator().manual_seed(0)
     F = m.faces_packed().shape[0]
-    fu = torch.rand(F, 3, 2, generator=gen).to(d).requires_grad_(True)
+    if os.environ.get("TEXUV_RANDOM"):  # a random uv per face corner: no texel locality at all (worst case for the map atomics)
+        fu = torch.rand(F, 3, 2, generator=gen).to(d).requires_grad_(True)
+    else:  # a planar chart: uv = the vertex's NDC xy mapped to [0, 1] -- neighbouring pixels read neighbouring texels
+        uvv = (m.verts_packed()[:, :2] * 0.45 + 0.5).clamp(0, 1)
+        fu = uvv[m.faces_packed()].contiguous().requires_grad_(True)
     maps = torch.rand(B, 1024, 1024, 3, generator=gen).to(d).requires_grad_(True)
     b = bary.detach().clone().requires_grad_(True)
     g = torch.randn(B, 512, 512, 8, 3, generator=gen).to(d)
