@@ -128,11 +128,15 @@ __global__ __launch_bounds__(256) void sample_uv_fwd_kernel(TexArgs a) {
   }
 }
 
-using UvTable = WaveTable<6, 256>;  // 4 waves x 256 x 40 B = 40 KB
+// Per wave: 128 slots for the per-face uv partials (6 values, 40 B) + 320 slots for the map gradient keyed by texel (up to
+// 4 channels, 24 B): 12.5 KB -> 50 KB per workgroup, three workgroups per CU.
+using UvTable = WaveTable<6, 128>;
+using TexelTable = WaveTable<4, 320, kChunk>;
 
 template <bool NEAREST>
 __global__ __launch_bounds__(256) void sample_uv_bwd_kernel(TexArgs a, int64_t span) {
   __shared__ __align__(16) int s_table[4][UvTable::kLdsInts];
+  __shared__ __align__(16) int s_texels[4][TexelTable::kLdsInts];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int n = blockIdx.y;
   const int C = a.C, Hm = a.Hm, Wm = a.Wm;
@@ -145,6 +149,16 @@ __global__ __launch_bounds__(256) void sample_uv_bwd_kernel(TexArgs a, int64_t s
   const int64_t img = (int64_t)n * a.HWK;
   UvTable tab;
   tab.init(s_table[w], lane);
+  // Map gradient of the samples with a face: neighbouring pixels read overlapping 2x2 texel footprints, so lanes of one
+  // instruction would hit the same addresses with atomics, which serialises them (6.4 ms for 34 M samples).  For
+  // C <= 4 the four corner contributions go through a second wave table keyed by the texel instead, and reach
+  // memory as one atomic per (wave span, texel, channel).
+  TexelTable ttab;
+  ttab.init(s_texels[w], lane);
+  ttab.plane = C;
+  ttab.pitch = 0;
+  ttab.nlive = C;
+  const bool merge = C <= 4;
   // Background samples (most of an image) all sample the map at uv = (0, 0): their gradient is summed per lane and
   // leaves the wave as ONE atomic per corner and channel at the end -- scattered per sample, millions of atomics would
   // serialise on a single texel (measured: 209 ms for 34 M samples).  Channels beyond the fourth take the slow road.
@@ -168,6 +182,8 @@ __global__ __launch_bounds__(256) void sample_uv_bwd_kernel(TexArgs a, int64_t s
     }
     float gix = 0.0f, giy = 0.0f;
     Corners c;
+    int tkey[4] = {-1, -1, -1, -1};  // texel of each corner (merge path), -1: none
+    float tval[4][4];
     if (ok && f < 0) {
       const float* g = a.gtex + p * C;
 #pragma unroll
@@ -181,37 +197,51 @@ __global__ __launch_bounds__(256) void sample_uv_bwd_kernel(TexArgs a, int64_t s
       if (NEAREST) {
         const int xn = (int)nearbyintf(c.ix), yn = (int)nearbyintf(c.iy);
         if (inside(xn, yn, Hm, Wm)) {
-          float* dst = gmap + ((int64_t)yn * Wm + xn) * C;
-          for (int ch = ch0; ch < C; ++ch) unsafeAtomicAdd(dst + ch, g[ch]);
+          if (merge) {
+            tkey[0] = yn * Wm + xn;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) tval[0][ch] = ch < C ? g[ch] : 0.0f;
+          } else {
+            float* dst = gmap + ((int64_t)yn * Wm + xn) * C;
+            for (int ch = ch0; ch < C; ++ch) unsafeAtomicAdd(dst + ch, g[ch]);
+          }
         }
       } else {
         const bool in[4] = {inside(c.x0, c.y0, Hm, Wm), inside(c.x0 + 1, c.y0, Hm, Wm), inside(c.x0, c.y0 + 1, Hm, Wm),
                             inside(c.x0 + 1, c.y0 + 1, Hm, Wm)};
         const int64_t o0 = ((int64_t)c.y0 * Wm + c.x0) * C, o2 = o0 + (int64_t)Wm * C;
         const float fx = (float)c.x0, fy = (float)c.y0, x1 = fx + 1.0f, y1 = fy + 1.0f;
+        if (merge) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (in[k]) tkey[k] = (c.y0 + (k >> 1)) * Wm + c.x0 + (k & 1);
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) tval[k][ch] = ch < C ? c.w[k] * g[ch] : 0.0f;
+          }
+        }
         for (int ch = ch0; ch < C; ++ch) {
           const float gc = g[ch];
           // grid_sampler_2d_backward: scatter g * weight, and d out / d (ix, iy) from the corner values
           if (in[0]) {
-            unsafeAtomicAdd(gmap + o0 + ch, c.w[0] * gc);
+            if (!merge) unsafeAtomicAdd(gmap + o0 + ch, c.w[0] * gc);
             const float val = map[o0 + ch];
             gix -= val * (y1 - c.iy) * gc;
             giy -= val * (x1 - c.ix) * gc;
           }
           if (in[1]) {
-            unsafeAtomicAdd(gmap + o0 + C + ch, c.w[1] * gc);
+            if (!merge) unsafeAtomicAdd(gmap + o0 + C + ch, c.w[1] * gc);
             const float val = map[o0 + C + ch];
             gix += val * (y1 - c.iy) * gc;
             giy -= val * (c.ix - fx) * gc;
           }
           if (in[2]) {
-            unsafeAtomicAdd(gmap + o2 + ch, c.w[2] * gc);
+            if (!merge) unsafeAtomicAdd(gmap + o2 + ch, c.w[2] * gc);
             const float val = map[o2 + ch];
             gix -= val * (c.iy - fy) * gc;
             giy += val * (x1 - c.ix) * gc;
           }
           if (in[3]) {
-            unsafeAtomicAdd(gmap + o2 + C + ch, c.w[3] * gc);
+            if (!merge) unsafeAtomicAdd(gmap + o2 + C + ch, c.w[3] * gc);
             const float val = map[o2 + C + ch];
             gix += val * (c.iy - fy) * gc;
             giy += val * (c.ix - fx) * gc;
@@ -238,8 +268,16 @@ __global__ __launch_bounds__(256) void sample_uv_bwd_kernel(TexArgs a, int64_t s
     }
     if (__ballot(f >= 0) == 0) continue;  // wave-uniform
     tab.add(a.gfuv, lane, f, g6);
+    if (merge) {
+#pragma unroll
+      for (int k = 0; k < (NEAREST ? 1 : 4); ++k) {
+        if (__ballot(tkey[k] >= 0) == 0) continue;  // wave-uniform
+        ttab.add(gmap, lane, tkey[k], tval[k]);
+      }
+    }
   }
   if (tab.used > 0) tab.flush(a.gfuv, lane);
+  if (ttab.used > 0) ttab.flush(gmap, lane);
   // the background's share of the map gradient
   const Corners cb = corners_of(0.0f, 0.0f, Hm, Wm, a.align != 0, a.border != 0);
 #pragma unroll
@@ -266,7 +304,7 @@ int check_tex(int N, int H, int W, int K, int64_t F, int Hm, int Wm, int C, int 
   if (N < 0 || H < 0 || W < 0 || K < 0 || F < 0 || Hm < 1 || Wm < 1 || C < 1) return P3D_ERR_INVALID_ARG;
   if (padding_mode != P3D_PAD_ZEROS && padding_mode != P3D_PAD_BORDER) return P3D_ERR_INVALID_ARG;
   if (sampling_mode != P3D_SAMPLE_BILINEAR && sampling_mode != P3D_SAMPLE_NEAREST) return P3D_ERR_INVALID_ARG;
-  if (N > 65535) return P3D_ERR_INVALID_ARG;
+  if (N > 65535 || (int64_t)Hm * Wm > 0x7fffffffll) return P3D_ERR_INVALID_ARG;
   return P3D_OK;
 }
 
