@@ -92,6 +92,13 @@ int p3d_rasterize_meshes_backward(const float* face_verts, const int64_t* pix_to
                                   const float* grad_bary, const float* grad_dists, int64_t F, int N, int H, int W, int K,
                                   int perspective_correct, int clip_barycentric_coords, float* grad_face_verts,
                                   p3d_stream_t stream);
+/* The same backward with the gradient of `face_verts = verts_packed[faces_packed]` (rasterize_meshes.py:146, torch
+ * indexing + its index_put backward) fused in: the per-face partials are flushed straight to grad_verts (V,3) through
+ * faces (F,3) -- no (F,3,3) intermediate, no separate scatter.  grad_verts zeroed and accumulated. */
+int p3d_rasterize_meshes_backward_verts(const float* face_verts, const int64_t* faces, const int64_t* pix_to_face,
+                                        const float* grad_zbuf, const float* grad_bary, const float* grad_dists, int64_t F,
+                                        int64_t V, int N, int H, int W, int K, int perspective_correct,
+                                        int clip_barycentric_coords, float* grad_verts, p3d_stream_t stream);
 
 /* ---- packed vertices <-> per-face vertices (optional fast path of the L2 function) ------ */
 

@@ -33,6 +33,8 @@ _SIGNATURES = {
                                           c_ptr]),
     "p3d_rasterize_meshes_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int,
                                               c_int, c_int, c_ptr, c_ptr]),
+    "p3d_rasterize_meshes_backward_verts": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int,
+                                                    c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
     "p3d_gather_face_verts": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     "p3d_scatter_face_grads": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     "p3d_rasterize_points_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int, c_int, c_int]),

@@ -31,6 +31,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace p3d {
 
 namespace {
@@ -38,6 +40,7 @@ namespace {
 constexpr int kRegion = 32;  // pixels per workgroup-region side (four 16x16 wave areas)
 // 4 waves x 182 slots x (8 + 12*4) B = 40768 B of LDS -> 4 workgroups per CU
 using FaceTable = WaveTable<9, 182>;
+using FaceTableV = WaveTable<9, 182, kCorners>;  // flushed straight to grad_verts through faces_packed
 
 struct BwdArgs {
   const float* face_verts;
@@ -45,7 +48,8 @@ struct BwdArgs {
   const float* grad_zbuf;
   const float* grad_bary;
   const float* grad_dists;
-  float* grad_fv;
+  float* grad_fv;           // (F,3,3), or (V,3) with `faces`
+  const int64_t* faces;     // (F,3) or null: send the partials of face f to grad_verts[faces[f]] instead of grad_face_verts[f]
   int N, H, W, K;
   int RY, RX;  // regions per image
   int persp, clip;
@@ -93,9 +97,11 @@ __device__ __forceinline__ void load_f32_row(const float* p, float (&out)[M]) {
 }
 
 // KT > 0: K == KT, rows read with vector loads.  KT == 0: any K, per-slot scalar loads.
-template <int KT>
+// TO_VERTS: the table is flushed to grad_verts through faces_packed (the scatter of `verts[faces]`'s backward fused in).
+template <int KT, bool TO_VERTS>
 __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
-  __shared__ __align__(16) int s_table[4][FaceTable::kLdsInts];
+  using Table = std::conditional_t<TO_VERTS, FaceTableV, FaceTable>;
+  __shared__ __align__(16) int s_table[4][Table::kLdsInts];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -111,8 +117,9 @@ __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
   const int H = a.H, W = a.W, K = a.K;
   if (ay >= H || ax >= W) return;  // wave-uniform; no workgroup barriers in this kernel
 
-  FaceTable tab;
+  Table tab;
   tab.init(s_table[w], lane);
+  tab.index = a.faces;
   tab.no_atomics = (a.debug & 8) != 0;
   tab.dbg = a.debug;
   const bool persp = a.persp != 0, clip = a.clip != 0;
@@ -218,25 +225,18 @@ __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
 
 using namespace p3d;
 
-P3D_API int p3d_rasterize_meshes_backward(const float* face_verts, const int64_t* p2f, const float* grad_zbuf,
-                                          const float* grad_bary, const float* grad_dists, int64_t F, int N, int H,
-                                          int W, int K, int persp, int clip, float* grad_face_verts,
-                                          p3d_stream_t stream) {
-  if (F < 0 || N < 0 || H < 0 || W < 0 || K < 0) return P3D_ERR_INVALID_ARG;
-  if (F == 0) return P3D_OK;
-  if (!grad_face_verts || !face_verts) return P3D_ERR_INVALID_ARG;
-  hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(grad_face_verts, 0, (size_t)F * 9 * sizeof(float), s) != hipSuccess) return P3D_ERR_LAUNCH;
-  const int64_t npix = (int64_t)N * H * W;
-  if (npix * K == 0) return P3D_OK;
-  if (!p2f || !grad_zbuf || !grad_bary || !grad_dists) return P3D_ERR_INVALID_ARG;
+namespace {
+int launch_mesh_backward(const float* face_verts, const int64_t* faces, const int64_t* p2f, const float* grad_zbuf,
+                         const float* grad_bary, const float* grad_dists, int N, int H, int W, int K, int persp, int clip,
+                         float* grad_out, hipStream_t s) {
   BwdArgs a;
   a.face_verts = face_verts;
   a.p2f = p2f;
   a.grad_zbuf = grad_zbuf;
   a.grad_bary = grad_bary;
   a.grad_dists = grad_dists;
-  a.grad_fv = grad_face_verts;
+  a.grad_fv = grad_out;
+  a.faces = faces;
   a.N = N;
   a.H = H;
   a.W = W;
@@ -253,12 +253,50 @@ P3D_API int p3d_rasterize_meshes_backward(const float* face_verts, const int64_t
   if (blocks > 0x7fffffffll) return P3D_ERR_INVALID_ARG;
   LaunchScope ls("mesh_backward", s);
   const unsigned grid = (unsigned)blocks;
-  switch (K) {
-    case 1: mesh_backward_kernel<1><<<grid, 256, 0, s>>>(a); break;
-    case 2: mesh_backward_kernel<2><<<grid, 256, 0, s>>>(a); break;
-    case 4: mesh_backward_kernel<4><<<grid, 256, 0, s>>>(a); break;
-    case 8: mesh_backward_kernel<8><<<grid, 256, 0, s>>>(a); break;
-    default: mesh_backward_kernel<0><<<grid, 256, 0, s>>>(a); break;
+#define P3D_LAUNCH_MESH_BWD(TV)                                                  \
+  switch (K) {                                                                   \
+    case 1: mesh_backward_kernel<1, TV><<<grid, 256, 0, s>>>(a); break;          \
+    case 2: mesh_backward_kernel<2, TV><<<grid, 256, 0, s>>>(a); break;          \
+    case 4: mesh_backward_kernel<4, TV><<<grid, 256, 0, s>>>(a); break;          \
+    case 8: mesh_backward_kernel<8, TV><<<grid, 256, 0, s>>>(a); break;          \
+    default: mesh_backward_kernel<0, TV><<<grid, 256, 0, s>>>(a); break;         \
   }
+  if (faces) {
+    P3D_LAUNCH_MESH_BWD(true)
+  } else {
+    P3D_LAUNCH_MESH_BWD(false)
+  }
+#undef P3D_LAUNCH_MESH_BWD
   return launch_status();
+}
+}  // namespace
+
+P3D_API int p3d_rasterize_meshes_backward(const float* face_verts, const int64_t* p2f, const float* grad_zbuf,
+                                          const float* grad_bary, const float* grad_dists, int64_t F, int N, int H,
+                                          int W, int K, int persp, int clip, float* grad_face_verts,
+                                          p3d_stream_t stream) {
+  if (F < 0 || N < 0 || H < 0 || W < 0 || K < 0) return P3D_ERR_INVALID_ARG;
+  if (F == 0) return P3D_OK;
+  if (!grad_face_verts || !face_verts) return P3D_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(grad_face_verts, 0, (size_t)F * 9 * sizeof(float), s) != hipSuccess) return P3D_ERR_LAUNCH;
+  if ((int64_t)N * H * W * K == 0) return P3D_OK;
+  if (!p2f || !grad_zbuf || !grad_bary || !grad_dists) return P3D_ERR_INVALID_ARG;
+  return launch_mesh_backward(face_verts, nullptr, p2f, grad_zbuf, grad_bary, grad_dists, N, H, W, K, persp, clip,
+                              grad_face_verts, s);
+}
+
+P3D_API int p3d_rasterize_meshes_backward_verts(const float* face_verts, const int64_t* faces, const int64_t* p2f,
+                                                const float* grad_zbuf, const float* grad_bary, const float* grad_dists,
+                                                int64_t F, int64_t V, int N, int H, int W, int K, int persp, int clip,
+                                                float* grad_verts, p3d_stream_t stream) {
+  if (F < 0 || V < 0 || N < 0 || H < 0 || W < 0 || K < 0) return P3D_ERR_INVALID_ARG;
+  if (V == 0) return P3D_OK;
+  if (!grad_verts) return P3D_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(grad_verts, 0, (size_t)V * 3 * sizeof(float), s) != hipSuccess) return P3D_ERR_LAUNCH;
+  if (F == 0 || (int64_t)N * H * W * K == 0) return P3D_OK;
+  if (!face_verts || !faces || !p2f || !grad_zbuf || !grad_bary || !grad_dists) return P3D_ERR_INVALID_ARG;
+  return launch_mesh_backward(face_verts, faces, p2f, grad_zbuf, grad_bary, grad_dists, N, H, W, K, persp, clip,
+                              grad_verts, s);
 }

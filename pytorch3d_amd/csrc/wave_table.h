@@ -30,8 +30,9 @@ constexpr int kEmptyKey = -1;
 //   kPlanar out[j * plane + f], j < nlive                     NV planes of `plane` floats, e.g. (C, P) features
 //   kChunk  out[f * plane + (j / 4) * pitch + j % 4], j % 4 < nlive
 //           a 4-wide column chunk of (P, NV/4, pitch) records, e.g. channels c0..c0+3 of (F, 3, D) face attributes
+//   kCorners out[index[f * (NV/3) + j / 3] * 3 + j % 3]         per-corner xyz partials of face f sent to its vertices
 // SPILL: see kFlushAt.
-enum { kRows = 0, kPlanar = 1, kChunk = 2 };
+enum { kRows = 0, kPlanar = 1, kChunk = 2, kCorners = 3 };
 template <int NV, int SLOTS, int LAYOUT = kRows, bool SPILL = false>
 struct WaveTable {
   static constexpr int kStride = (NV + 3) / 4 * 4;  // floats per slot: values are moved as 16-byte chunks
@@ -51,11 +52,13 @@ struct WaveTable {
   int64_t plane = 0;        // kPlanar: floats per output plane; kChunk: floats per primitive record
   int pitch = 0;            // kChunk: floats between the NV/4 sub-rows of a record
   int nlive = NV;           // kPlanar: planes that exist; kChunk: live columns of the chunk (others are never flushed)
+  const int64_t* index = nullptr;  // kCorners: (P, NV/3) vertex ids
 
   // address of value j of primitive f, or nullptr when that value has no destination
   __device__ __forceinline__ float* dest(float* __restrict__ out, int f, int j) const {
     if constexpr (LAYOUT == kPlanar) return j < nlive ? out + j * plane + f : nullptr;
     if constexpr (LAYOUT == kChunk) return (j & 3) < nlive ? out + (int64_t)f * plane + (j >> 2) * pitch + (j & 3) : nullptr;
+    if constexpr (LAYOUT == kCorners) return out + index[(int64_t)f * (NV / 3) + j / 3] * 3 + j % 3;
     return out + (int64_t)f * NV + j;
   }
   bool no_atomics = false;  // ablation only (profiles/ablate.py): drop the global atomics of flush()

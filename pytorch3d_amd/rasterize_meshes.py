@@ -51,7 +51,10 @@ def rasterize_meshes(
     """Returns (pix_to_face, zbuf, barycentric_coords, dists), each (N, H, W, faces_per_pixel[, 3])."""
     verts_packed = meshes.verts_packed()
     faces_packed = meshes.faces_packed()
-    face_verts = gather_face_verts(verts_packed, faces_packed)
+    # without clipping the face gather, the rasterization and both their backwards run as one autograd node (the
+    # per-face gradient is flushed straight to the vertices: no (F,3,3) intermediate, no separate scatter)
+    fused_verts = (z_clip_value is None and not cull_to_frustum and _gatherable(verts_packed, faces_packed))
+    face_verts = None if fused_verts else gather_face_verts(verts_packed, faces_packed)
     mesh_to_face_first_idx = meshes.mesh_to_faces_packed_first_idx()
     num_faces_per_mesh = meshes.num_faces_per_mesh()
     im_size = parse_image_size(image_size)
@@ -72,7 +75,8 @@ def rasterize_meshes(
         clipped_faces_neighbor_idx = clipped_faces.clipped_faces_neighbor_idx
     if clipped_faces_neighbor_idx is None:
         clipped_faces_neighbor_idx = torch.full(
-            size=(face_verts.shape[0],), fill_value=-1, device=face_verts.device, dtype=torch.int64)
+            size=(faces_packed.shape[0] if fused_verts else face_verts.shape[0],), fill_value=-1,
+            device=verts_packed.device, dtype=torch.int64)
 
     if bin_size is None:
         bin_size = default_bin_size(max_image_size)
@@ -84,6 +88,11 @@ def rasterize_meshes(
     if max_faces_per_bin is None:
         max_faces_per_bin = int(max(10000, meshes._F / 5))
 
+    if fused_verts:
+        return _RasterizeMeshVerts.apply(
+            verts_packed, faces_packed, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, im_size,
+            blur_radius, faces_per_pixel, bin_size, max_faces_per_bin, perspective_correct, clip_barycentric_coords,
+            cull_backfaces)
     pix_to_face, zbuf, barycentric_coords, dists = _RasterizeFaceVerts.apply(
         face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, im_size, blur_radius,
         faces_per_pixel, bin_size, max_faces_per_bin, perspective_correct, clip_barycentric_coords, cull_backfaces)
@@ -96,12 +105,16 @@ def rasterize_meshes(
     return pix_to_face, zbuf, barycentric_coords, dists
 
 
+def _gatherable(verts_packed, faces_packed):
+    return (verts_packed.is_cuda and verts_packed.dtype == torch.float32 and faces_packed.dtype == torch.int64
+            and faces_packed.device == verts_packed.device and verts_packed.dim() == 2 and faces_packed.dim() == 2)
+
+
 def gather_face_verts(verts_packed, faces_packed):
     """`verts_packed[faces_packed]` (rasterize_meshes.py:146) -> (F, 3, 3).  On the GPU both the gather and its
     autograd scatter are single HIP kernels (include/p3d_amd.h: p3d_gather_face_verts / p3d_scatter_face_grads)
     instead of torch indexing, whose backward on ROCm is a radix sort + segmented sum."""
-    if (verts_packed.is_cuda and verts_packed.dtype == torch.float32 and faces_packed.dtype == torch.int64
-            and faces_packed.device == verts_packed.device and verts_packed.dim() == 2 and faces_packed.dim() == 2):
+    if _gatherable(verts_packed, faces_packed):
         return _GatherFaceVerts.apply(verts_packed, faces_packed)
     return verts_packed[faces_packed]
 
@@ -177,3 +190,57 @@ class _RasterizeFaceVerts(torch.autograd.Function):
                                                        grad_dists, ctx.perspective_correct,
                                                        ctx.clip_barycentric_coords)
         return (grad_face_verts,) + (None,) * 11
+
+
+class _RasterizeMeshVerts(torch.autograd.Function):
+    """`verts_packed[faces_packed]` + _RasterizeFaceVerts as ONE node: forward = the gather kernel + the rasterizer,
+    backward = p3d_rasterize_meshes_backward_verts, which flushes the per-face partials straight to grad_verts."""
+
+    @staticmethod
+    def forward(ctx, verts, faces, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, image_size,
+                blur_radius, faces_per_pixel, bin_size, max_faces_per_bin, perspective_correct, clip_barycentric_coords,
+                cull_backfaces):
+        from . import _lib
+
+        lib = _lib.load()
+        verts_c, faces_c = verts.contiguous(), faces.contiguous()
+        V, F = verts_c.shape[0], faces_c.shape[0]
+        with torch.cuda.device(verts.device):
+            face_verts = torch.empty((F, 3, 3), dtype=torch.float32, device=verts.device)
+            if F:
+                rc = lib.p3d_gather_face_verts(_C._ptr(verts_c), _C._ptr(faces_c), V, F, _C._ptr(face_verts),
+                                               _C._stream(verts.device))
+                _lib.check(rc, "gather_face_verts")
+        pix_to_face, zbuf, barycentric_coords, dists = _C.rasterize_meshes(
+            face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, image_size, blur_radius,
+            faces_per_pixel, bin_size, max_faces_per_bin, perspective_correct, clip_barycentric_coords, cull_backfaces)
+        ctx.save_for_backward(face_verts, faces_c, pix_to_face)
+        ctx.mark_non_differentiable(pix_to_face)
+        ctx.set_materialize_grads(False)
+        ctx.V = V
+        ctx.flags = (int(bool(perspective_correct)), int(bool(clip_barycentric_coords)))
+        return pix_to_face, zbuf, barycentric_coords, dists
+
+    @staticmethod
+    def backward(ctx, grad_pix_to_face, grad_zbuf, grad_barycentric_coords, grad_dists):
+        from . import _lib
+
+        face_verts, faces, pix_to_face = ctx.saved_tensors
+        if grad_zbuf is None and grad_barycentric_coords is None and grad_dists is None:
+            return (None,) * 13
+        if torch.are_deterministic_algorithms_enabled() and not torch.is_deterministic_algorithms_warn_only_enabled():
+            raise RuntimeError("RasterizeMeshesBackwardCuda does not have a deterministic implementation")
+        dev = pix_to_face.device
+        N, H, W, K = pix_to_face.shape
+        zeros = lambda *tail: torch.zeros(tuple(pix_to_face.shape) + tail, dtype=torch.float32, device=dev)
+        gz = grad_zbuf.contiguous() if grad_zbuf is not None else zeros()
+        gd = grad_dists.contiguous() if grad_dists is not None else zeros()
+        gb = grad_barycentric_coords.contiguous() if grad_barycentric_coords is not None else zeros(3)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            grad_verts = torch.empty((ctx.V, 3), dtype=torch.float32, device=dev)
+            rc = lib.p3d_rasterize_meshes_backward_verts(
+                _C._ptr(face_verts), _C._ptr(faces), _C._ptr(pix_to_face), _C._ptr(gz), _C._ptr(gb), _C._ptr(gd),
+                faces.shape[0], ctx.V, N, H, W, K, ctx.flags[0], ctx.flags[1], _C._ptr(grad_verts), _C._stream(dev))
+            _lib.check(rc, "rasterize_meshes_backward")
+        return (grad_verts,) + (None,) * 12
