@@ -368,3 +368,43 @@ def test_rasterize_meshes_is_hip_graph_capturable():
     torch.cuda.synchronize()
     for a, b in zip(out, ref):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("size,K", [((1000, 1400), 4), ((2048, 640), 8), ((1300, 1300), 5)])
+def test_images_larger_than_the_bin_grid_property_checks(size, K):
+    """Above 512 pixels the internal bins grow beyond one 16x16 tile (at most 32 bins per side): naive == binned, sorted
+    K-prefixes, -1 padding, also for non-square sizes that are no multiple of the tile and for a K without vector rows;
+    the backward of both agrees."""
+    verts, faces = U.hetero_batch(2, seed=7, fmin=1500, fmax=4000)
+    from pytorch3d_amd import PackedMeshes, _C
+
+    m = PackedMeshes(verts, faces)
+    fv = m.verts_packed()[m.faces_packed()]
+    first, count = m.mesh_to_faces_packed_first_idx(), m.num_faces_per_mesh()
+    nbr = torch.full((fv.shape[0],), -1, dtype=torch.int64)
+    blur = 3e-4
+    from pytorch3d_amd.rasterize_meshes import default_bin_size
+
+    a = _run_ours(fv, first, count, nbr, size, blur, K, default_bin_size(max(size)), 20000, True, True, False)
+    b = _run_ours(fv, first, count, nbr, size, blur, K, 0, 0, True, True, False)
+    _assert_fwd_equal(a, b, tag=f"naive==binned@{size}")
+    p2f, zbuf, bary, dists = a
+    valid = p2f >= 0
+    assert (zbuf[~valid] == -1).all() and (dists[~valid] == -1).all() and (bary[~valid] == -1).all()
+    assert (valid[..., 1:] <= valid[..., :-1]).all()
+    z = torch.where(valid, zbuf, torch.full_like(zbuf, float("inf")))
+    assert (z[..., 1:] >= z[..., :-1]).all()
+    assert valid.float().mean() > 0.01
+    # backward: linear in the upstream gradients (size-independent property), finite, and only on faces that were hit
+    d = _dev()
+    gen = torch.Generator().manual_seed(K)
+    gz, gd = (torch.randn(p2f.shape, generator=gen).to(d) for _ in range(2))
+    gb = torch.randn(p2f.shape + (3,), generator=gen).to(d)
+    fvd, p2fd = fv.to(d), p2f.to(d)
+    g1 = _C.rasterize_meshes_backward(fvd, p2fd, gz, gb, gd, True, True)
+    g2 = _C.rasterize_meshes_backward(fvd, p2fd, 2 * gz, 2 * gb, 2 * gd, True, True)
+    assert torch.isfinite(g1).all()
+    assert torch.allclose(g2, 2 * g1, rtol=1e-3, atol=1e-3 * g1.abs().max().item())
+    hit = torch.zeros(fv.shape[0], dtype=torch.bool)
+    hit[p2f[valid]] = True
+    assert (g1.cpu()[~hit] == 0).all()
