@@ -42,6 +42,31 @@ def test_points_naive_and_binned_vs_oracle(size, K):
         assert all(torch.equal(a, b) for a, b in zip(ours, r))
 
 
+@pytest.mark.parametrize("size,K", [((1100, 900), 6), ((640, 2048), 10)])
+def test_points_on_images_larger_than_the_bin_grid(size, K):
+    """Above 512 pixels the internal bins grow beyond one tile: naive == binned (bit-exact), sorted K-prefixes, -1 padding."""
+    from pytorch3d_amd import _C
+
+    d = _dev()
+    gen = torch.Generator().manual_seed(K)
+    P = 60000
+    pts = torch.cat([torch.rand(P, 2, generator=gen) * 2.4 - 1.2, torch.rand(P, 1, generator=gen) * 2 + 0.3], 1).to(d)
+    first = torch.tensor([0, 25000], device=d)
+    count = torch.tensor([25000, 35000], device=d)
+    radius = (torch.rand(P, generator=gen) * 0.02 + 0.004).to(d)
+    a = _C.rasterize_points(pts, first, count, size, radius, K, 128, 60000)
+    b = _C.rasterize_points(pts, first, count, size, radius, K, 0, 0)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    idx, zbuf, dists = (t.cpu() for t in a)
+    valid = idx >= 0
+    assert (zbuf[~valid] == -1).all() and (dists[~valid] == -1).all()
+    assert (valid[..., 1:] <= valid[..., :-1]).all()
+    z = torch.where(valid, zbuf, torch.full_like(zbuf, float("inf")))
+    assert (z[..., 1:] >= z[..., :-1]).all()
+    assert 0.02 < valid.float().mean() < 0.98
+    assert (idx[0][valid[0]] < 25000).all() and (idx[1][valid[1]] >= 25000).all()
+
+
 def test_points_coarse_and_fine_ops():
     from pytorch3d_amd import _C
 
