@@ -221,3 +221,20 @@ def test_shading_host_logic_packs_broadcasts_and_refuses():
     assert torch.allclose(m.verts_normals_packed().norm(dim=1), torch.ones(4), atol=1e-6)
     assert torch.allclose(m.faces_normals_packed().norm(dim=1), torch.ones(2), atol=1e-6)
     assert m.verts_packed_to_mesh_idx().tolist() == [0, 0, 0, 0]
+
+
+def test_uv_sampling_host_logic_refuses_loudly():
+    """pytorch3d_amd/textures.py host side (no GPU): argument checks, no CPU emulation."""
+    from collections import namedtuple
+
+    import pytorch3d_amd as p3d
+
+    Frag = namedtuple("Frag", "pix_to_face bary_coords")
+    frag = Frag(torch.zeros(1, 2, 2, 1, dtype=torch.int64), torch.rand(1, 2, 2, 1, 3))
+    fu, maps = torch.rand(3, 3, 2), torch.rand(1, 4, 4, 3)
+    with pytest.raises(NotImplementedError, match="padding_mode"):
+        p3d.sample_textures_uv(frag, fu, maps, padding_mode="reflection")
+    with pytest.raises(ValueError, match="sampling_mode"):
+        p3d.sample_textures_uv(frag, fu, maps, sampling_mode="bicubic")
+    with pytest.raises(RuntimeError, match="GPU path only"):
+        p3d.sample_textures_uv(frag, fu, maps)
