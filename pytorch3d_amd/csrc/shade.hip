@@ -178,11 +178,11 @@ template <int D>
 struct ShadeTable {
   static constexpr int NV = 3 * D;
   // LDS per workgroup = 4 waves x slots x (8 + 4 * stride) B and the kernel is latency-bound, so the tables are sized
-  // for 4 workgroups per CU (D = 6: 37 KB, D = 9: 40 KB) rather than for the worst case of a step (64 consecutive
+  // for 5 / 4 workgroups per CU (D = 6: 32 KB, D = 9: 40 KB) rather than for the worst case of a step (64 consecutive
   // samples can name 64 faces): they run in SPILL mode (wave_table.h).  Measured on the config-3 fragments, D = 6:
-  // 182 slots (2 WG/CU) 4.3 ms, 144 (3 WG/CU) 3.3 ms, 106 (4 WG/CU) 2.9 ms; D = 9: 110 slots (3 WG/CU) 3.6 ms, 83 (4 WG/CU) 3.2 ms.
+  // 182 slots (2 WG/CU) 4.3 ms, 144 (3 WG/CU) 3.3 ms, 106 (4 WG/CU) 2.9 ms, 90 (5 WG/CU) 2.6 ms, 75 (6 WG/CU) 2.65 ms; D = 9: 110 slots (3 WG/CU) 3.6 ms, 83 (4 WG/CU) 3.2 ms.
 #ifndef P3D_SHADE_SLOTS6
-#define P3D_SHADE_SLOTS6 106
+#define P3D_SHADE_SLOTS6 90
 #endif
 #ifndef P3D_SHADE_SLOTS9
 #define P3D_SHADE_SLOTS9 83
