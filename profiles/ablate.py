@@ -4,6 +4,10 @@
     python profiles/ablate.py bwd 0 1 2 3 4 7       # P3D_DEBUG_BWD values
     python profiles/ablate.py fwd 0 1 2 ...         # P3D_DEBUG_FWD values
 Prints one line per variant: average kernel ms (HIP events inside the library).
+
+The switches exist only in an ablation build (the product library never reads the environment):
+    P3D_EXTRA_FLAGS="-DP3D_ABLATION -DP3D_FWD_STATS" P3D_LIB_PATH=$PWD/pytorch3d_amd/libp3d_amd_abl.so python -m pytorch3d_amd.build
+    P3D_LIB_PATH=$PWD/pytorch3d_amd/libp3d_amd_abl.so python profiles/ablate.py fwd 0 1 2 64
 """
 import math
 import os

@@ -8,7 +8,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libp3d_amd.so")
+# P3D_LIB_PATH selects an ablation build (profiles/ scripts only; see build.py)
+LIB_PATH = os.environ.get("P3D_LIB_PATH") or os.path.join(_HERE, "libp3d_amd.so")
 
 c_i64 = ctypes.c_int64
 c_int = ctypes.c_int

@@ -14,7 +14,8 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libp3d_amd.so")
+# P3D_LIB_PATH: build / load an ABLATION variant next to the product library (profiles/ only; the driver never sets it)
+LIB = os.environ.get("P3D_LIB_PATH") or os.path.join(HERE, "libp3d_amd.so")
 ARCH = "gfx950"
 
 SOURCES = ["binning.hip", "raster_mesh.hip", "raster_mesh_bwd.hip", "gather.hip", "raster_points.hip", "composite.hip", "blend.hip", "clip.hip", "interp.hip", "shade.hip", "texture.hip", "profile.cpp"]
@@ -40,8 +41,26 @@ def _newest(paths):
     return max(os.path.getmtime(p) for p in paths if os.path.exists(p))
 
 
+def _extra_flags():
+    return os.environ.get("P3D_EXTRA_FLAGS", "").split()  # e.g. -DP3D_FWD_STATS, -DP3D_FINE_WAVES_PER_SIMD=3
+
+
+def _flag_signature():
+    return " ".join(FLAGS + _extra_flags())
+
+
+def _stamp_path():
+    return LIB + ".flags"
+
+
 def needs_build():
     if not os.path.exists(LIB):
+        return True
+    # a library built with other flags (ablation -D switches, table sizes) must never be reused as the product build
+    try:
+        if open(_stamp_path()).read() != _flag_signature():
+            return True
+    except OSError:
         return True
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return _newest(deps) > os.path.getmtime(LIB)
@@ -51,12 +70,12 @@ def build(force=False, verbose=False):
     if not (force or needs_build()):
         return LIB
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build", os.path.basename(LIB))
     os.makedirs(objdir, exist_ok=True)
 
     def compile_one(src):
         obj = os.path.join(objdir, src + ".o")
-        extra = os.environ.get("P3D_EXTRA_FLAGS", "").split()  # e.g. -DP3D_FWD_STATS, -DP3D_FINE_WAVES_PER_SIMD=3
+        extra = _extra_flags()
         cmd = [hipcc] + FLAGS + extra + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
@@ -69,6 +88,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(_stamp_path(), "w") as f:
+        f.write(_flag_signature())
     return LIB
 
 

@@ -170,7 +170,7 @@ __device__ __forceinline__ void write_subtile_fill_patch(const MeshArgs& a, cons
   const int rows = min(8, y_end - sy0), cols = min(8, x_end - sx0);
   const int seg = cols * K;             // contiguous entries per sub-tile row (outputs are stored flipped: x_out = W-1-x)
   const int64_t col0 = W - sx0 - cols;  // first output column of the sub-tile
-  const bool patch = have && !(a.debug & 1024);
+  const bool patch = have && !(P3D_DBG(a) & 1024);
   for (int r = 0; r < rows; ++r) {
     // ---- (A) fill row r of the sub-tile: one contiguous piece of each output ----
     const int64_t px = ((int64_t)n * H + (H - 1 - (sy0 + r))) * W + col0;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
   }
   if (count <= 0) {
     // background tile (4 of 5 at the bench workload): nothing but the -1 stores; skip the NDC set-up below
-    if (!(a.debug & 4)) {
+    if (!(P3D_DBG(a) & 4)) {
       Queue e;
       e.init();
       if (IN_REGS && a.K == KT) {
@@ -302,7 +302,8 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
   q.init();
   const int K = a.K;
 #ifdef P3D_FWD_STATS
-  unsigned long long c_cand = 0, c_body = 0, c_lanes = 0, c_hit = 0, c_ins = 0, c_staged = 0, c_groups = 0;
+  unsigned long long c_cand = 0, c_body = 0, c_lanes = 0, c_hit = 0, c_ins = 0, c_staged = 0, c_groups = 0, c_body_hit = 0,
+                     c_body_ins = 0, c_chunks = 0;
 #define P3D_STAT(x) x
 #else
 #define P3D_STAT(x)
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
     // faces is therefore visited front to back (ascending depth key), which lets the depth cull
     // discard almost everything behind the first K layers; a chunk with neighbour faces keeps
     // the reference's ascending-index order.
-    const bool sorted = __syncthreads_or(has_nb ? 1 : 0) == 0 && !(a.debug & 32);
+    const bool sorted = __syncthreads_or(has_nb ? 1 : 0) == 0 && !(P3D_DBG(a) & 32);
     if (sorted) {
       chunk_bucket_order(s_zc, staged, s_order, s_qlow, s_ord, tid);
     } else {
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
     }
 
     P3D_STAT(c_staged += staged);
+    P3D_STAT(++c_chunks);
     // ---- per wave: sub-tile cull 64 faces at a time, then per-pixel evaluation -----------
     if (wave_ok) {
       for (int jb = 0; jb < staged; jb += kWave) {
@@ -393,21 +395,25 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
           const float zc = s_zc[jj];
           const float4 r0 = s_vert[jj][0], r1 = s_vert[jj][1], r2 = s_vert[jj][2];
           const bool out = p.x > b.y || p.x < b.x || p.y > b.w || p.y < b.z;
-          const bool too_deep = zc > q.kth_z(K) && !(a.debug & 16);
+          const bool too_deep = zc > q.kth_z(K) && !(P3D_DBG(a) & 16);
 #ifdef P3D_FWD_STATS
-          if (a.debug & 64) {
+          if (P3D_DBG(a) & 64) {
             const unsigned long long m = __ballot(pix_ok && !out && !too_deep);
             c_body += m != 0;
             c_lanes += __popcll(m);
           }
 #endif
-          if (pix_ok && !out && !too_deep && !(a.debug & 1)) {
+#ifdef P3D_FWD_STATS
+          bool st_hit = false, st_ins = false;
+#endif
+          if (pix_ok && !out && !too_deep && !(P3D_DBG(a) & 1)) {
             const f3 a0 = mk3(r0.x, r0.y, r0.z);
             const f3 a1 = mk3(r0.w, r1.x, r1.y);
             const f3 a2 = mk3(r1.z, r1.w, r2.x);
             FaceHit h;
             if (face_hit(a0, a1, a2, p, a.blur, persp, clip, &h)) {
               P3D_STAT(++c_hit);
+              P3D_STAT(st_hit = true);
               const int f = __float_as_int(r2.y);
               const int nb = __float_as_int(r2.z);
               const float pl[kMeshPayload] = {h.dist, h.bary.x, h.bary.y, h.bary.z};
@@ -426,12 +432,19 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
               }
               // a candidate that sorts after the K-th entry of a full queue would fall straight
               // off the end of the insertion network: skip the network for it
-              if (ins && q.admits(K, h.z, f) && !(a.debug & 2)) {
+              if (ins && q.admits(K, h.z, f) && !(P3D_DBG(a) & 2)) {
                 P3D_STAT(++c_ins);
+                P3D_STAT(st_ins = true);
                 q.insert(K, h.z, f, pl);
               }
             }
           }
+#ifdef P3D_FWD_STATS
+          if (P3D_DBG(a) & 64) {
+            c_body_hit += __ballot(st_hit) != 0;
+            c_body_ins += __ballot(st_ins) != 0;
+          }
+#endif
         }
       }
     }
@@ -439,7 +452,7 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
   }
 
 #ifdef P3D_FWD_STATS
-  if ((a.debug & 64) && a.counters) {
+  if ((P3D_DBG(a) & 64) && a.counters) {
     // [0] waves, [1] staged faces (per wave), [2] 64-face groups, [3] candidate iterations, [4] iterations whose
     // body ran, [5] lanes active in those bodies, [6] lane-level hits, [7] lane-level insertions
     if (lane == 0) {
@@ -449,12 +462,16 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
       atomicAdd(&a.counters[3], c_cand);
       atomicAdd(&a.counters[4], c_body);
       atomicAdd(&a.counters[5], c_lanes);
+      atomicAdd(&a.counters[8], c_body_hit);
+      atomicAdd(&a.counters[9], c_body_ins);
+      atomicAdd(&a.counters[10], c_chunks);
+      atomicAdd(&a.counters[11], (unsigned long long)(c_body > 0));
     }
     atomicAdd(&a.counters[6], c_hit);
     atomicAdd(&a.counters[7], c_ins);
   }
 #endif
-  if (!(a.debug & 4)) {
+  if (!(P3D_DBG(a) & 4)) {
     if (IN_REGS && K == KT) {
       if (pix_ok) write_pixel<Queue, KT, IN_REGS>(a, q, ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi));
     } else if (wave_ok) {
@@ -466,11 +483,13 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
 template <bool BINNED>
 int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
   MeshArgs a = a0;
+#ifdef P3D_ABLATION
   {
     const char* e = getenv("P3D_DEBUG_FWD");
     a.debug = e ? atoi(e) : 0;
-    if (a.debug & 128) a.tm.bin_mult = 1;
+    if (P3D_DBG(a) & 128) a.tm.bin_mult = 1;
   }
+#endif
   const unsigned grid = tile_grid(a.tm);
   const char* name = BINNED ? "mesh_fine" : "mesh_naive";
   struct Stats {  // debug bit 64 only: synchronous, prints to stderr
@@ -478,23 +497,25 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
     hipStream_t s;
     ~Stats() {
       if (!dev) return;
-      unsigned long long h[8];
+      unsigned long long h[12];
       (void)hipStreamSynchronize(s);
       (void)hipMemcpy(h, dev, sizeof(h), hipMemcpyDeviceToHost);
       (void)hipFree(dev);
       fprintf(stderr,
               "[p3d fwd stats] waves %llu | staged faces/wave %.1f | groups/wave %.2f | candidate iters/wave %.1f | body "
-              "iters/wave %.1f | lanes per body %.1f | hits/lane %.2f | inserts/lane %.2f\n",
+              "iters/wave %.1f | lanes per body %.1f | hits/lane %.2f | inserts/lane %.2f | bodies with a hit %.1f /wave | "
+              "bodies with an insertion %.1f /wave | chunks/wave %.2f | waves with any body %llu\n",
               h[0], (double)h[1] / h[0], (double)h[2] / h[0], (double)h[3] / h[0], (double)h[4] / h[0],
-              h[4] ? (double)h[5] / h[4] : 0.0, (double)h[6] / (h[0] * 64.0), (double)h[7] / (h[0] * 64.0));
+              h[4] ? (double)h[5] / h[4] : 0.0, (double)h[6] / (h[0] * 64.0), (double)h[7] / (h[0] * 64.0),
+              (double)h[8] / h[0], (double)h[9] / h[0], (double)h[10] / h[0], h[11]);
     }
   } stats;
   stats.s = stream;
   a.counters = nullptr;
-  if (a.debug & 64) {
+  if (P3D_DBG(a) & 64) {
     // ablation only (P3D_DEBUG_FWD bit 64 in a -DP3D_FWD_STATS build): the one place that allocates and synchronises
-    if (hipMalloc(&stats.dev, 8 * sizeof(unsigned long long)) != hipSuccess) stats.dev = nullptr;
-    if (stats.dev) (void)hipMemsetAsync(stats.dev, 0, 8 * sizeof(unsigned long long), stream);
+    if (hipMalloc(&stats.dev, 12 * sizeof(unsigned long long)) != hipSuccess) stats.dev = nullptr;
+    if (stats.dev) (void)hipMemsetAsync(stats.dev, 0, 12 * sizeof(unsigned long long), stream);
     a.counters = stats.dev;
   }
   LaunchScope ls(name, stream);
@@ -613,8 +634,12 @@ P3D_API int p3d_rasterize_meshes(const float* face_verts, const int64_t* mesh_fi
   if (!mesh_first || !mesh_count || !p2f || !zbuf || !bary || !dists) return P3D_ERR_INVALID_ARG;
   const BinGeom gu = make_geom(H, W, bin_size);
   if (gu.BH > P3D_MAX_BINS_PER_SIDE || gu.BW > P3D_MAX_BINS_PER_SIDE) return P3D_ERR_TOO_MANY_BINS;
+#ifdef P3D_ABLATION
   const char* dbg_env = getenv("P3D_DEBUG_FWD");
   const bool user_bins = dbg_env && (atoi(dbg_env) & 512);  // ablation: bin with the caller's geometry
+#else
+  const bool user_bins = false;
+#endif
   const BinGeom g = user_bins ? gu : make_internal_geom(H, W, bin_size);  // tile-sized bins: results do not depend on the binning
   Arena arena(workspace, workspace_bytes);
   BinWorkspace ws;

@@ -126,8 +126,8 @@ __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
   Table tab;
   tab.init(s_table[w], lane);
   tab.index = a.faces;
-  tab.no_atomics = (a.debug & 8) != 0;
-  tab.dbg = a.debug;
+  tab.no_atomics = (P3D_DBG(a) & 8) != 0;
+  tab.dbg = P3D_DBG(a);
   const bool persp = a.persp != 0, clip = a.clip != 0;
 
 #pragma unroll 1
@@ -159,11 +159,11 @@ __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
         if (__ballot(f[k] >= 0) == 0) continue;  // wave-uniform
         FaceGrad r;
         if (f[k] >= 0) {
-          const float* g = a.face_verts + (int64_t)((a.debug & 4) ? 0 : f[k]) * 9;
+          const float* g = a.face_verts + (int64_t)((P3D_DBG(a) & 4) ? 0 : f[k]) * 9;
           const f3 v0 = mk3(g[0], g[1], g[2]);
           const f3 v1 = mk3(g[3], g[4], g[5]);
           const f3 v2 = mk3(g[6], g[7], g[8]);
-          if (a.debug & 1) {
+          if (P3D_DBG(a) & 1) {
 #pragma unroll
             for (int j = 0; j < 9; ++j) r.g[j] = v0.x + gz[k] + gd[k] + gb[3 * k];
           } else {
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
                                 false);
           }
         }
-        if (a.debug & 2) {
+        if (P3D_DBG(a) & 2) {
           if (f[k] >= 0 && r.g[0] == 1234.5f) a.grad_fv[0] = r.g[1];
           continue;
         }
@@ -251,10 +251,12 @@ int launch_mesh_backward(const float* face_verts, const int64_t* faces, const in
   a.RX = (int)ceil_div(W, kRegion);
   a.persp = persp;
   a.clip = clip;
+#ifdef P3D_ABLATION
   {
     const char* e = getenv("P3D_DEBUG_BWD");
     a.debug = e ? atoi(e) : 0;
   }
+#endif
   const int64_t blocks = (int64_t)N * a.RY * a.RX;
   if (blocks > 0x7fffffffll) return P3D_ERR_INVALID_ARG;
   LaunchScope ls("mesh_backward", s);

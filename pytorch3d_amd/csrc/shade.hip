@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void phong_bwd_kernel(ShadeArgs a) {
       const int r = (int)(((float)e + 0.5f) * inv_run);
       const int64_t p = (((int64_t)n * H + y0 + r) * W + x0) * K + (e - r * run);
       int f = ok ? (int)a.p2f[p] : -1;
-      if (a.debug & 2) f = -1;
+      if (P3D_DBG(a) & 2) f = -1;
       float g[NV];
       float gb[3] = {0.f, 0.f, 0.f};
       float go[3] = {0.f, 0.f, 0.f};
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void phong_bwd_kernel(ShadeArgs a) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) go[j] = a.gcolors[p * 3 + j];
       }
-      if (D == 6 && ok && f < 0 && !(a.debug & 4)) {
+      if (D == 6 && ok && f < 0 && !(P3D_DBG(a) & 4)) {
         // background sample with caller-supplied texels: colour = ambient * texel (+ a constant)
 #pragma unroll
         for (int j = 0; j < 3; ++j) a.gtexels[p * 3 + j] = amb[j] * go[j];
@@ -351,16 +351,16 @@ __global__ __launch_bounds__(256) void phong_bwd_kernel(ShadeArgs a) {
           }
           gb[i] = acc;
         }
-        if (D == 6 && !(a.debug & 4)) {
+        if (D == 6 && !(P3D_DBG(a) & 4)) {
 #pragma unroll
           for (int j = 0; j < 3; ++j) a.gtexels[p * 3 + j] = dtex[j];
         }
       }
-      if (ok && !(a.debug & 4)) {
+      if (ok && !(P3D_DBG(a) & 4)) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) a.gbary[p * 3 + j] = gb[j];
       }
-      if (__ballot(f >= 0) == 0 || (a.debug & 1)) continue;  // wave-uniform
+      if (__ballot(f >= 0) == 0 || (P3D_DBG(a) & 1)) continue;  // wave-uniform
       tab.add(a.gattrs, lane, f, g);
     }
   }
@@ -467,10 +467,12 @@ P3D_API int p3d_phong_shade_backward(const float* grad_colors, const int64_t* pi
   a.AW = K >= 4 ? 16 : (K == 3 ? 24 : (K == 2 ? 32 : 64));  // >= 64 samples per row of the area
   a.RY = (int)ceil_div(H, 16);
   a.RX = (int)ceil_div(W, a.AW);
+#ifdef P3D_ABLATION
   {
     const char* e = getenv("P3D_DEBUG_SHADE");
     a.debug = e ? atoi(e) : 0;
   }
+#endif
   const int64_t blocks = ceil_div((int64_t)N * a.RY * a.RX, 4);
   if (blocks > 0x7fffffff) return P3D_ERR_INVALID_ARG;
   LaunchScope ls("phong_bwd", s);
