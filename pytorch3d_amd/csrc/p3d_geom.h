@@ -219,6 +219,179 @@ P3D_HD bool face_hit(f3 v0, f3 v1, f3 v2, f2 p, float blur_radius, bool perspect
 }
 
 // ---------------------------------------------------------------------------
+// The same per-(pixel, face) test with SHARED RECIPROCALS -- bit-identical results, fewer instructions.
+//
+// An IEEE float division costs 11 instructions on gfx950 (v_div_scale x2, v_rcp, 5 fma, v_div_fmas, v_div_fixup),
+// twelve of them per (pixel, face) = 132 of ~300.  Nine share a denominator with two others (the face area, the
+// perspective denominator, the clip sum), the other three divide by per-FACE squared edge lengths.  Replacing
+// `n / d` by a multiplication with a reciprocal is not exact in float arithmetic -- but it is in DOUBLE:
+//
+//     (float)((double)n * rd)  ==  n / d   (the correctly rounded float quotient)   whenever |rd * d - 1| <= 2^-52
+//
+// Proof.  Scale n, d to integers in [2^23, 2^24); q = n/d lies in (1/2, 2).  The rounding boundaries of the float
+// grid around q are M = j / 2^25 (j odd; 2^24 for q >= 1).  |q - M| = |n 2^25 - j d| / (d 2^25) >= 1 / (d 2^25):
+// the numerator is a non-zero integer (n 2^25 = j d would need 2^25 | d).  So q is at least 2^-49 (relative) away
+// from every boundary, while (double)n * rd is within 2^-52 (rd) + 2^-53 (the product's rounding) of q: rounding it
+// to float lands on the same float as rounding q.  n = 0, d = inf and NaNs propagate as in IEEE division; for
+// results below 2^-126 (float denormals) the argument does not hold and the last denormal bit may differ.
+//
+// rd: a hardware reciprocal estimate refined by two Newton steps in double.  Per pixel the seed is v_rcp_f32 (1 ulp =
+// 2^-23 -> 2^-46 -> below 2^-52), which needs 2^-126 <= d <= 2^126; that holds for the per-pixel denominators of every
+// face whose coordinates are of ordinary magnitude (`FaceRec::wide` false).  For the other faces, and for the per-face
+// reciprocals (computed once per face), the seed is v_rcp_f64, valid over the whole float range.  On the host 1.0 / d.
+// All of them give the same float quotients, by the argument above.
+// ---------------------------------------------------------------------------
+P3D_HD double recip_newton(double dd, double r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double e = __builtin_fma(-dd, r, 1.0);
+  r = __builtin_fma(e, r, r);
+  e = __builtin_fma(-dd, r, 1.0);
+  r = __builtin_fma(e, r, r);
+#endif
+  return r;
+}
+
+P3D_HD double recip_for_div(float d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return recip_newton((double)d, (double)__builtin_amdgcn_rcpf(d));
+#else
+  return 1.0 / (double)d;
+#endif
+}
+
+P3D_HD double recip_for_div_wide(float d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return recip_newton((double)d, __builtin_amdgcn_rcp((double)d));
+#else
+  return 1.0 / (double)d;
+#endif
+}
+
+P3D_HD float exact_div(float n, double rd) { return (float)((double)n * rd); }
+
+// Per-face record for `face_hit_rec`: vertices + the per-face reciprocals.  A degenerate edge (squared length <= 1e-8,
+// geometry_utils.cuh:345: the distance to the edge is the distance to its end point) is marked by a NEGATIVE reciprocal.
+struct FaceRec {
+  f3 v0, v1, v2;
+  double rd_area;                // 1 / bary_area(v0, v1, v2)
+  double rd_l01, rd_l02, rd_l12;  // 1 / |v1 - v0|^2 etc., < 0 when the edge is degenerate
+  bool wide;                      // magnitudes beyond the ordinary: per-pixel reciprocals need the f64 seed
+};
+
+P3D_HD double edge_recip(f2 a, f2 b) {
+  const float bax = b.x - a.x;
+  const float bay = b.y - a.y;
+  const float l2 = bax * bax + bay * bay;
+  return ((double)l2 <= P3D_KEPS) ? -1.0 : recip_for_div_wide(l2);
+}
+
+P3D_HD void face_rec_make(f3 v0, f3 v1, f3 v2, FaceRec* r) {
+  const f2 a = mk2(v0.x, v0.y), b = mk2(v1.x, v1.y), c = mk2(v2.x, v2.y);
+  const float area = bary_area(a, b, c);
+  r->v0 = v0;
+  r->v1 = v1;
+  r->v2 = v2;
+  r->rd_area = recip_for_div_wide(area);
+  r->rd_l01 = edge_recip(a, b);
+  r->rd_l02 = edge_recip(a, c);
+  r->rd_l12 = edge_recip(b, c);
+  const float big = fmaxf(fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v1.x), fabsf(v1.y))),
+                          fmaxf(fmaxf(fabsf(v2.x), fabsf(v2.y)), max3(fabsf(v0.z), fabsf(v1.z), fabsf(v2.z))));
+  // Ordinary: |x|, |y|, z <= 1024 and |area| >= 1e-9 bound the perspective denominator by 1e22 and the clip sum by
+  // 3e30 (both are >= 1e-8 by construction), inside v_rcp_f32's range.  !(x <= y) also catches NaN.
+  r->wide = !((big <= 1024.0f) & (fabsf(area) >= 1e-9f));
+}
+
+// seg_dist2 with the edge's reciprocal: same value as seg_dist2(p, a, b)
+P3D_HD float seg_dist2_rec(f2 p, f2 a, f2 b, double rd_l2) {
+  const float bax = b.x - a.x;
+  const float bay = b.y - a.y;
+  float t = exact_div(bax * (p.x - a.x) + bay * (p.y - a.y), rd_l2);
+  const float ex = p.x - b.x;
+  const float ey = p.y - b.y;
+  const float d_point = ex * ex + ey * ey;
+  t = sat01(t);
+  const float dx = (a.x + t * bax) - p.x;
+  const float dy = (a.y + t * bay) - p.y;
+  const float d_seg = dx * dx + dy * dy;
+  return (rd_l2 < 0.0) ? d_point : d_seg;
+}
+
+// face_hit on a FaceRec: identical outputs, 12 divisions -> 12 (cvt, mul_f64, cvt) + 2 reciprocals.
+P3D_HD bool face_hit_rec(const FaceRec& r, f2 p, float blur_radius, bool perspective_correct, bool clip_bary,
+                         FaceHit* out) {
+  const f2 a = mk2(r.v0.x, r.v0.y);
+  const f2 b = mk2(r.v1.x, r.v1.y);
+  const f2 c = mk2(r.v2.x, r.v2.y);
+  const f3 bw = mk3(exact_div(edge_fn(p, b, c), r.rd_area), exact_div(edge_fn(p, c, a), r.rd_area),
+                    exact_div(edge_fn(p, a, b), r.rd_area));
+  f3 bp = bw;
+  if (perspective_correct) {
+    const float t0 = bw.x * r.v1.z * r.v2.z;
+    const float t1 = r.v0.z * bw.y * r.v2.z;
+    const float t2 = r.v0.z * r.v1.z * bw.z;
+    const float denom = fmaxf(t0 + t1 + t2, (float)P3D_KEPS);
+    const double rd = r.wide ? recip_for_div_wide(denom) : recip_for_div(denom);
+    bp = mk3(exact_div(t0, rd), exact_div(t1, rd), exact_div(t2, rd));
+  }
+  f3 bc = bp;
+  if (clip_bary) {
+    const float w0 = bp.x > 0.0f ? bp.x : 0.0f;
+    const float w1 = bp.y > 0.0f ? bp.y : 0.0f;
+    const float w2 = bp.z > 0.0f ? bp.z : 0.0f;
+    float s = w0 + w1 + w2;
+    s = fmaxf(s, 1e-5f);
+    const double rd = r.wide ? recip_for_div_wide(s) : recip_for_div(s);
+    bc = mk3(exact_div(w0, rd), exact_div(w1, rd), exact_div(w2, rd));
+  }
+  const float pz = bc.x * r.v0.z + bc.y * r.v1.z + bc.z * r.v2.z;
+  const float e01 = seg_dist2_rec(p, a, b, r.rd_l01);
+  const float e02 = seg_dist2_rec(p, a, c, r.rd_l02);
+  const float e12 = seg_dist2_rec(p, b, c, r.rd_l12);
+  const float dist = fminf(fminf(e01, e02), e12);
+  const bool inside = (bp.x > 0.0f) & (bp.y > 0.0f) & (bp.z > 0.0f);
+  const bool hit = !(pz < 0.0f) & (inside | !(dist >= blur_radius));
+  out->z = pz;
+  out->dist = inside ? -dist : dist;
+  out->bary = bc;
+  return hit;
+}
+
+// ---------------------------------------------------------------------------
+// Conservative rectangle-vs-face reject for the fine rasterizers' culling stages: true only if NO pixel centre
+// in [x0, x1] x [y0, y1] can be hit by the face, i.e. every point of the rectangle is outside the triangle AND
+// farther than sqrt(blur) from it.  Two sufficient conditions: (1) the rectangle is farther than r from the
+// triangle's bounding box (Euclidean: rounds the corners of the blur-expanded box); (2) the rectangle lies beyond
+// one edge LINE by more than r.  `m` absorbs the float error of these tests and of the reference's own inside /
+// distance arithmetic (both ~1e-6 for coordinates of a few units); faces with larger coordinates are never
+// rejected here.  A reject only skips work; results never depend on it.
+// ---------------------------------------------------------------------------
+P3D_HD bool rect_cannot_hit(f2 a, f2 b, f2 c, float x0, float x1, float y0, float y1, float r) {
+  const float big = fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(b.x), fabsf(b.y))), fmaxf(fabsf(c.x), fabsf(c.y)));
+  const float rm = r + (2e-5f + 1e-4f * r);
+  const float rm2 = rm * rm;
+  // (1) distance to the bounding box
+  const float gx = fmaxf(fmaxf(min3(a.x, b.x, c.x) - x1, x0 - max3(a.x, b.x, c.x)), 0.0f);
+  const float gy = fmaxf(fmaxf(min3(a.y, b.y, c.y) - y1, y0 - max3(a.y, b.y, c.y)), 0.0f);
+  const bool miss_box = gx * gx + gy * gy > rm2;
+  bool miss = false;
+  // (2) beyond an edge line.  s * edge_fn(p, u, v) > 0 on the inner side of edge (u, v), s = sign of the area.
+  const float area = edge_fn(c, a, b);
+  const float s = area < 0.0f ? -1.0f : 1.0f;
+#define P3D_EDGE_MISS(u, v)                                                                      \
+  {                                                                                              \
+    const float A = s * (v.y - u.y), B = -s * (v.x - u.x);                                       \
+    const float f = A * ((A > 0.0f ? x1 : x0) - u.x) + B * ((B > 0.0f ? y1 : y0) - u.y);         \
+    miss = miss | ((f < 0.0f) & (f * f > rm2 * (A * A + B * B)));                                \
+  }
+  P3D_EDGE_MISS(b, c)
+  P3D_EDGE_MISS(c, a)
+  P3D_EDGE_MISS(a, b)
+#undef P3D_EDGE_MISS
+  return (big <= 8.0f) & (miss_box | (miss & (fabsf(area) >= 1e-7f)));
+}
+
+// ---------------------------------------------------------------------------
 // Backward pieces (geometry_utils.cuh:54-64, 101-161, 200-228, 273-329,
 // 365-385, 421-462).  Gradients are tolerance-gated, the expression order is
 // kept anyway; pow(x, 2.0f) is written x*x.

@@ -48,8 +48,7 @@ struct MeshArgs {
   TileMap tm;
   float blur, sqrt_blur;
   int persp, clip, cull;
-  int debug;  // P3D_DEBUG_FWD ablation bits (profiles/ablate.py): 1 no per-pixel evaluation, 2 no queue insertion, 4 no stores, 16 no depth cull, 32 no front-to-back order, 64 print work statistics (build with -DP3D_FWD_STATS), 128 no bin permutation, 512 caller's bin geometry instead of tile-sized bins
-  unsigned long long* counters;  // debug bit 64: per-launch statistics (see launch_mesh_raster)
+  int debug;  // P3D_DEBUG_FWD ablation bits (profiles/ablate.py): 1 no per-pixel evaluation, 2 no queue insertion, 4 no stores, 16 no depth cull, 32 no front-to-back order, 64 background tiles stored per lane instead of cooperatively, 128 no bin permutation, 256 no rectangle-vs-face prune, 512 caller's bin geometry instead of tile-sized bins, 2048 background tiles store nothing, 4096 tiles with faces do nothing, 8192 every tile is background, 16384 staging only (no candidate loop), 32768 every chunk takes the general (neighbour rule) loop
   int64_t* p2f;
   float* zbuf;
   float* bary;
@@ -236,13 +235,218 @@ __device__ __forceinline__ void write_subtile_fill_patch(const MeshArgs& a, cons
   }
 }
 
+// Background tile with K % 4 == 0: the 16x16 tile's rows of the four outputs are filled with -1 in memory order by all
+// 256 threads -- every store instruction of a wave covers one contiguous 1 KiB piece (a lane writing its own pixel's
+// K-row stores 16 bytes at a stride of 4*K..12*K).  Per tile row the outputs hold cols*K floats (zbuf, dists),
+// 3*cols*K floats (bary) and cols*K int64 (pix_to_face) = 7 * cols*K/4 16-byte pieces.
+__device__ __forceinline__ void fill_tile_background(const MeshArgs& a, int n, int ty0, int tx0, int y_end, int x_end,
+                                                     int tid) {
+  const int H = a.H, W = a.W, K = a.K;
+  const int rows = min(kTile, y_end - ty0), cols = min(kTile, x_end - tx0);
+  const int q4 = (cols * K) >> 2;       // 16-byte pieces of one tile row of zbuf
+  const int per_row = 7 * q4;           // zbuf q4 | dists q4 | bary 3 q4 | p2f 2 q4
+  const int64_t col0 = W - tx0 - cols;  // outputs are stored flipped: x_out = W-1-x
+  for (int r = 0; r < rows; ++r) {
+    const int64_t px = ((int64_t)n * H + (H - 1 - (ty0 + r))) * W + col0;
+    for (int e = tid; e < per_row; e += kStage) {
+      // branch-free choice of (output, piece): lanes of one wave straddle the boundaries between the outputs
+      const bool in_z = e < q4, in_d = e < 2 * q4, in_b = e < 5 * q4;
+      char* base = in_z ? reinterpret_cast<char*>(a.zbuf + px * K)
+                        : (in_d ? reinterpret_cast<char*>(a.dists + px * K)
+                                : (in_b ? reinterpret_cast<char*>(a.bary + px * K * 3) : reinterpret_cast<char*>(a.p2f + px * K)));
+      const int piece = e - (in_z ? 0 : (in_d ? q4 : (in_b ? 2 * q4 : 5 * q4)));
+      const unsigned v = in_b ? 0xbf800000u : ~0u;  // four -1.0f, or two int64 -1 (a select of two uint4 constants compiles to a scratch array)
+      *reinterpret_cast<uint4*>(base + (size_t)piece * 16) = make_uint4(v, v, v, v);
+    }
+  }
+}
+
+// Staged face in LDS: five 16-byte words, each read by a wave as one broadcast (all lanes, same address).
+//   [0] v0x v0y v1x v1y   [1] v2x v2y z0 z1   [2] z2 fid nb wide   [3] rd_area, rd_l01 (doubles)   [4] rd_l02, rd_l12
+constexpr int kRecWords = 5;
+
+// One 64-face group of a staged chunk against one wave's 8x8 sub-tile: every candidate is evaluated on its FaceRec
+// (shared-reciprocal arithmetic, p3d_geom.h: same bits as the reference's expression tree).  GENERAL adds the
+// clipped-neighbour rule (rasterize_meshes.cu:186-215).  Two instantiations, chosen per tile region (see the kernel):
+// with the rule in the common loop body the compiler copies the whole queue (48 moves) after every hit to feed the
+// rule's control flow.
+template <bool GENERAL, typename Queue>
+__device__ __forceinline__ void eval_candidates(const MeshArgs& a, Queue& q, unsigned long long cand, int oj, f2 p,
+                                                bool pix_ok, bool persp, bool clip, const float4* s_box,
+                                                const float4 (*s_rec)[kRecWords], const float* s_zc) {
+  const int K = a.K;
+  while (cand) {
+    const int jj = __builtin_amdgcn_readlane(oj, __builtin_ctzll(cand));
+    cand &= cand - 1;
+    // all LDS reads of this candidate are issued together (one round trip instead of dependent ones)
+    const float4 b = s_box[jj];
+    const float zc = s_zc[jj];
+    const float4 r0 = s_rec[jj][0], r1 = s_rec[jj][1], r2 = s_rec[jj][2];
+    const bool out = p.x > b.y || p.x < b.x || p.y > b.w || p.y < b.z;
+    const bool too_deep = zc > q.kth_z(K) && !(P3D_DBG(a) & 16);
+    if (pix_ok && !out && !too_deep && !(P3D_DBG(a) & 1)) {
+      const int f = __float_as_int(r2.y);
+      FaceHit h;
+      bool hit;
+      {
+        const double2 d0 = *reinterpret_cast<const double2*>(&s_rec[jj][3]);
+        const double2 d1 = *reinterpret_cast<const double2*>(&s_rec[jj][4]);
+        FaceRec fr;
+        fr.v0 = mk3(r0.x, r0.y, r1.z);
+        fr.v1 = mk3(r0.z, r0.w, r1.w);
+        fr.v2 = mk3(r1.x, r1.y, r2.x);
+        fr.rd_area = d0.x;
+        fr.rd_l01 = d0.y;
+        fr.rd_l02 = d1.x;
+        fr.rd_l12 = d1.y;
+        fr.wide = __float_as_int(r2.w) != 0;
+        hit = face_hit_rec(fr, p, a.blur, persp, clip, &h);
+      }
+      if (hit) {
+        const float pl[kMeshPayload] = {h.dist, h.bary.x, h.bary.y, h.bary.z};
+        bool ins = true;
+        if constexpr (GENERAL) {
+          const int nb = __float_as_int(r2.z);
+          if (nb != -1) {
+            // clipped-face neighbour rule (rasterize_meshes.cu:186-215, rasterize_meshes_cpu.cpp:249-277): at most one of
+            // the two halves of a split face stays in the queue -- the one closer to the pixel.
+            const int at = q.find(nb);
+            if (at >= 0) {
+              if (fabsf(h.dist) < fabsf(q.payload_at(0, at)))
+                q.erase(at);
+              else
+                ins = false;
+            }
+          }
+        }
+        // a candidate that sorts after the K-th entry of a full queue would fall straight off the end of the insertion
+        // network: skip the network for it
+        if (ins && q.admits(K, h.z, f) && !(P3D_DBG(a) & 2)) q.insert(K, h.z, f, pl);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+struct StageLds {
+  float4* box;
+  float4 (*rec)[kRecWords];
+  float* zc;
+  int* order;
+  float* qlow;
+  ChunkOrderScratch* ord;
+  int* wcnt;
+};
+
+struct TileRect {
+  float x0, x1, y0, y1;  // pixel-centre extent of the workgroup's tile (NDC)
+};
+
+// Stage up to 256 faces of the tile's list into LDS: per-face setup (done once per workgroup -- the reference redoes it
+// per pixel), tile cull, ordered compaction (ballot + mbcnt), FaceRec.  Returns the number of staged faces;
+// *general = some staged face has a clipped neighbour (workgroup-uniform).  Ends with a barrier.
+template <bool BINNED>
+__device__ __forceinline__ int stage_chunk(const MeshArgs& a, const StageLds& l, const TileRect& tile, int64_t src_base,
+                                           int count, int base, int tid, bool cull, bool clip, bool prune, bool* general) {
+  const int lane = tid & 63, w = tid >> 6;
+  const int i = base + tid;
+  bool keep = false;
+  f3 v0, v1, v2;
+  FaceSetup fs;
+  int fid = -1, nb = -1;
+  if (i < count) {
+    fid = BINNED ? a.csr.list[src_base + i] : (int)(src_base + i);
+    const float* g = a.face_verts + (int64_t)fid * 9;
+    nb = (int)a.neighbor[fid];  // requested together with the vertices: one memory round trip, not two
+    v0 = mk3(g[0], g[1], g[2]);
+    v1 = mk3(g[3], g[4], g[5]);
+    v2 = mk3(g[6], g[7], g[8]);
+    fs = face_setup(v0, v1, v2, a.sqrt_blur, cull);
+    const bool off_tile = tile.x0 > fs.xhi || tile.x1 < fs.xlo || tile.y0 > fs.yhi || tile.y1 < fs.ylo;
+    keep = !fs.reject && !off_tile;
+    if (keep && prune)
+      keep = !rect_cannot_hit(mk2(v0.x, v0.y), mk2(v1.x, v1.y), mk2(v2.x, v2.y), tile.x0, tile.x1, tile.y0, tile.y1, a.sqrt_blur);
+  }
+  const unsigned long long km = __ballot(keep);
+  if (lane == 0) l.wcnt[w] = __popcll(km);
+  __syncthreads();
+  int pos = mask_rank(km);
+  int staged = 0;
+#pragma unroll
+  for (int j = 0; j < kStage / kWave; ++j) {
+    const int c = l.wcnt[j];
+    if (j < w) pos += c;
+    staged += c;
+  }
+  bool gen = false;
+  if (keep) {
+    FaceRec fr;
+    face_rec_make(v0, v1, v2, &fr);
+    gen = nb != -1 || (P3D_DBG(a) & 32768);
+    l.box[pos] = make_float4(fs.xlo, fs.xhi, fs.ylo, fs.yhi);
+    l.rec[pos][0] = make_float4(v0.x, v0.y, v1.x, v1.y);
+    l.rec[pos][1] = make_float4(v2.x, v2.y, v0.z, v1.z);
+    l.rec[pos][2] = make_float4(v2.z, __int_as_float(fid), __int_as_float(nb), __int_as_float(fr.wide ? 1 : 0));
+    double2 d0, d1;
+    d0.x = fr.rd_area;
+    d0.y = fr.rd_l01;
+    d1.x = fr.rd_l02;
+    d1.y = fr.rd_l12;
+    *reinterpret_cast<double2*>(&l.rec[pos][3]) = d0;
+    *reinterpret_cast<double2*>(&l.rec[pos][4]) = d1;
+    // Depth cull (exact): with clipped barycentrics a sample's depth is a convex combination of
+    // the vertex depths, so pz >= zmin * (1 - 4e-7) in float arithmetic (three roundings each in
+    // the normalisation and the dot product); a lane whose queue is full with K-th depth below
+    // that bound can never admit the face.  Not applicable when barycentrics are unclipped (pz may
+    // leave [zmin, zmax]), when the face has a clipped neighbour (it may REPLACE a queued entry,
+    // rasterize_meshes.cu:186-215), or for depths so small that bary_clip's 1e-5 floor could bite.
+    const float zmin = min3(v0.z, v1.z, v2.z);
+    l.zc[pos] = (clip && nb == -1 && zmin >= 1e-3f) ? zmin * 0.999998f : -INFINITY;
+  }
+  // also the barrier that publishes the staged records
+  *general = __syncthreads_or(gen ? 1 : 0) != 0;
+  return staged;
+}
+
+struct SubTile {
+  float x0, x1, y0, y1;  // pixel-centre extent of the wave's 8x8 sub-tile (NDC)
+};
+
+// One wave's pass over a staged chunk: sub-tile cull 64 faces at a time (one lane per face), then the per-pixel loop.
+template <bool GENERAL, typename Queue>
+__device__ __forceinline__ void wave_chunk(const MeshArgs& a, Queue& q, int staged, bool sorted, const SubTile& st, f2 p,
+                                           bool pix_ok, int lane, bool persp, bool clip, bool prune, const float4* s_box,
+                                           const float4 (*s_rec)[kRecWords], const float* s_zc, const int* s_order,
+                                           const float* s_qlow) {
+  const int K = a.K;
+  for (int jb = 0; jb < staged; jb += kWave) {
+    // sorted chunk: once the nearest remaining face is too deep for every pixel of this wave, so is everything behind it
+    if (sorted && __ballot(pix_ok && !(s_qlow[jb] > q.kth_z(K))) == 0) break;
+    const int j = jb + lane;
+    bool touch = false;
+    int oj = 0;
+    if (j < staged) {
+      oj = s_order[j];
+      const float4 b = s_box[oj];
+      touch = !(st.x0 > b.y || st.x1 < b.x || st.y0 > b.w || st.y1 < b.z);
+      if (touch && prune) {
+        const float4 r0 = s_rec[oj][0], r1 = s_rec[oj][1];
+        touch = !rect_cannot_hit(mk2(r0.x, r0.y), mk2(r0.z, r0.w), mk2(r1.x, r1.y), st.x0, st.x1, st.y0, st.y1, a.sqrt_blur);
+      }
+    }
+    const unsigned long long cand = __ballot(touch);
+    eval_candidates<GENERAL, Queue>(a, q, cand, oj, p, pix_ok, persp, clip, s_box, s_rec, s_zc);
+  }
+}
+
 template <typename Queue, int KT, bool IN_REGS, bool BINNED>
 __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_kernel(MeshArgs a) {
-  __shared__ float4 s_box[kStage];       // xlo, xhi, ylo, yhi (blur-expanded)
-  __shared__ float4 s_vert[kStage][3];   // v0x v0y v0z v1x | v1y v1z v2x v2y | v2z idx nb -
-  __shared__ __align__(16) float s_zc[kStage];  // depth-cull key: every sample of the face has z >= s_zc (or -inf)
-  __shared__ int s_order[kStage];        // visiting order of the staged faces: ascending s_zc (by bucket) when order is free
-  __shared__ float s_qlow[kStage];       // lower bound of s_zc over sorted positions >= i
+  __shared__ float4 s_box[kStage];                  // xlo, xhi, ylo, yhi (blur-expanded)
+  __shared__ float4 s_rec[kStage][kRecWords];       // see kRecWords
+  __shared__ __align__(16) float s_zc[kStage];      // depth-cull key: every sample of the face has z >= s_zc (or -inf)
+  __shared__ int s_order[kStage];                   // visiting order of the staged faces: ascending s_zc (by bucket) when order is free
+  __shared__ float s_qlow[kStage];                  // lower bound of s_zc over sorted positions >= i
   __shared__ ChunkOrderScratch s_ord;
   __shared__ int s_wcnt[kStage / kWave];
 
@@ -270,21 +474,28 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
   int64_t src_base;
   int count;
   if (BINNED) {
+    // both words of the bin's CSR row are requested at once (offset has rows + 1 entries, so the load is always valid)
     const int64_t row = ((int64_t)n * a.tm.BH + by) * a.tm.BW + bx;
     count = a.csr.total[row];
-    src_base = count > 0 ? a.csr.offset[row] : 0;
+    src_base = a.csr.offset[row];
   } else {
     src_base = a.mesh_first[n];
     count = (int)a.mesh_count[n];
   }
+  if (P3D_DBG(a) & 8192) count = 0;            // ablation: every tile is treated as background (pure fill)
+  if ((P3D_DBG(a) & 4096) && count > 0) return;  // ablation: tiles with faces do nothing at all
   if (count <= 0) {
-    // background tile (4 of 5 at the bench workload): nothing but the -1 stores; skip the NDC set-up below
-    if (!(P3D_DBG(a) & 4)) {
-      Queue e;
-      e.init();
-      if (IN_REGS && a.K == KT) {
+    // background tile (3 of 5 at the bench workload): nothing but the -1 stores; skip the NDC set-up below
+    if (!(P3D_DBG(a) & 4) && !(P3D_DBG(a) & 2048)) {
+      if ((a.K & 3) == 0 && !(P3D_DBG(a) & 64)) {
+        fill_tile_background(a, n, ty0, tx0, y_end, x_end, tid);
+      } else if (IN_REGS && a.K == KT) {
+        Queue e;
+        e.init();
         if (pix_ok) write_pixel<Queue, KT, IN_REGS>(a, e, ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi));
       } else if (wave_ok) {
+        Queue e;
+        e.init();
         write_subtile_fill_patch<Queue, KT, IN_REGS>(a, e, false, n, sy0, sx0, y_end, x_end, lane, pix_ok, yi, xi);
       }
     }
@@ -293,184 +504,75 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
 
   const f2 p = mk2(pix_to_ndc(xi, W, H), pix_to_ndc(yi, H, W));
   // pixel-centre extents (pix_to_ndc is monotone in the pixel index)
-  const float tile_x0 = pix_to_ndc(tx0, W, H), tile_x1 = pix_to_ndc(min(tx0 + kTile, x_end) - 1, W, H);
-  const float tile_y0 = pix_to_ndc(ty0, H, W), tile_y1 = pix_to_ndc(min(ty0 + kTile, y_end) - 1, H, W);
-  const float sub_x0 = pix_to_ndc(sx0, W, H), sub_x1 = pix_to_ndc(min(sx0 + 8, x_end) - 1, W, H);
-  const float sub_y0 = pix_to_ndc(sy0, H, W), sub_y1 = pix_to_ndc(min(sy0 + 8, y_end) - 1, H, W);
+  // wave-uniform values: keep them in SGPRs (the divisions inside pix_to_ndc leave them in VGPRs otherwise)
+  const float tile_x0 = uniform_f(pix_to_ndc(tx0, W, H)), tile_x1 = uniform_f(pix_to_ndc(min(tx0 + kTile, x_end) - 1, W, H));
+  const float tile_y0 = uniform_f(pix_to_ndc(ty0, H, W)), tile_y1 = uniform_f(pix_to_ndc(min(ty0 + kTile, y_end) - 1, H, W));
+  const float sub_x0 = uniform_f(pix_to_ndc(sx0, W, H)), sub_x1 = uniform_f(pix_to_ndc(min(sx0 + 8, x_end) - 1, W, H));
+  const float sub_y0 = uniform_f(pix_to_ndc(sy0, H, W)), sub_y1 = uniform_f(pix_to_ndc(min(sy0 + 8, y_end) - 1, H, W));
 
   Queue q;
   q.init();
   const int K = a.K;
-#ifdef P3D_FWD_STATS
-  unsigned long long c_cand = 0, c_body = 0, c_lanes = 0, c_hit = 0, c_ins = 0, c_staged = 0, c_groups = 0, c_body_hit = 0,
-                     c_body_ins = 0, c_chunks = 0;
-#define P3D_STAT(x) x
-#else
-#define P3D_STAT(x)
-#endif
   const bool persp = a.persp != 0, clip = a.clip != 0, cull = a.cull != 0;
+  const bool prune = !(P3D_DBG(a) & 256);
+  StageLds lds;
+  lds.box = s_box;
+  lds.rec = s_rec;
+  lds.zc = s_zc;
+  lds.order = s_order;
+  lds.qlow = s_qlow;
+  lds.ord = &s_ord;
+  lds.wcnt = s_wcnt;
+  TileRect tile;
+  tile.x0 = tile_x0;
+  tile.x1 = tile_x1;
+  tile.y0 = tile_y0;
+  tile.y1 = tile_y1;
+  SubTile st;
+  st.x0 = sub_x0;
+  st.x1 = sub_x1;
+  st.y0 = sub_y0;
+  st.y1 = sub_y1;
+  const bool run_waves = wave_ok && !(P3D_DBG(a) & 16384);
 
-  for (int base = 0; base < count; base += kStage) {
-    // ---- stage: per-face setup, tile cull, ordered compaction into LDS -------------------
-    const int i = base + tid;
-    bool keep = false;
-    f3 v0, v1, v2;
-    FaceSetup fs;
-    int fid = -1;
-    if (i < count) {
-      fid = BINNED ? a.csr.list[src_base + i] : (int)(src_base + i);
-      const float* g = a.face_verts + (int64_t)fid * 9;
-      v0 = mk3(g[0], g[1], g[2]);
-      v1 = mk3(g[3], g[4], g[5]);
-      v2 = mk3(g[6], g[7], g[8]);
-      fs = face_setup(v0, v1, v2, a.sqrt_blur, cull);
-      const bool off_tile = tile_x0 > fs.xhi || tile_x1 < fs.xlo || tile_y0 > fs.yhi || tile_y1 < fs.ylo;
-      keep = !fs.reject && !off_tile;
-    }
-    const unsigned long long km = __ballot(keep);
-    if (lane == 0) s_wcnt[w] = __popcll(km);
-    __syncthreads();
-    int pos = mask_rank(km);
-    int staged = 0;
-#pragma unroll
-    for (int j = 0; j < kStage / kWave; ++j) {
-      const int c = s_wcnt[j];
-      if (j < w) pos += c;
-      staged += c;
-    }
-    bool has_nb = false;
-    if (keep) {
-      const int nb = (int)a.neighbor[fid];
-      has_nb = nb != -1;
-      s_box[pos] = make_float4(fs.xlo, fs.xhi, fs.ylo, fs.yhi);
-      s_vert[pos][0] = make_float4(v0.x, v0.y, v0.z, v1.x);
-      s_vert[pos][1] = make_float4(v1.y, v1.z, v2.x, v2.y);
-      s_vert[pos][2] = make_float4(v2.z, __int_as_float(fid), __int_as_float(nb), 0.0f);
-      // Depth cull (exact): with clipped barycentrics a sample's depth is a convex combination of
-      // the vertex depths, so pz >= zmin * (1 - 4e-7) in float arithmetic (three roundings each in
-      // the normalisation and the dot product); a lane whose queue is full with K-th depth below
-      // that bound can never admit the face.  Not applicable when barycentrics are unclipped (pz may
-      // leave [zmin, zmax]), when the face has a clipped neighbour (it may REPLACE a queued entry,
-      // rasterize_meshes.cu:186-215), or for depths so small that bary_clip's 1e-5 floor could bite.
-      const float zmin = min3(v0.z, v1.z, v2.z);
-      s_zc[pos] = (clip && nb == -1 && zmin >= 1e-3f) ? zmin * 0.999998f : -INFINITY;
-    }
-    // The K nearest under the total order (z, face index) do not depend on the order faces are
-    // offered in -- except through the clipped-neighbour rule.  A staged chunk without neighbour
-    // faces is therefore visited front to back (ascending depth key), which lets the depth cull
-    // discard almost everything behind the first K layers; a chunk with neighbour faces keeps
-    // the reference's ascending-index order.
-    const bool sorted = __syncthreads_or(has_nb ? 1 : 0) == 0 && !(P3D_DBG(a) & 32);
-    if (sorted) {
+  // Two loop nests, entered one after the other and never re-entered: chunks are processed by the FAST nest (shared-
+  // reciprocal evaluation, front-to-back order) until the first chunk that holds a face with a clipped neighbour;
+  // from that chunk on the GENERAL nest (the same evaluation + the neighbour rule, ascending index order) finishes
+  // the tile.  Per-chunk switching back and forth would be equally exact, but with both bodies inside one
+  // loop the register allocator spills the queue (150 VGPRs of scratch, and every wave of the launch -- background
+  // tiles included -- then pays for scratch set-up: the pure fill ran 0.94 -> 1.7 ms).
+  int base = 0;
+  bool general = false;
+  int staged = 0;
+  for (; base < count; base += kStage) {
+    staged = stage_chunk<BINNED>(a, lds, tile, src_base, count, base, tid, cull, clip, prune, &general);
+    if (general) break;  // uniform
+    if (!(P3D_DBG(a) & 32)) {
       chunk_bucket_order(s_zc, staged, s_order, s_qlow, s_ord, tid);
     } else {
       if (tid < staged) s_order[tid] = tid;
       __syncthreads();
     }
-
-    P3D_STAT(c_staged += staged);
-    P3D_STAT(++c_chunks);
-    // ---- per wave: sub-tile cull 64 faces at a time, then per-pixel evaluation -----------
-    if (wave_ok) {
-      for (int jb = 0; jb < staged; jb += kWave) {
-        // sorted chunk: once the nearest remaining face is too deep for every pixel of this wave,
-        // so is everything behind it
-        if (sorted && __ballot(pix_ok && !(s_qlow[jb] > q.kth_z(K))) == 0) break;
-        P3D_STAT(++c_groups);
-        const int j = jb + lane;
-        bool touch = false;
-        int oj = 0;
-        if (j < staged) {
-          oj = s_order[j];
-          const float4 b = s_box[oj];
-          touch = !(sub_x0 > b.y || sub_x1 < b.x || sub_y0 > b.w || sub_y1 < b.z);
-        }
-        unsigned long long cand = __ballot(touch);
-        while (cand) {
-          const int jj = __builtin_amdgcn_readlane(oj, __builtin_ctzll(cand));
-          cand &= cand - 1;
-          P3D_STAT(++c_cand);
-          // all LDS reads of this candidate are issued together (one round trip instead of three dependent ones)
-          const float4 b = s_box[jj];
-          const float zc = s_zc[jj];
-          const float4 r0 = s_vert[jj][0], r1 = s_vert[jj][1], r2 = s_vert[jj][2];
-          const bool out = p.x > b.y || p.x < b.x || p.y > b.w || p.y < b.z;
-          const bool too_deep = zc > q.kth_z(K) && !(P3D_DBG(a) & 16);
-#ifdef P3D_FWD_STATS
-          if (P3D_DBG(a) & 64) {
-            const unsigned long long m = __ballot(pix_ok && !out && !too_deep);
-            c_body += m != 0;
-            c_lanes += __popcll(m);
-          }
-#endif
-#ifdef P3D_FWD_STATS
-          bool st_hit = false, st_ins = false;
-#endif
-          if (pix_ok && !out && !too_deep && !(P3D_DBG(a) & 1)) {
-            const f3 a0 = mk3(r0.x, r0.y, r0.z);
-            const f3 a1 = mk3(r0.w, r1.x, r1.y);
-            const f3 a2 = mk3(r1.z, r1.w, r2.x);
-            FaceHit h;
-            if (face_hit(a0, a1, a2, p, a.blur, persp, clip, &h)) {
-              P3D_STAT(++c_hit);
-              P3D_STAT(st_hit = true);
-              const int f = __float_as_int(r2.y);
-              const int nb = __float_as_int(r2.z);
-              const float pl[kMeshPayload] = {h.dist, h.bary.x, h.bary.y, h.bary.z};
-              bool ins = true;
-              if (nb != -1) {
-                // clipped-face neighbour rule (rasterize_meshes.cu:186-215,
-                // rasterize_meshes_cpu.cpp:249-277): at most one of the two halves of a split
-                // face stays in the queue -- the one closer to the pixel.
-                const int at = q.find(nb);
-                if (at >= 0) {
-                  if (fabsf(h.dist) < fabsf(q.payload_at(0, at)))
-                    q.erase(at);
-                  else
-                    ins = false;
-                }
-              }
-              // a candidate that sorts after the K-th entry of a full queue would fall straight
-              // off the end of the insertion network: skip the network for it
-              if (ins && q.admits(K, h.z, f) && !(P3D_DBG(a) & 2)) {
-                P3D_STAT(++c_ins);
-                P3D_STAT(st_ins = true);
-                q.insert(K, h.z, f, pl);
-              }
-            }
-          }
-#ifdef P3D_FWD_STATS
-          if (P3D_DBG(a) & 64) {
-            c_body_hit += __ballot(st_hit) != 0;
-            c_body_ins += __ballot(st_ins) != 0;
-          }
-#endif
-        }
-      }
-    }
+    if (run_waves)
+      wave_chunk<false, Queue>(a, q, staged, !(P3D_DBG(a) & 32), st, p, pix_ok, lane, persp, clip, prune, s_box, s_rec, s_zc, s_order,
+                               s_qlow);
     __syncthreads();
   }
-
-#ifdef P3D_FWD_STATS
-  if ((P3D_DBG(a) & 64) && a.counters) {
-    // [0] waves, [1] staged faces (per wave), [2] 64-face groups, [3] candidate iterations, [4] iterations whose
-    // body ran, [5] lanes active in those bodies, [6] lane-level hits, [7] lane-level insertions
-    if (lane == 0) {
-      atomicAdd(&a.counters[0], 1ull);
-      atomicAdd(&a.counters[1], c_staged);
-      atomicAdd(&a.counters[2], c_groups);
-      atomicAdd(&a.counters[3], c_cand);
-      atomicAdd(&a.counters[4], c_body);
-      atomicAdd(&a.counters[5], c_lanes);
-      atomicAdd(&a.counters[8], c_body_hit);
-      atomicAdd(&a.counters[9], c_body_ins);
-      atomicAdd(&a.counters[10], c_chunks);
-      atomicAdd(&a.counters[11], (unsigned long long)(c_body > 0));
+  if (general) {
+    for (;;) {
+      // chunk `base` is staged; faces keep ascending index order (the neighbour rule depends on it)
+      if (tid < staged) s_order[tid] = tid;
+      __syncthreads();
+      if (run_waves)
+        wave_chunk<true, Queue>(a, q, staged, false, st, p, pix_ok, lane, persp, clip, prune, s_box, s_rec, s_zc, s_order, s_qlow);
+      __syncthreads();
+      base += kStage;
+      if (base >= count) break;
+      bool dummy = false;
+      staged = stage_chunk<BINNED>(a, lds, tile, src_base, count, base, tid, cull, clip, prune, &dummy);
     }
-    atomicAdd(&a.counters[6], c_hit);
-    atomicAdd(&a.counters[7], c_ins);
   }
-#endif
+
   if (!(P3D_DBG(a) & 4)) {
     if (IN_REGS && K == KT) {
       if (pix_ok) write_pixel<Queue, KT, IN_REGS>(a, q, ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi));
@@ -492,32 +594,6 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
 #endif
   const unsigned grid = tile_grid(a.tm);
   const char* name = BINNED ? "mesh_fine" : "mesh_naive";
-  struct Stats {  // debug bit 64 only: synchronous, prints to stderr
-    unsigned long long* dev = nullptr;
-    hipStream_t s;
-    ~Stats() {
-      if (!dev) return;
-      unsigned long long h[12];
-      (void)hipStreamSynchronize(s);
-      (void)hipMemcpy(h, dev, sizeof(h), hipMemcpyDeviceToHost);
-      (void)hipFree(dev);
-      fprintf(stderr,
-              "[p3d fwd stats] waves %llu | staged faces/wave %.1f | groups/wave %.2f | candidate iters/wave %.1f | body "
-              "iters/wave %.1f | lanes per body %.1f | hits/lane %.2f | inserts/lane %.2f | bodies with a hit %.1f /wave | "
-              "bodies with an insertion %.1f /wave | chunks/wave %.2f | waves with any body %llu\n",
-              h[0], (double)h[1] / h[0], (double)h[2] / h[0], (double)h[3] / h[0], (double)h[4] / h[0],
-              h[4] ? (double)h[5] / h[4] : 0.0, (double)h[6] / (h[0] * 64.0), (double)h[7] / (h[0] * 64.0),
-              (double)h[8] / h[0], (double)h[9] / h[0], (double)h[10] / h[0], h[11]);
-    }
-  } stats;
-  stats.s = stream;
-  a.counters = nullptr;
-  if (P3D_DBG(a) & 64) {
-    // ablation only (P3D_DEBUG_FWD bit 64 in a -DP3D_FWD_STATS build): the one place that allocates and synchronises
-    if (hipMalloc(&stats.dev, 12 * sizeof(unsigned long long)) != hipSuccess) stats.dev = nullptr;
-    if (stats.dev) (void)hipMemsetAsync(stats.dev, 0, 12 * sizeof(unsigned long long), stream);
-    a.counters = stats.dev;
-  }
   LaunchScope ls(name, stream);
   const int K = a.K;
   if (K == 1)

@@ -12,9 +12,12 @@
 
 using namespace p3d;
 
+// `rect`: when non-null, the fine kernel's fast path is exercised instead of the plain one -- faces that the
+// conservative rectangle test (rect_cannot_hit on rect = x0, x1, y0, y1 around the pixel) rejects are skipped, and faces
+// with a FaceRec are evaluated by face_hit_rec (shared reciprocals).  Results must not change.
 template <typename Queue>
 static void raster_pixel(const float* fv, const int64_t* nbr, int64_t f0, int64_t f1, f2 p, float blur, float sqrt_blur,
-                         int K, bool persp, bool clip, bool cull, Queue& q) {
+                         int K, bool persp, bool clip, bool cull, Queue& q, const float* rect = nullptr) {
   q.init();
   for (int64_t f = f0; f < f1; ++f) {
     const float* g = fv + f * 9;
@@ -22,7 +25,15 @@ static void raster_pixel(const float* fv, const int64_t* nbr, int64_t f0, int64_
     const FaceSetup fs = face_setup(v0, v1, v2, sqrt_blur, cull);
     if (fs.reject || outside_box(fs, p)) continue;
     FaceHit h;
-    if (!face_hit(v0, v1, v2, p, blur, persp, clip, &h)) continue;
+    if (rect) {
+      if (rect_cannot_hit(mk2(v0.x, v0.y), mk2(v1.x, v1.y), mk2(v2.x, v2.y), rect[0], rect[1], rect[2], rect[3], sqrt_blur))
+        continue;
+      FaceRec fr;
+      face_rec_make(v0, v1, v2, &fr);
+      if (!face_hit_rec(fr, p, blur, persp, clip, &h)) continue;
+    } else if (!face_hit(v0, v1, v2, p, blur, persp, clip, &h)) {
+      continue;
+    }
     const float pl[4] = {h.dist, h.bary.x, h.bary.y, h.bary.z};
     const int nb = (int)nbr[f];
     if (nb != -1) {
@@ -63,13 +74,25 @@ extern "C" int hg_rasterize_meshes(const float* fv, const int64_t* first, const 
         const f2 p = mk2(pix_to_ndc(xi, W, H), pix_to_ndc(yi, H, W));
         const int64_t o = (((int64_t)n * H + yo) * W + xo) * K;
         const int64_t f0 = first[n], f1 = first[n] + count[n];
-        if (!use_mem && K <= 8) {
+        // use_mem bit 1: the fast path, with the 8x8 pixel block around the pixel as the culling rectangle
+        float rect_v[4];
+        const float* rect = nullptr;
+        if (use_mem & 2) {
+          const int bx0 = xi & ~7, by0 = yi & ~7;
+          const int bx1 = (bx0 + 7 < W ? bx0 + 7 : W - 1), by1 = (by0 + 7 < H ? by0 + 7 : H - 1);
+          rect_v[0] = pix_to_ndc(bx0, W, H);
+          rect_v[1] = pix_to_ndc(bx1, W, H);
+          rect_v[2] = pix_to_ndc(by0, H, W);
+          rect_v[3] = pix_to_ndc(by1, H, W);
+          rect = rect_v;
+        }
+        if (!(use_mem & 1) && K <= 8) {
           TopKReg<8, 4> q;
-          raster_pixel(fv, nbr, f0, f1, p, blur, sqrt_blur, K, persp, clip, cull, q);
+          raster_pixel(fv, nbr, f0, f1, p, blur, sqrt_blur, K, persp, clip, cull, q, rect);
           emit(q, K, o, p2f, zbuf, bary, dists);
         } else {
           TopKMem<150, 4> q;
-          raster_pixel(fv, nbr, f0, f1, p, blur, sqrt_blur, K, persp, clip, cull, q);
+          raster_pixel(fv, nbr, f0, f1, p, blur, sqrt_blur, K, persp, clip, cull, q, rect);
           emit(q, K, o, p2f, zbuf, bary, dists);
         }
       }
@@ -114,4 +137,44 @@ extern "C" void hg_bin_rect(float xmin, float xmax, float ymin, float ymax, int 
   out4[1] = x1 - 1;
   out4[2] = y0;
   out4[3] = y1 - 1;
+}
+
+
+// exact_div property (p3d_geom.h): (float)((double)n * rd) == n / d for every rd within 1 ulp (double) of 1/d -- the
+// device's Newton-refined reciprocal is not correctly rounded.  Returns the number of mismatches over `trials` random
+// pairs (xorshift, mantissas and exponents drawn independently; every 4th pair has d's mantissa near all-ones / n's near
+// a rounding boundary pattern).
+extern "C" int64_t hg_exact_div_check(int64_t trials, uint64_t seed) {
+  uint64_t s = seed * 0x9E3779B97F4A7C15ull + 1;
+  auto next = [&]() {
+    s ^= s << 13;
+    s ^= s >> 7;
+    s ^= s << 17;
+    return s;
+  };
+  int64_t bad = 0;
+  for (int64_t t = 0; t < trials; ++t) {
+    const uint64_t r = next(), r2 = next();
+    uint32_t mn = (uint32_t)(r & 0x7fffff), md = (uint32_t)((r >> 23) & 0x7fffff);
+    if ((t & 3) == 3) {
+      md |= 0x7fff00;                 // long runs of ones
+      mn = (mn & 0xff) | ((uint32_t)(r2 >> 40) & 0x7f0000);
+    }
+    const uint32_t en = 127 - 30 + (uint32_t)(r2 % 60), ed = 127 - 30 + (uint32_t)((r2 >> 8) % 60);
+    uint32_t bn = (en << 23) | mn | ((uint32_t)(r2 >> 20) & 1u) << 31, bd = (ed << 23) | md | ((uint32_t)(r2 >> 21) & 1u) << 31;
+    float n, d;
+    memcpy(&n, &bn, 4);
+    memcpy(&d, &bd, 4);
+    const float want = n / d;
+    const double rd = 1.0 / (double)d;
+    uint64_t rb;
+    memcpy(&rb, &rd, 8);
+    for (int k = -1; k <= 1; ++k) {
+      const uint64_t pb = rb + (uint64_t)(int64_t)k;
+      double rp;
+      memcpy(&rp, &pb, 8);
+      if (exact_div(n, rp) != want) ++bad;
+    }
+  }
+  return bad;
 }
