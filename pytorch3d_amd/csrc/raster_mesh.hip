@@ -78,79 +78,52 @@ __device__ __forceinline__ void store_row(float* dst, const float (&v)[KT]) {
   }
 }
 
+// One pixel's K = KT rows of the four outputs from the register queue: 16-byte stores.
 template <typename Queue, int KT, bool IN_REGS>
 __device__ __forceinline__ void write_pixel(const MeshArgs& a, const Queue& q, int64_t opix) {
-  const int K = a.K;
-  const int64_t base = opix * K;
-  if constexpr (IN_REGS) {
-    if (K == KT) {
-      // exact-capacity fast path: 16-byte stores
-      float zv[KT], dv[KT], bv[3 * KT];
-      long long iv[KT];
+  static_assert(IN_REGS, "vector-row stores need the register queue");
+  const int64_t base = opix * KT;
+  float zv[KT], dv[KT], bv[3 * KT];
+  long long iv[KT];
 #pragma unroll
-      for (int k = 0; k < KT; ++k) {
-        const bool ok = q.valid(k);
-        iv[k] = ok ? (long long)q.idx[k] : -1ll;
-        zv[k] = ok ? q.z[k] : -1.0f;
-        dv[k] = ok ? q.pl[0][k] : -1.0f;
-        bv[3 * k + 0] = ok ? q.pl[1][k] : -1.0f;
-        bv[3 * k + 1] = ok ? q.pl[2][k] : -1.0f;
-        bv[3 * k + 2] = ok ? q.pl[3][k] : -1.0f;
-      }
-      store_row<KT>(a.zbuf + base, zv);
-      store_row<KT>(a.dists + base, dv);
-      if constexpr (KT % 4 == 0) {
-        float* bp = a.bary + base * 3;
+  for (int k = 0; k < KT; ++k) {
+    const bool ok = q.valid(k);
+    iv[k] = ok ? (long long)q.idx[k] : -1ll;
+    zv[k] = ok ? q.z[k] : -1.0f;
+    dv[k] = ok ? q.pl[0][k] : -1.0f;
+    bv[3 * k + 0] = ok ? q.pl[1][k] : -1.0f;
+    bv[3 * k + 1] = ok ? q.pl[2][k] : -1.0f;
+    bv[3 * k + 2] = ok ? q.pl[3][k] : -1.0f;
+  }
+  store_row<KT>(a.zbuf + base, zv);
+  store_row<KT>(a.dists + base, dv);
+  if constexpr (KT % 4 == 0) {
+    float* bp = a.bary + base * 3;
 #pragma unroll
-        for (int k = 0; k < 3 * KT; k += 4) {
-          float4 t;
-          t.x = bv[k];
-          t.y = bv[k + 1];
-          t.z = bv[k + 2];
-          t.w = bv[k + 3];
-          *reinterpret_cast<float4*>(bp + k) = t;
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < 3 * KT; ++k) a.bary[base * 3 + k] = bv[k];
-      }
-      if constexpr (KT % 2 == 0) {
-        long long* ip = reinterpret_cast<long long*>(a.p2f + base);
-#pragma unroll
-        for (int k = 0; k < KT; k += 2) {
-          longlong2 t;
-          t.x = iv[k];
-          t.y = iv[k + 1];
-          *reinterpret_cast<longlong2*>(ip + k) = t;
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < KT; ++k) a.p2f[base + k] = iv[k];
-      }
-      return;
-    }
-#pragma unroll
-    for (int k = 0; k < KT; ++k) {
-      if (k < K) {
-        const bool ok = q.valid(k);
-        a.p2f[base + k] = ok ? (int64_t)q.idx[k] : (int64_t)-1;
-        a.zbuf[base + k] = ok ? q.z[k] : -1.0f;
-        a.dists[base + k] = ok ? q.pl[0][k] : -1.0f;
-        a.bary[(base + k) * 3 + 0] = ok ? q.pl[1][k] : -1.0f;
-        a.bary[(base + k) * 3 + 1] = ok ? q.pl[2][k] : -1.0f;
-        a.bary[(base + k) * 3 + 2] = ok ? q.pl[3][k] : -1.0f;
-      }
+    for (int k = 0; k < 3 * KT; k += 4) {
+      float4 t;
+      t.x = bv[k];
+      t.y = bv[k + 1];
+      t.z = bv[k + 2];
+      t.w = bv[k + 3];
+      *reinterpret_cast<float4*>(bp + k) = t;
     }
   } else {
-    for (int k = 0; k < K; ++k) {
-      const bool ok = q.valid(k);
-      a.p2f[base + k] = ok ? (int64_t)q.idx[k] : (int64_t)-1;
-      a.zbuf[base + k] = ok ? q.z[k] : -1.0f;
-      a.dists[base + k] = ok ? q.pl[0][k] : -1.0f;
-      a.bary[(base + k) * 3 + 0] = ok ? q.pl[1][k] : -1.0f;
-      a.bary[(base + k) * 3 + 1] = ok ? q.pl[2][k] : -1.0f;
-      a.bary[(base + k) * 3 + 2] = ok ? q.pl[3][k] : -1.0f;
+#pragma unroll
+    for (int k = 0; k < 3 * KT; ++k) a.bary[base * 3 + k] = bv[k];
+  }
+  if constexpr (KT % 2 == 0) {
+    long long* ip = reinterpret_cast<long long*>(a.p2f + base);
+#pragma unroll
+    for (int k = 0; k < KT; k += 2) {
+      longlong2 t;
+      t.x = iv[k];
+      t.y = iv[k + 1];
+      *reinterpret_cast<longlong2*>(ip + k) = t;
     }
+  } else {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) a.p2f[base + k] = iv[k];
   }
 }
 
@@ -271,10 +244,9 @@ constexpr int kRecWords = 5;
 // with the rule in the common loop body the compiler copies the whole queue (48 moves) after every hit to feed the
 // rule's control flow.
 template <bool GENERAL, typename Queue>
-__device__ __forceinline__ void eval_candidates(const MeshArgs& a, Queue& q, unsigned long long cand, int oj, f2 p,
+__device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue& q, unsigned long long cand, int oj, f2 p,
                                                 bool pix_ok, bool persp, bool clip, const float4* s_box,
                                                 const float4 (*s_rec)[kRecWords], const float* s_zc) {
-  const int K = a.K;
   while (cand) {
     const int jj = __builtin_amdgcn_readlane(oj, __builtin_ctzll(cand));
     cand &= cand - 1;
@@ -415,11 +387,10 @@ struct SubTile {
 
 // One wave's pass over a staged chunk: sub-tile cull 64 faces at a time (one lane per face), then the per-pixel loop.
 template <bool GENERAL, typename Queue>
-__device__ __forceinline__ void wave_chunk(const MeshArgs& a, Queue& q, int staged, bool sorted, const SubTile& st, f2 p,
+__device__ __forceinline__ void wave_chunk(const MeshArgs& a, int K, Queue& q, int staged, bool sorted, const SubTile& st, f2 p,
                                            bool pix_ok, int lane, bool persp, bool clip, bool prune, const float4* s_box,
                                            const float4 (*s_rec)[kRecWords], const float* s_zc, const int* s_order,
                                            const float* s_qlow) {
-  const int K = a.K;
   for (int jb = 0; jb < staged; jb += kWave) {
     // sorted chunk: once the nearest remaining face is too deep for every pixel of this wave, so is everything behind it
     if (sorted && __ballot(pix_ok && !(s_qlow[jb] > q.kth_z(K))) == 0) break;
@@ -436,11 +407,13 @@ __device__ __forceinline__ void wave_chunk(const MeshArgs& a, Queue& q, int stag
       }
     }
     const unsigned long long cand = __ballot(touch);
-    eval_candidates<GENERAL, Queue>(a, q, cand, oj, p, pix_ok, persp, clip, s_box, s_rec, s_zc);
+    eval_candidates<GENERAL, Queue>(a, K, q, cand, oj, p, pix_ok, persp, clip, s_box, s_rec, s_zc);
   }
 }
 
-template <typename Queue, int KT, bool IN_REGS, bool BINNED>
+// EXACT: K == KT is known at compile time (K = 1, 2, 4, 8): the queue's live capacity folds to a constant and the
+// generic epilogue (fill + patch, for K that has no vector-row path) is not even compiled into the hot kernels.
+template <typename Queue, int KT, bool IN_REGS, bool BINNED, bool EXACT>
 __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_kernel(MeshArgs a) {
   __shared__ float4 s_box[kStage];                  // xlo, xhi, ylo, yhi (blur-expanded)
   __shared__ float4 s_rec[kStage][kRecWords];       // see kRecWords
@@ -489,7 +462,7 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
     if (!(P3D_DBG(a) & 4) && !(P3D_DBG(a) & 2048)) {
       if ((a.K & 3) == 0 && !(P3D_DBG(a) & 64)) {
         fill_tile_background(a, n, ty0, tx0, y_end, x_end, tid);
-      } else if (IN_REGS && a.K == KT) {
+      } else if constexpr (EXACT) {
         Queue e;
         e.init();
         if (pix_ok) write_pixel<Queue, KT, IN_REGS>(a, e, ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi));
@@ -512,7 +485,7 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
 
   Queue q;
   q.init();
-  const int K = a.K;
+  const int K = EXACT ? KT : a.K;
   const bool persp = a.persp != 0, clip = a.clip != 0, cull = a.cull != 0;
   const bool prune = !(P3D_DBG(a) & 256);
   StageLds lds;
@@ -554,7 +527,7 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
       __syncthreads();
     }
     if (run_waves)
-      wave_chunk<false, Queue>(a, q, staged, !(P3D_DBG(a) & 32), st, p, pix_ok, lane, persp, clip, prune, s_box, s_rec, s_zc, s_order,
+      wave_chunk<false, Queue>(a, K, q, staged, !(P3D_DBG(a) & 32), st, p, pix_ok, lane, persp, clip, prune, s_box, s_rec, s_zc, s_order,
                                s_qlow);
     __syncthreads();
   }
@@ -564,7 +537,7 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
       if (tid < staged) s_order[tid] = tid;
       __syncthreads();
       if (run_waves)
-        wave_chunk<true, Queue>(a, q, staged, false, st, p, pix_ok, lane, persp, clip, prune, s_box, s_rec, s_zc, s_order, s_qlow);
+        wave_chunk<true, Queue>(a, K, q, staged, false, st, p, pix_ok, lane, persp, clip, prune, s_box, s_rec, s_zc, s_order, s_qlow);
       __syncthreads();
       base += kStage;
       if (base >= count) break;
@@ -574,14 +547,15 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
   }
 
   if (!(P3D_DBG(a) & 4)) {
-    if (IN_REGS && K == KT) {
+    if constexpr (EXACT) {
       if (pix_ok) write_pixel<Queue, KT, IN_REGS>(a, q, ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi));
-    } else if (wave_ok) {
-      write_subtile_fill_patch<Queue, KT, IN_REGS>(a, q, true, n, sy0, sx0, y_end, x_end, lane, pix_ok, yi, xi);
+    } else {
+      if (wave_ok) write_subtile_fill_patch<Queue, KT, IN_REGS>(a, q, true, n, sy0, sx0, y_end, x_end, lane, pix_ok, yi, xi);
     }
   }
 }
 
+#define P3D_COMMA ,
 template <bool BINNED>
 int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
   MeshArgs a = a0;
@@ -596,16 +570,22 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
   const char* name = BINNED ? "mesh_fine" : "mesh_naive";
   LaunchScope ls(name, stream);
   const int K = a.K;
+#define P3D_LAUNCH_FINE(KT_, REGS_, EXACT_, Q_) mesh_raster_kernel<Q_, KT_, REGS_, BINNED, EXACT_><<<grid, kStage, 0, stream>>>(a)
   if (K == 1)
-    mesh_raster_kernel<TopKReg<1, kMeshPayload>, 1, true, BINNED><<<grid, kStage, 0, stream>>>(a);
+    P3D_LAUNCH_FINE(1, true, true, TopKReg<1 P3D_COMMA kMeshPayload>);
   else if (K == 2)
-    mesh_raster_kernel<TopKReg<2, kMeshPayload>, 2, true, BINNED><<<grid, kStage, 0, stream>>>(a);
-  else if (K <= 4)
-    mesh_raster_kernel<TopKReg<4, kMeshPayload>, 4, true, BINNED><<<grid, kStage, 0, stream>>>(a);
-  else if (K <= 8)
-    mesh_raster_kernel<TopKReg<8, kMeshPayload>, 8, true, BINNED><<<grid, kStage, 0, stream>>>(a);
+    P3D_LAUNCH_FINE(2, true, true, TopKReg<2 P3D_COMMA kMeshPayload>);
+  else if (K == 3)
+    P3D_LAUNCH_FINE(4, true, false, TopKReg<4 P3D_COMMA kMeshPayload>);
+  else if (K == 4)
+    P3D_LAUNCH_FINE(4, true, true, TopKReg<4 P3D_COMMA kMeshPayload>);
+  else if (K < 8)
+    P3D_LAUNCH_FINE(8, true, false, TopKReg<8 P3D_COMMA kMeshPayload>);
+  else if (K == 8)
+    P3D_LAUNCH_FINE(8, true, true, TopKReg<8 P3D_COMMA kMeshPayload>);
   else
-    mesh_raster_kernel<TopKMem<P3D_MAX_K, kMeshPayload>, P3D_MAX_K, false, BINNED><<<grid, kStage, 0, stream>>>(a);
+    P3D_LAUNCH_FINE(P3D_MAX_K, false, false, TopKMem<P3D_MAX_K P3D_COMMA kMeshPayload>);
+#undef P3D_LAUNCH_FINE
   return launch_status();
 }
 
