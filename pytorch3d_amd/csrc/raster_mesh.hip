@@ -55,6 +55,25 @@ struct MeshArgs {
   float* dists;
 };
 
+// P3D_BG_FILL_MODE (ablation builds): how background tiles are stored.  0 every lane its own pixel's rows, 1 cooperative
+// fill in memory order (fill_tile_background), 2 the same by one wave of the workgroup, 3 / 4 = 1 / 0 with non-temporal
+// stores.
+#ifndef P3D_BG_FILL_MODE
+#define P3D_BG_FILL_MODE 1
+#endif
+#ifndef P3D_ACTIVE_NT
+#define P3D_ACTIVE_NT 0  // 1: the tiles with faces store their rows non-temporally
+#endif
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ void store16(void* p, unsigned a, unsigned b, unsigned c, unsigned d) {
+  u32x4 v = {a, b, c, d};
+  if (NT)
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
+  else
+    *reinterpret_cast<u32x4*>(p) = v;
+}
+
 template <int KT>
 __device__ __forceinline__ void store_row(float* dst, const float (&v)[KT]) {
   if constexpr (KT % 4 == 0) {
@@ -79,7 +98,7 @@ __device__ __forceinline__ void store_row(float* dst, const float (&v)[KT]) {
 }
 
 // One pixel's K = KT rows of the four outputs from the register queue: 16-byte stores.
-template <typename Queue, int KT, bool IN_REGS>
+template <typename Queue, int KT, bool IN_REGS, bool NT = false>
 __device__ __forceinline__ void write_pixel(const MeshArgs& a, const Queue& q, int64_t opix) {
   static_assert(IN_REGS, "vector-row stores need the register queue");
   const int64_t base = opix * KT;
@@ -95,35 +114,39 @@ __device__ __forceinline__ void write_pixel(const MeshArgs& a, const Queue& q, i
     bv[3 * k + 1] = ok ? q.pl[2][k] : -1.0f;
     bv[3 * k + 2] = ok ? q.pl[3][k] : -1.0f;
   }
-  store_row<KT>(a.zbuf + base, zv);
-  store_row<KT>(a.dists + base, dv);
   if constexpr (KT % 4 == 0) {
-    float* bp = a.bary + base * 3;
 #pragma unroll
-    for (int k = 0; k < 3 * KT; k += 4) {
-      float4 t;
-      t.x = bv[k];
-      t.y = bv[k + 1];
-      t.z = bv[k + 2];
-      t.w = bv[k + 3];
-      *reinterpret_cast<float4*>(bp + k) = t;
+    for (int k = 0; k < KT; k += 4) {
+      store16<NT>(a.zbuf + base + k, __float_as_uint(zv[k]), __float_as_uint(zv[k + 1]), __float_as_uint(zv[k + 2]),
+                  __float_as_uint(zv[k + 3]));
+      store16<NT>(a.dists + base + k, __float_as_uint(dv[k]), __float_as_uint(dv[k + 1]), __float_as_uint(dv[k + 2]),
+                  __float_as_uint(dv[k + 3]));
     }
+#pragma unroll
+    for (int k = 0; k < 3 * KT; k += 4)
+      store16<NT>(a.bary + base * 3 + k, __float_as_uint(bv[k]), __float_as_uint(bv[k + 1]), __float_as_uint(bv[k + 2]),
+                  __float_as_uint(bv[k + 3]));
+#pragma unroll
+    for (int k = 0; k < KT; k += 2)
+      store16<NT>(a.p2f + base + k, (unsigned)iv[k], (unsigned)(iv[k] >> 32), (unsigned)iv[k + 1], (unsigned)(iv[k + 1] >> 32));
   } else {
+    store_row<KT>(a.zbuf + base, zv);
+    store_row<KT>(a.dists + base, dv);
 #pragma unroll
     for (int k = 0; k < 3 * KT; ++k) a.bary[base * 3 + k] = bv[k];
-  }
-  if constexpr (KT % 2 == 0) {
-    long long* ip = reinterpret_cast<long long*>(a.p2f + base);
+    if constexpr (KT % 2 == 0) {
+      long long* ip = reinterpret_cast<long long*>(a.p2f + base);
 #pragma unroll
-    for (int k = 0; k < KT; k += 2) {
-      longlong2 t;
-      t.x = iv[k];
-      t.y = iv[k + 1];
-      *reinterpret_cast<longlong2*>(ip + k) = t;
+      for (int k = 0; k < KT; k += 2) {
+        longlong2 t;
+        t.x = iv[k];
+        t.y = iv[k + 1];
+        *reinterpret_cast<longlong2*>(ip + k) = t;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < KT; ++k) a.p2f[base + k] = iv[k];
     }
-  } else {
-#pragma unroll
-    for (int k = 0; k < KT; ++k) a.p2f[base + k] = iv[k];
   }
 }
 
@@ -212,6 +235,7 @@ __device__ __forceinline__ void write_subtile_fill_patch(const MeshArgs& a, cons
 // 256 threads -- every store instruction of a wave covers one contiguous 1 KiB piece (a lane writing its own pixel's
 // K-row stores 16 bytes at a stride of 4*K..12*K).  Per tile row the outputs hold cols*K floats (zbuf, dists),
 // 3*cols*K floats (bary) and cols*K int64 (pix_to_face) = 7 * cols*K/4 16-byte pieces.
+template <int THREADS, bool NT>
 __device__ __forceinline__ void fill_tile_background(const MeshArgs& a, int n, int ty0, int tx0, int y_end, int x_end,
                                                      int tid) {
   const int H = a.H, W = a.W, K = a.K;
@@ -221,7 +245,7 @@ __device__ __forceinline__ void fill_tile_background(const MeshArgs& a, int n, i
   const int64_t col0 = W - tx0 - cols;  // outputs are stored flipped: x_out = W-1-x
   for (int r = 0; r < rows; ++r) {
     const int64_t px = ((int64_t)n * H + (H - 1 - (ty0 + r))) * W + col0;
-    for (int e = tid; e < per_row; e += kStage) {
+    for (int e = tid; e < per_row; e += THREADS) {
       // branch-free choice of (output, piece): lanes of one wave straddle the boundaries between the outputs
       const bool in_z = e < q4, in_d = e < 2 * q4, in_b = e < 5 * q4;
       char* base = in_z ? reinterpret_cast<char*>(a.zbuf + px * K)
@@ -229,7 +253,7 @@ __device__ __forceinline__ void fill_tile_background(const MeshArgs& a, int n, i
                                 : (in_b ? reinterpret_cast<char*>(a.bary + px * K * 3) : reinterpret_cast<char*>(a.p2f + px * K)));
       const int piece = e - (in_z ? 0 : (in_d ? q4 : (in_b ? 2 * q4 : 5 * q4)));
       const unsigned v = in_b ? 0xbf800000u : ~0u;  // four -1.0f, or two int64 -1 (a select of two uint4 constants compiles to a scratch array)
-      *reinterpret_cast<uint4*>(base + (size_t)piece * 16) = make_uint4(v, v, v, v);
+      store16<NT>(base + (size_t)piece * 16, v, v, v, v);
     }
   }
 }
@@ -460,12 +484,16 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
   if (count <= 0) {
     // background tile (3 of 5 at the bench workload): nothing but the -1 stores; skip the NDC set-up below
     if (!(P3D_DBG(a) & 4) && !(P3D_DBG(a) & 2048)) {
-      if ((a.K & 3) == 0 && !(P3D_DBG(a) & 64)) {
-        fill_tile_background(a, n, ty0, tx0, y_end, x_end, tid);
+      if ((a.K & 3) == 0 && !(P3D_DBG(a) & 64) && P3D_BG_FILL_MODE != 0 && P3D_BG_FILL_MODE != 4) {
+        if (P3D_BG_FILL_MODE == 2) {
+          if (tid < kWave) fill_tile_background<kWave, false>(a, n, ty0, tx0, y_end, x_end, tid);
+        } else {
+          fill_tile_background<kStage, P3D_BG_FILL_MODE == 3>(a, n, ty0, tx0, y_end, x_end, tid);
+        }
       } else if constexpr (EXACT) {
         Queue e;
         e.init();
-        if (pix_ok) write_pixel<Queue, KT, IN_REGS>(a, e, ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi));
+        if (pix_ok) write_pixel<Queue, KT, IN_REGS, P3D_BG_FILL_MODE == 4>(a, e, ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi));
       } else if (wave_ok) {
         Queue e;
         e.init();
@@ -548,7 +576,7 @@ __global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_k
 
   if (!(P3D_DBG(a) & 4)) {
     if constexpr (EXACT) {
-      if (pix_ok) write_pixel<Queue, KT, IN_REGS>(a, q, ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi));
+      if (pix_ok) write_pixel<Queue, KT, IN_REGS, P3D_ACTIVE_NT != 0>(a, q, ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi));
     } else {
       if (wave_ok) write_subtile_fill_patch<Queue, KT, IN_REGS>(a, q, true, n, sy0, sx0, y_end, x_end, lane, pix_ok, yi, xi);
     }
