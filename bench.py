@@ -1,24 +1,32 @@
 #!/usr/bin/env python
 """bench.py -- rasterized Mpix/s (fwd+bwd) at 512^2, faces_per_pixel=8, on MI355X.
 
-A "step" is one pass of the hot path over one batch of synthetic input: BASELINE.json configs[2],
-a batch of 64 heterogeneous meshes (1k-20k faces each, log-uniform; tori and icospheres, random
-rotation, pinhole view from 2.7), 512x512, K=8, SoftRas blur, perspective-correct + clipped
-barycentrics: `rasterize_meshes` forward (face gather + coarse binning + fine rasterization) and
-backward (SoftRas gradient to the packed vertices) through the L2 mirror's autograd Function,
-driven by fixed random upstream gradients for zbuf / bary / dists (the reference's gradient
-check, tests/test_rasterize_meshes.py:563-571).  Inputs are resident in HBM before the timed
-region.  With --gpus N every rank rasterizes its own batch of 64 (weak scaling, no data-path
-collective); the only collective is the final gather of the last step's depth images to rank 0 over
-RCCL/xGMI, inside the timed region.
+A "step" is one pass of the hot path over one batch of synthetic input: BASELINE.json configs[2], a batch of 64
+heterogeneous meshes (1k-20k faces each, log-uniform; tori and icospheres, random rotation, pinhole view from 2.7),
+512x512, K=8, SoftRas blur, perspective-correct + clipped barycentrics: `rasterize_meshes` forward (face gather + coarse
+binning + fine rasterization) and backward (SoftRas gradient to the packed vertices) through the L2 mirror's autograd
+Function, driven by fixed random upstream gradients for zbuf / bary / dists (the reference's gradient check,
+tests/test_rasterize_meshes.py:563-571).  Inputs are resident in HBM before the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W]                      weak scaling: every rank its own batch of 64
+    python bench.py --jobs 512 [--gpus N]                                    BASELINE configs[4]: 512 fixed jobs = 8 sub-batches
+                                                                             of 64 (generator seeds 0..7), rank r runs sub-batches
+                                                                             r, r+G, ...; one pass = K "steps" (K = 8/G per rank)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line.
+The only collective is the final gather of the depth images to rank 0 (RCCL over xGMI), inside the timed region; its
+time is also reported separately (`gather_ms`).  Rank 0 prints ONE JSON line.
+
+Beside the headline number the line carries (rank 0, N = 1 only, all outside the timed region):
+  roofline       dominant kernel: algorithmic bytes per launch / average launch duration (HIP events on the launch stream)
+  cpu_baseline   the reference's own CPU kernels (oracle/_ref) on a seeded 8-mesh subset of the batch at full resolution,
+                 and the reference's pure-Python `rasterize_meshes_python` on BASELINE configs[0], both on this box's cores
+  other_configs  BASELINE configs[1] (the reference's cow, 256^2, K=8, coarse+fine forward) and configs[3] (1M points,
+                 512^2, K=10, rasterizer + alpha compositor, fwd+bwd): wall and kernel milliseconds
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -30,17 +38,21 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+TORUS_SCALE = "tori R=1 scaled by 1/1.5 (tests/_util.py::hetero_batch): the meshes cover ~37% of the pixels, not the full frame"
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--image-size", type=int, default=512)
     ap.add_argument("--faces-per-pixel", type=int, default=8)
+    ap.add_argument("--jobs", type=int, default=0, help="BASELINE configs[4]: a fixed number of jobs (multiple of --batch), strong scaling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=150.0, help="wall-clock bound for the CPU baseline legs")
     return ap.parse_args()
 
 
@@ -54,42 +66,188 @@ def build_batch(n_meshes, seed, device):
     return meshes, verts, faces, nfaces
 
 
-def cpu_baseline(verts, faces, H, W, K, blur):
-    """Reference CPU path (oracle/_ref, the reference's own C++ kernels) on a bounded sample:
-    the smallest mesh of the batch, full resolution, forward + backward."""
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1, after the timed region).  The only place that touches oracle/.
+# ---------------------------------------------------------------------------------------------------------------
+def cpu_baseline(verts, faces, H, W, K, blur, budget_s):
+    """(i) the reference's pure-Python rasterize_meshes_python on BASELINE configs[0] -- the path north_star names --
+    and (ii) the reference's C++ CPU kernels (oracle/_ref: RasterizeMeshesNaiveCpu + RasterizeMeshesBackwardCpu) on a
+    seeded subset of 8 meshes of the bench batch (meshes are independent, so the batch rate is the subset's),
+    full resolution, forward (multi-threaded over image rows) + backward (single-threaded by construction,
+    rasterize_meshes_cpu.cpp:412-529)."""
     from oracle import oracle as orc
 
-    j = min(range(len(faces)), key=lambda i: faces[i].shape[0])
-    v, f = verts[j], faces[j]
-    fv = v[f].contiguous()
-    F = fv.shape[0]
-    first = torch.zeros(1, dtype=torch.int64)
-    count = torch.tensor([F], dtype=torch.int64)
-    nbr = torch.full((F,), -1, dtype=torch.int64)
-    gen = torch.Generator().manual_seed(231)
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
+    t_start = time.perf_counter()
+    py = python_reference_baseline(orc)
     ref = orc.ref_module()
-    t0 = time.perf_counter()
-    if ref is not None:
-        kind = "reference"
-        out = ref._rasterize_meshes_naive(fv, first, count, nbr, (H, W), blur, K, True, True, False)
+    kind = "reference" if ref is not None else "port"
+    order = torch.randperm(len(faces), generator=torch.Generator().manual_seed(0)).tolist()[:8]
+    gen = torch.Generator().manual_seed(231)
+    done, px, t_fwd, t_bwd, nf = 0, 0, 0.0, 0.0, []
+    for j in order:
+        if done >= 2 and time.perf_counter() - t_start > budget_s:
+            break
+        v, f = verts[j], faces[j]
+        fv = v[f].contiguous()
+        F = fv.shape[0]
+        first = torch.zeros(1, dtype=torch.int64)
+        count = torch.tensor([F], dtype=torch.int64)
+        nbr = torch.full((F,), -1, dtype=torch.int64)
+        t0 = time.perf_counter()
+        if ref is not None:
+            out = ref._rasterize_meshes_naive(fv, first, count, nbr, (H, W), blur, K, True, True, False)
+        else:
+            out = orc.rasterize_meshes_naive(fv, first, count, nbr, (H, W), blur, K, True, True, False)
+        t1 = time.perf_counter()
         g = [torch.randn(o.shape, generator=gen) for o in out[1:]]
-        ref.rasterize_meshes_backward(fv, out[0], g[0], g[1], g[2], True, True)
-    else:
-        kind = "port"
-        out = orc.rasterize_meshes_naive(fv, first, count, nbr, (H, W), blur, K, True, True, False)
-        g = [torch.randn(o.shape, generator=gen) for o in out[1:]]
-        orc.rasterize_meshes_backward(fv, out[0], g[0], g[1], g[2], True, True)
-    dt = time.perf_counter() - t0
+        t2 = time.perf_counter()
+        if ref is not None:
+            ref.rasterize_meshes_backward(fv, out[0], g[0], g[1], g[2], True, True)
+        else:
+            orc.rasterize_meshes_backward(fv, out[0], g[0], g[1], g[2], True, True)
+        t3 = time.perf_counter()
+        t_fwd += t1 - t0
+        t_bwd += t3 - t2
+        px += H * W
+        nf.append(F)
+        done += 1
+    dt = t_fwd + t_bwd
     return {
-        "value": H * W / dt / 1e6,
+        "value": px / dt / 1e6,
         "unit": "Mpix/s",
         "cores": cores,
         "kind": kind,
-        "sample": f"1 mesh of the batch ({F} faces), {H}x{W}, K={K}, naive fwd (multi-thread) + bwd (single-thread, "
-                  f"as the reference CPU path is), {dt:.1f} s",
+        "sample": f"{done} of the seeded 8-mesh subset (randperm seed 0) of the batch, faces {nf}, {H}x{W}, K={K}, "
+                  f"naive fwd {t_fwd:.1f} s (multi-threaded over rows, {cores} threads) + bwd {t_bwd:.1f} s (single-threaded, "
+                  "as the reference CPU path is); batch of 64 = this x 8",
+        "python_reference": py,
     }
+
+
+def python_reference_baseline(orc):
+    """BASELINE configs[0] exactly: ico_sphere(2) (320 faces), view from 2.7, 64x64, K=1, blur 0,
+    the reference's `rasterize_meshes_python` (renderer/mesh/rasterize_meshes.py:404-619) on CPU.  The reference's Python
+    package exists on the GPU box only as the staged, git-ignored copy under oracle/_ref/reference_py."""
+    stage = os.path.join(ROOT, "oracle", "_ref", "reference_py")
+    for cand in (os.environ.get("P3D_REFERENCE_ROOT", "/root/reference"), stage):
+        if os.path.isdir(os.path.join(cand, "pytorch3d", "renderer")):
+            ref_root = cand
+            break
+    else:
+        return {"value": None, "reason": "the reference's Python package is not on this machine (neither /root/reference nor "
+                                         "oracle/_ref/reference_py staged by oracle/stage_reference.py)"}
+    ref = orc.ref_module()
+    if ref is None:
+        return {"value": None, "reason": "oracle/_ref/p3d_ref_cpu.so not built: pytorch3d.renderer needs a _C module to import"}
+    try:
+        import importlib
+
+        sys.modules["pytorch3d._C"] = ref
+        if ref_root not in sys.path:
+            sys.path.insert(0, ref_root)
+        import pytorch3d
+
+        pytorch3d._C = ref
+        rm = importlib.import_module("pytorch3d.renderer.mesh.rasterize_meshes")
+        from pytorch3d.structures import Meshes
+
+        import _util as U
+
+        v, f = U.ico_sphere(2)
+        meshes = Meshes(verts=[U.to_ndc(v)], faces=[f])
+        t0 = time.perf_counter()
+        out = rm.rasterize_meshes_python(meshes, image_size=64, blur_radius=0.0, faces_per_pixel=1,
+                                         perspective_correct=False, clip_barycentric_coords=False, cull_backfaces=False)
+        dt = time.perf_counter() - t0
+        # plumbing check of configs[0]: identical pix_to_face to the reference's C++ CPU rasterizer
+        fv = meshes.verts_packed()[meshes.faces_packed()]
+        cpp = ref._rasterize_meshes_naive(fv, meshes.mesh_to_faces_packed_first_idx(), meshes.num_faces_per_mesh(),
+                                          torch.full((fv.shape[0],), -1, dtype=torch.int64), (64, 64), 0.0, 1, False, False, False)
+        same = bool(torch.equal(out[0], cpp[0]))
+        pairs = 64 * 64 * int(f.shape[0])
+        return {"value": 64 * 64 / dt / 1e6, "unit": "Mpix/s", "seconds": dt, "pixel_face_pairs_per_s": pairs / dt, "cores": 1,
+                "config": "BASELINE configs[0]: ico_sphere(2) 320 faces, 64x64, K=1, blur 0, rasterize_meshes_python (forward)",
+                "pix_to_face_equals_cpp_cpu": same,
+                "extrapolated_seconds_for_one_5k_face_512x512_mesh": 512 * 512 * 5000 / (pairs / dt)}
+    except Exception as e:  # never sink the measurement
+        return {"value": None, "reason": repr(e)}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The other BASELINE configs (N = 1, after the timed region): extra keys, not the headline.
+# ---------------------------------------------------------------------------------------------------------------
+def _timed(lib, _lib, fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    lib.p3d_profile_reset()
+    lib.p3d_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / iters * 1e3
+    lib.p3d_profile_enable(0)
+    prof = _lib.profile_snapshot()
+    return wall, {k: round(ms / n, 4) for k, (n, ms) in sorted(prof.items())}
+
+
+def other_configs(lib, _lib, device):
+    import numpy as np
+
+    import pytorch3d_amd as p3d
+    from pytorch3d_amd import _C
+
+    out = {}
+    # configs[1]: the reference's cow as MeshRasterizer.transform leaves it (tests/golden/cow_ref.npz), 256^2, K=8
+    try:
+        g = np.load(os.path.join(ROOT, "tests", "golden", "cow_ref.npz"))
+        m = p3d.PackedMeshes([torch.from_numpy(g["verts_ndc"]).to(device)], [torch.from_numpy(g["faces"]).long().to(device)])
+        H = int(g["image_size"])
+        K, blur = int(g["K"]), float(g["blur_radius"])
+
+        def c2():
+            return p3d.rasterize_meshes(m, image_size=H, blur_radius=blur, faces_per_pixel=K, perspective_correct=True,
+                                        clip_barycentric_coords=True)
+
+        wall, kern = _timed(lib, _lib, c2)
+        F = int(g["faces"].shape[0])
+        alg = H * H * K * 28 + F * 44 + 16
+        out["config2_cow_256_k8_fwd"] = {"wall_ms": round(wall, 4), "kernels_ms": kern, "kernel_sum_ms": round(sum(kern.values()), 4),
+                                         "algorithmic_bytes": alg, "gbps_of_wall": alg / (wall * 1e-3) / 1e9, "faces": F}
+    except Exception as e:
+        out["config2_cow_256_k8_fwd"] = {"error": repr(e)}
+    # configs[3]: 1M points, 512^2, K=10, r=0.01, rasterizer + alpha compositor, forward + backward
+    try:
+        gen = torch.Generator().manual_seed(0)
+        P, H, K, r, C = 1_000_000, 512, 10, 0.01, 3
+        pts = torch.cat([torch.rand(P, 2, generator=gen) * 2 - 1, torch.rand(P, 1, generator=gen) * 2 + 0.5], 1).to(device)
+        feats = torch.rand(C, P, generator=gen).to(device)
+        first = torch.zeros(1, dtype=torch.int64, device=device)
+        count = torch.full((1,), P, dtype=torch.int64, device=device)
+        radius = torch.full((P,), r, device=device)
+        gz = torch.randn((1, H, H, K), generator=gen).to(device)
+        gd = torch.randn((1, H, H, K), generator=gen).to(device)
+        gi = torch.randn((1, C, H, H), generator=gen).to(device)
+
+        def c4():
+            idx, zbuf, dists = _C.rasterize_points(pts, first, count, (H, H), radius, K, 32, 200000)
+            alphas = (1 - dists / (r * r)).clamp(0, 1).permute(0, 3, 1, 2)
+            pidx = idx.long().permute(0, 3, 1, 2)
+            img = _C.accum_alphacomposite(feats, alphas, pidx)
+            gf, ga = _C.accum_alphacomposite_backward(gi, feats, alphas, pidx)
+            gp = _C.rasterize_points_backward(pts, idx, gz, gd)
+            return img, gf, ga, gp
+
+        wall, kern = _timed(lib, _lib, c4)
+        out["config4_points_1m_512_k10_fwd_bwd"] = {"wall_ms": round(wall, 4), "kernels_ms": kern,
+                                                    "kernel_sum_ms": round(sum(kern.values()), 4),
+                                                    "note": "wall includes the torch glue between the operators (alphas, permutes)"}
+    except Exception as e:
+        out["config4_points_1m_512_k10_fwd_bwd"] = {"error": repr(e)}
+    return out
 
 
 def main():
@@ -124,115 +282,173 @@ def main():
     H = W = args.image_size
     K = args.faces_per_pixel
     sigma = 1e-4
-    import math
-
     blur = math.log(1.0 / 1e-4 - 1.0) * sigma  # SoftRas convention, tests/test_render_meshes.py:462
     B = args.batch
-    meshes, verts_cpu, faces_cpu, nfaces = build_batch(B, seed=rank, device=device)
-    total_faces = sum(nfaces)
-    verts_packed = meshes.verts_packed().clone().requires_grad_(True)
+
+    # ---- which sub-batches this rank owns ---------------------------------------------------------------------
+    jobs_mode = args.jobs > 0
+    if jobs_mode:
+        if args.jobs % B:
+            raise SystemExit("--jobs must be a multiple of --batch")
+        n_sub = args.jobs // B
+        if n_sub % world:
+            raise SystemExit(f"--jobs {args.jobs}: {n_sub} sub-batches do not divide over {world} ranks")
+        seeds = list(range(rank, n_sub, world))  # sub-batch s = generator seed s
+        steps = len(seeds)
+    else:
+        seeds = [rank]
+        steps = args.steps
+    batches = []
+    for s in seeds:
+        meshes, verts_cpu, faces_cpu, nfaces = build_batch(B, seed=s, device=device)
+        vp = meshes.verts_packed().clone().requires_grad_(True)
+        batches.append((meshes, vp, sum(nfaces), verts_cpu, faces_cpu))
     gen = torch.Generator().manual_seed(231 + rank)
     g_z = torch.randn((B, H, W, K), generator=gen).to(device)
     g_b = torch.randn((B, H, W, K, 3), generator=gen).to(device)
     g_d = torch.randn((B, H, W, K), generator=gen).to(device)
 
-    def step():
-        verts_packed.grad = None
-        m = meshes.update_verts_packed(verts_packed)
+    def step(i):
+        meshes, vp, _, _, _ = batches[i % len(batches)]
+        vp.grad = None
+        m = meshes.update_verts_packed(vp)
         p2f, zbuf, bary, dists = p3d.rasterize_meshes(m, image_size=(H, W), blur_radius=blur, faces_per_pixel=K,
                                                       perspective_correct=True, clip_barycentric_coords=True)
         torch.autograd.backward([zbuf, bary, dists], [g_z, g_b, g_d])
-        return zbuf
+        return p2f, zbuf
 
-    def final_gather(z):
+    own = [B] * world if not jobs_mode else [B * steps] * world
+
+    def final_gather(depths):
         # the one collective of the job: the final depth images of every rank are gathered on rank 0
-        shard = z[..., 0].detach().contiguous()
+        shard = torch.cat([z[..., 0].detach() for z in depths], 0).contiguous()
         try:
-            return sharding.gather_batch(shard, [B] * world, dst=0)
+            return sharding.gather_batch(shard, own, dst=0)
         except (RuntimeError, NotImplementedError):  # a backend without gather: every rank raises alike
-            return sharding.gather_batch(shard, [B] * world)
+            return sharding.gather_batch(shard, own)
 
-    for _ in range(args.warmup):
-        zbuf = step()
+    for i in range(args.warmup):
+        p2f, zbuf = step(i)
     if dist_on and args.warmup > 0:
         # part of the warmup: RCCL opens its point-to-point xGMI channels on the first gather (lazily, ~100 ms)
-        del_me = final_gather(zbuf)
+        del_me = final_gather([zbuf] * (steps if jobs_mode else 1))
         del del_me
     torch.cuda.synchronize()
     lib.p3d_profile_reset()
     lib.p3d_profile_enable(1)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        zbuf = step()
+    kept = []
+    ev[0].record()
+    for i in range(steps):
+        p2f, zbuf = step(i)
+        ev[i + 1].record()
+        if jobs_mode:
+            kept.append(zbuf)
+    tg0 = time.perf_counter()
+    gather_ms = 0.0
     if dist_on:
-        final = final_gather(zbuf)
+        torch.cuda.synchronize()
+        tg0 = time.perf_counter()
+        final = final_gather(kept if jobs_mode else [zbuf])
         del final
     torch.cuda.synchronize()
     if dist_on:
+        gather_ms = (time.perf_counter() - tg0) * 1e3
         dist.barrier()
     t1 = time.perf_counter()
     lib.p3d_profile_enable(0)
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
+    elapsed = torch.tensor([t1 - t0, gather_ms], dtype=torch.float64, device=device)
     if dist_on:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
+    elapsed, gather_ms = float(elapsed[0].item()), float(elapsed[1].item())
     prof = _lib.profile_snapshot()
-    hit_frac = float((zbuf >= 0).float().mean().item())
+    per_step = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+    median_ms = per_step[len(per_step) // 2]
+    valid = p2f >= 0
+    hit_frac = float(valid.float().mean().item())
+    covered = int(valid.any(-1).sum().item())  # pixels of the last step's batch with at least one face
+    total_faces = batches[(steps - 1) % len(batches)][2]
 
     if rank == 0:
-        pixels = world * B * H * W * args.steps
+        pixels = world * B * H * W * steps
         value = pixels / elapsed / 1e6
-        # ---- roofline of the dominant kernel (algorithmic bytes) -------------------
+        # ---- roofline of the dominant kernel (algorithmic bytes) -----------------------------------
         px = B * H * W
         alg = {
             "mesh_fine": px * K * 28 + total_faces * 44 + 16 * B,
             "mesh_naive": px * K * 28 + total_faces * 44 + 16 * B,
+            # SURVEY 8d's figure (every sample's gradients read) ...
             "mesh_backward": px * K * 28 + 2 * total_faces * 36,
         }
+        # ... and what the backward has to move given the data: pix_to_face of every sample, gradient rows only of
+        # pixels that hold a face (background rows carry no information and are skipped)
+        compulsory = dict(alg)
+        compulsory["mesh_backward"] = px * K * 8 + covered * K * 20 + 2 * total_faces * 36
         kernels = {k: {"launches": n, "avg_ms": ms / n} for k, (n, ms) in prof.items()}
         dom = max((k for k in kernels if k in alg), key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
         achieved = alg[dom] / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                tj = json.load(open(tpath))
+                traffic = tj.get(dom)
+                traffic_source = tj.get("_source", "profiles/traffic.json") + " (rocprofv3 PMC passes of an earlier run of this command; not measured in this run)"
             except Exception:
                 traffic = None
         roofline = {
             "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "algorithmic_bytes_per_launch": alg[dom],
-            "avg_launch_ms": kernels[dom]["avg_ms"],
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+            "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kernels[dom]["avg_ms"],
+            "per_kernel": {k: {"avg_ms": round(kernels[k]["avg_ms"], 4), "algorithmic_gbps": alg[k] / (kernels[k]["avg_ms"] * 1e-3) / 1e9,
+                               "compulsory_bytes": compulsory[k],
+                               "compulsory_gbps": compulsory[k] / (kernels[k]["avg_ms"] * 1e-3) / 1e9,
+                               "frac_of_peak_compulsory": compulsory[k] / (kernels[k]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                           for k in kernels if k in alg},
+            "step_algorithmic_gbps": (alg["mesh_fine"] + alg["mesh_backward"]) / (median_ms * 1e-3) / 1e9,
         }
+        workload = (f"BASELINE configs[2]: batch of {B} heterogeneous meshes per GPU (1k-20k faces log-uniform, tori/icospheres; "
+                    f"{TORUS_SCALE}), 512x512, faces_per_pixel=8, SoftRas blur, perspective-correct + clipped bary, fwd+bwd")
+        if jobs_mode:
+            workload = (f"BASELINE configs[4]: {args.jobs} jobs = {args.jobs // B} sub-batches of {B} (configs[2] generator, seeds "
+                        f"0..{args.jobs // B - 1}), each rank runs {steps} sub-batches back to back; " + workload)
         out = {
             "metric": "rasterized Mpix/s (fwd+bwd) at 512^2 faces_per_pixel=8",
             "value": value,
             "unit": "Mpix/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": elapsed / steps * 1e3,
+            "ms_per_step_median": median_ms,
+            "gather_ms": gather_ms,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if jobs_mode else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[2]: batch of {B} heterogeneous meshes per GPU (1k-20k faces, tori/icospheres), "
-                            "512x512, faces_per_pixel=8, SoftRas blur, perspective-correct + clipped bary, fwd+bwd",
-                "global_batch": world * B, "image_size": [H, W], "faces_per_pixel": K, "blur_radius": blur,
-                "total_faces_per_rank": total_faces, "pixel_slot_fill": hit_frac,
+                "workload": workload,
+                "global_batch": world * B * (steps if jobs_mode else 1), "image_size": [H, W], "faces_per_pixel": K, "blur_radius": blur,
+                "total_faces_per_rank": total_faces, "pixel_slot_fill": hit_frac, "covered_pixel_fraction": covered / px,
                 "parallelism": f"batch-sharded x{world}, final gather to rank 0 only",
             },
             "roofline": roofline,
             "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in sorted(kernels.items())},
         }
+        if world == 1 and not args.no_other_configs:
+            try:
+                out["other_configs"] = other_configs(lib, _lib, device)
+            except Exception as e:
+                out["other_configs"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(verts_cpu, faces_cpu, H, W, K, blur)
+                _, _, _, verts_cpu, faces_cpu = batches[0]
+                out["cpu_baseline"] = cpu_baseline(verts_cpu, faces_cpu, H, W, K, blur, args.cpu_budget_s)
             except Exception as e:  # the baseline must never sink the GPU measurement
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out), flush=True)

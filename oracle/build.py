@@ -39,6 +39,10 @@ _REF_SOURCES = [
     "pytorch3d/csrc/compositing/alpha_composite_cpu.cpp",
     "pytorch3d/csrc/compositing/norm_weighted_sum_cpu.cpp",
     "pytorch3d/csrc/compositing/weighted_sum_cpu.cpp",
+    # not on the hot path: the reference's own unit tests (tests/run_reference_suite.py) reach them through
+    # Meshes.faces_normals_packed / packed_to_padded, so the test runner routes them to the reference's CPU code
+    "pytorch3d/csrc/face_areas_normals/face_areas_normals_cpu.cpp",
+    "pytorch3d/csrc/packed_to_padded_tensor/packed_to_padded_tensor_cpu.cpp",
 ]
 
 

@@ -11,6 +11,8 @@
 #include "compositing/alpha_composite.h"
 #include "compositing/norm_weighted_sum.h"
 #include "compositing/weighted_sum.h"
+#include "face_areas_normals/face_areas_normals.h"
+#include "packed_to_padded_tensor/packed_to_padded_tensor.h"
 #include "rasterize_meshes/rasterize_meshes.h"
 #include "rasterize_points/rasterize_points.h"
 
@@ -32,6 +34,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("_rasterize_meshes_naive", &RasterizeMeshesNaive);
   m.def("_rasterize_meshes_coarse", &RasterizeMeshesCoarse);
   m.def("_rasterize_meshes_fine", &RasterizeMeshesFine);
+  // outside the hot path; used only by tests/run_reference_suite.py to keep the reference's own tests running
+  m.def("face_areas_normals_forward", &FaceAreasNormalsForward);
+  m.def("face_areas_normals_backward", &FaceAreasNormalsBackward);
+  m.def("packed_to_padded", &PackedToPadded);
+  m.def("padded_to_packed", &PaddedToPacked);
   // constants pytorch3d/renderer/points/pulsar/renderer.py reads at import time (ext.cpp:180-185)
   m.attr("EPS") = py::float_(1e-6);
   m.attr("MAX_FLOAT") = py::float_(3.4e38);

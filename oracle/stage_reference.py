@@ -66,6 +66,11 @@ def stage(force=False):
     for f in os.listdir(ddir):
         if f.endswith(".png"):
             _copy(os.path.join(ddir, f), os.path.join(STAGE, "tests", "data", f))
+    for sub in ("missing_usemtl", "missing_files_obj", "obj_mtl_no_image"):  # small OBJ fixtures of test_render_meshes
+        for d, _dirs, files in os.walk(os.path.join(ddir, sub)):
+            for f in files:
+                src = os.path.join(d, f)
+                _copy(src, os.path.join(STAGE, "tests", "data", os.path.relpath(src, ddir)))
     cow = os.path.join(REFERENCE, "docs", "tutorials", "data", "cow_mesh")
     for f in os.listdir(cow):
         _copy(os.path.join(cow, f), os.path.join(STAGE, "docs", "tutorials", "data", "cow_mesh", f))

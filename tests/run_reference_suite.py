@@ -110,6 +110,26 @@ def _device_routed_C():
 
     for name in ours_C.HOT_PATH_EXPORTS:
         setattr(mod, name, route(name, getattr(ours_C, name)))
+
+    # Operators OUTSIDE the hot path that the reference's renderer tests touch on the way (vertex normals, padding):
+    # computed by the reference's CPU code on host copies.  Counted separately; they never reach pytorch3d_amd.
+    def via_cpu(name, theirs):
+        def call(*args, **kwargs):
+            dev = next((a.device for a in args if isinstance(a, torch.Tensor)), torch.device("cpu"))
+            cargs = [a.cpu() if isinstance(a, torch.Tensor) else a for a in args]
+            out = theirs(*cargs, **kwargs)
+            counts.setdefault("outside_path_ref_cpu", {})[name] = counts.get("outside_path_ref_cpu", {}).get(name, 0) + 1
+            if isinstance(out, tuple):
+                return tuple(o.to(dev) if isinstance(o, torch.Tensor) else o for o in out)
+            return out.to(dev) if isinstance(out, torch.Tensor) else out
+
+        call.__name__ = name
+        return call
+
+    if ref is not None:
+        for name in ("face_areas_normals_forward", "face_areas_normals_backward", "packed_to_padded", "padded_to_packed"):
+            if hasattr(ref, name):
+                setattr(mod, name, via_cpu(name, getattr(ref, name)))
     return mod, counts
 
 

@@ -1,0 +1,60 @@
+"""bench.py itself: the single-rank line and the multi-rank code path (two ranks over gloo sharing cuda:0 -- the driver's
+N > 1 launch with `P3D_BENCH_TEST_BACKEND=gloo` standing in for RCCL), in both modes: weak scaling (every rank its own
+batch) and `--jobs` (BASELINE configs[4]: a fixed set of sub-batches dealt to the ranks, final gather timed separately)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(cmd, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=e)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def _check_common(j, n_gpus, steps):
+    assert j["metric"].startswith("rasterized Mpix/s") and j["unit"] == "Mpix/s" and j["dtype"] == "f32"
+    assert j["n_gpus"] == n_gpus and j["steps"] == steps and j["higher_is_better"] is True and j["vs_baseline"] is None
+    assert j["value"] > 0 and j["ms_per_step"] > 0 and "workload" in j["config"]
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    for k, v in r["per_kernel"].items():
+        assert 0 < v["frac_of_peak_compulsory"] < 1, (k, v)
+
+
+def test_single_rank_line_small():
+    j = _run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--batch", "4", "--image-size", "128",
+              "--no-cpu-baseline"])
+    _check_common(j, 1, 3)
+    assert j["scaling"] == "weak" and "other_configs" in j
+    oc = j["other_configs"]
+    assert "wall_ms" in oc["config2_cow_256_k8_fwd"], oc
+    assert "wall_ms" in oc["config4_points_1m_512_k10_fwd_bwd"], oc
+
+
+@pytest.mark.parametrize("mode", ["weak", "jobs"])
+def test_two_ranks_over_gloo_on_one_gpu(mode):
+    port = 29571 if mode == "weak" else 29572
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", "2", "--warmup", "1", "--batch", "4", "--image-size", "128"]
+    cmd += ["--steps", "2"] if mode == "weak" else ["--jobs", "16"]
+    j = _run(cmd, {"P3D_BENCH_TEST_BACKEND": "gloo"})
+    if mode == "weak":
+        _check_common(j, 2, 2)
+        assert j["scaling"] == "weak" and j["config"]["global_batch"] == 8
+    else:
+        _check_common(j, 2, 2)  # 16 jobs = 4 sub-batches of 4, two per rank
+        assert j["scaling"] == "strong" and j["config"]["global_batch"] == 16
+    assert j["gather_ms"] > 0
+    assert "cpu_baseline" not in j  # rank 0 at N = 1 only

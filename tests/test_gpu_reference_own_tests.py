@@ -1,0 +1,99 @@
+"""The REFERENCE's own unit tests, unmodified, on the MI355X kernels through the `pytorch3d._C` shim.
+
+tests/run_reference_suite.py (a subprocess, so that the shim does not leak into the other tests) imports the reference's
+pure-Python package and its test modules from oracle/_ref/reference_py (staged by oracle/stage_reference.py in the build
+container; git-ignored; travels with gpurun) and runs the unittest classes on `cuda` (= HIP).  `_C` calls with HIP tensors
+arrive at pytorch3d_amd; `_C` calls with CPU tensors (the reference's "cpu vs cuda" comparisons) go to the reference's own
+CPU kernels (oracle/_ref/p3d_ref_cpu.so), so those tests compare reference-CPU with our HIP kernels.
+
+Gate: every test of the hot-path modules passes; in the renderer modules only the cases listed in KNOWN may fail, each
+with its reason.  The per-test record is written to gpurun_out/ref_suite.json (and kept under profiles/ per round).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STAGE = os.path.join(ROOT, "oracle", "_ref", "reference_py")
+
+MUST_PASS_MODULES = ["test_rasterize_meshes", "test_rasterize_points", "test_compositing",
+                     "test_interpolate_face_attributes", "test_blending", "test_texturing", "test_shader"]
+RENDER_MODULES = ["test_render_points", "test_render_meshes", "test_rasterize_rectangle_images"]
+
+# test-name substring -> why it cannot pass here
+KNOWN = {
+    "pulsar": "pulsar renderer: outside the hot path (SURVEY.md §2c), _C.PulsarRenderer is not provided",
+    "opengl": "needs EGL / pyopengl (MeshRasterizerOpenGL), not in the image; skipped by PYTORCH3D_NO_TEST_OPENGL",
+    # Both compare a square image with a rescaled non-square one at assertClose's default tolerance (1e-7 abs + 1e-5
+    # rel).  The two renders use different pixel->NDC maps, so equality is a matter of rounding luck: the reference's
+    # CPU kernels happen to pass, arithmetic in the CUDA expression order without FMA contraction differs by 3e-7 in
+    # a handful of barycentrics / 3e-8 in point distances (2.5 ulp).  Not a parity statement about any one render.
+    "TestRasterizeRectangleImagesMeshes.test_gpu": "square-vs-rectangle self-comparison at 1e-7: 3e-7 bary difference",
+    "TestRasterizeRectangleImagesPointclouds.test_gpu": "square-vs-rectangle self-comparison at 1e-7: 3e-8 dists difference",
+}
+
+
+def _known(test_id):
+    low = test_id.lower()
+    for key, why in KNOWN.items():
+        if key.lower() in low:
+            return why
+    return None
+
+
+@pytest.fixture(scope="module")
+def report():
+    if not os.path.isdir(os.path.join(STAGE, "pytorch3d", "renderer")):
+        pytest.skip("oracle/_ref/reference_py is not staged (run __graft_entry__.build() where /root/reference exists)")
+    out = os.path.join(ROOT, "gpurun_out", "ref_suite.json")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "run_reference_suite.py"), "--out", out] + MUST_PASS_MODULES + RENDER_MODULES
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
+    print(res.stdout[-6000:])
+    assert res.returncode == 0, res.stderr[-3000:]
+    with open(out) as f:
+        return json.load(f)
+
+
+def test_reference_hot_path_test_modules_pass_on_the_hip_kernels(report):
+    bad = []
+    n = 0
+    for m in MUST_PASS_MODULES:
+        assert m in report and "__import__" not in report[m], f"{m} did not import: {report.get(m)}"
+        for tid, r in report[m].items():
+            n += 1
+            if r["outcome"] not in ("pass", "skip"):
+                bad.append((tid, r["outcome"], r["msg"].strip().splitlines()[-1] if r["msg"].strip() else ""))
+    print(f"{n} reference tests in {len(MUST_PASS_MODULES)} hot-path modules, {len(bad)} not passing")
+    assert not bad, bad
+    calls = report["__calls__"]
+    assert sum(calls["hip"].values()) > 300, "the HIP operators were hardly called -- are the tests running on the GPU?"
+    for op in ("rasterize_meshes", "rasterize_meshes_backward", "rasterize_points", "rasterize_points_backward",
+               "accum_alphacomposite", "accum_weightedsumnorm", "accum_weightedsum", "interp_face_attrs_forward",
+               "sigmoid_alpha_blend"):
+        assert calls["hip"].get(op, 0) > 0, f"{op} never reached pytorch3d_amd"
+
+
+def test_reference_renderer_test_modules_on_the_hip_kernels(report):
+    """MeshRenderer / PointsRenderer level tests of the reference (PNG fixtures included): everything that is not pulsar /
+    OpenGL must pass, except the two listed self-comparisons."""
+    unexpected, known, passed = [], [], 0
+    for m in RENDER_MODULES:
+        assert m in report and "__import__" not in report[m], f"{m} did not import: {report.get(m)}"
+        for tid, r in report[m].items():
+            if r["outcome"] == "pass":
+                passed += 1
+            elif r["outcome"] == "skip" or _known(tid):
+                known.append((tid.split(".", 2)[-1], r["outcome"], _known(tid) or r["msg"]))
+            else:
+                unexpected.append((tid, r["outcome"], r["msg"].strip().splitlines()[-1] if r["msg"].strip() else ""))
+    print(f"renderer modules: {passed} passed, {len(known)} known / skipped, {len(unexpected)} unexpected")
+    for k in known:
+        print("   known:", k)
+    assert not unexpected, unexpected
+    assert passed >= 30
