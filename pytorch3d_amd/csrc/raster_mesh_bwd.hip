@@ -59,7 +59,7 @@ struct BwdArgs {
   int N, H, W, K;
   int RY, RX;  // regions per image
   int persp, clip;
-  int debug;  // P3D_DEBUG_BWD ablation bits (profiles/ablate.py): 1 no compute, 2 no accumulate, 4 no vertex gathers, 8 no global atomics in the table flush, 16 / 32 see wave_table.h
+  int debug;  // P3D_DEBUG_BWD ablation bits (profiles/ablate.py): 1 no compute, 2 no accumulate, 4 no vertex gathers, 8 no global atomics in the table flush, 16 / 32 see wave_table.h, 64 no per-lane slot permutation
 };
 
 // Row loaders: KT contiguous elements starting at a (KT * elemsize)-aligned address.
@@ -99,6 +99,39 @@ __device__ __forceinline__ void load_f32_row(const float* p, float (&out)[M]) {
   } else {
 #pragma unroll
     for (int k = 0; k < M; ++k) out[k] = p[k];
+  }
+}
+
+// The same rows with the slot PAIRS permuted: out pair j <- memory pair j ^ m (m < KT / 2).  C floats per slot.
+template <int KT>
+__device__ __forceinline__ void load_idx_row_pairs(const int64_t* p, int m, int (&out)[KT]) {
+  if constexpr (KT % 2 == 0) {
+#pragma unroll
+    for (int j = 0; j < KT / 2; ++j) {
+      const longlong2 t = *reinterpret_cast<const longlong2*>(p + 2 * (j ^ m));
+      out[2 * j] = (int)t.x;
+      out[2 * j + 1] = (int)t.y;
+    }
+  } else {
+    load_idx_row<KT>(p, out);
+  }
+}
+
+template <int KT, int C>
+__device__ __forceinline__ void load_f32_row_pairs(const float* p, int m, float (&out)[KT * C]) {
+  if constexpr (KT >= 4) {
+#pragma unroll
+    for (int j = 0; j < KT / 2; ++j) {
+      const float* src = p + 2 * C * (j ^ m);  // 8-byte aligned: rows start on 16-byte boundaries, pairs are 8 * C bytes
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float2 t = *reinterpret_cast<const float2*>(src + 2 * c);
+        out[2 * C * j + 2 * c] = t.x;
+        out[2 * C * j + 2 * c + 1] = t.y;
+      }
+    }
+  } else {
+    load_f32_row<KT * C>(p, out);
   }
 }
 
@@ -143,16 +176,23 @@ __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
       int f[KT];
 #pragma unroll
       for (int k = 0; k < KT; ++k) f[k] = -1;
-      if (ok) load_idx_row<KT>(a.p2f + base, f);
+      // Neighbouring pixels hold (nearly) the same faces in the same depth order, so at a common slot k many lanes of
+      // the wave hit ONE face and the table step has to sum long lists (log2(group) rounds of pointer jumping, the most
+      // expensive part of this kernel).  Each lane therefore walks its K slots in its own order: slot PAIR j ^ m, with
+      // m distinct within every 2x2 pixel block -- the same (pixel, slot) samples, spread so that a step sees ~4x fewer
+      // lanes per face.  The permutation is done by the loads (pairs are 16 / 8 / 8 / 24 bytes of the four rows): it
+      // costs no VALU and no registers (a butterfly of conditional swaps over the 48 row registers spilled 76 of them).
+      const int m = (KT >= 4 && !(P3D_DBG(a) & 64)) ? (((lane & 1) | (((lane >> 3) & 1) << 1)) & (KT / 2 - 1)) : 0;
+      if (ok) load_idx_row_pairs<KT>(a.p2f + base, m, f);
       bool any = false;
 #pragma unroll
       for (int k = 0; k < KT; ++k) any |= f[k] >= 0;
       if (__ballot(any) == 0) continue;  // wave-uniform: nothing rendered in this 8x8 tile
       float gz[KT], gd[KT], gb[3 * KT];
       if (any) {
-        load_f32_row<KT>(a.grad_zbuf + base, gz);
-        load_f32_row<KT>(a.grad_dists + base, gd);
-        load_f32_row<3 * KT>(a.grad_bary + base * 3, gb);
+        load_f32_row_pairs<KT, 1>(a.grad_zbuf + base, m, gz);
+        load_f32_row_pairs<KT, 1>(a.grad_dists + base, m, gd);
+        load_f32_row_pairs<KT, 3>(a.grad_bary + base * 3, m, gb);
       }
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
