@@ -312,3 +312,23 @@ def sample_uv_backward(grad_texels, pix_to_face, bary, face_uvs, maps, align_cor
     lib().orc_sample_uv_backward(_p(g), _p(p2f), _p(b), _p(fu), _p(mp), N, ctypes.c_int64(H * W * K), ctypes.c_int64(F), Hm,
                                  Wm, C, int(align_corners), _PAD[padding_mode], _SMODE[sampling_mode], _p(gb), _p(gfu), _p(gm))
     return gb, gfu, gm
+
+
+_ref_hip = {}
+
+
+def ref_hip_module(nofma=False):
+    """The reference's own CUDA kernels built for gfx950 (oracle/build_ref_hip.py), or None.  nofma: the variant compiled
+    with -ffp-contract=off (the reference's expression order itself); default: hipcc's defaults, like a user's build."""
+    key = bool(nofma)
+    if key in _ref_hip:
+        return _ref_hip[key]
+    name = "p3d_ref_hip_nofma" if nofma else "p3d_ref_hip"
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", name + ".so")
+    mod = None
+    if os.path.exists(path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    _ref_hip[key] = mod
+    return mod
