@@ -7,8 +7,12 @@ the reference's device code evaluates exactly the expression trees SURVEY.md app
   * pix_to_face / point idx must be IDENTICAL and zbuf / bary / dists BIT-EQUAL between our kernels and the
     reference's -- this pins the "CUDA order" branch of the C oracle (and our kernels) to the reference's device code bit
     for bit, at small sizes, on the cow (BASELINE configs[1]) and on bench meshes at 512^2 (configs[2]);
-  * the one documented deviation is the reference CUDA queue's eviction rule among entries that tie exactly at the
-    maximum depth (SURVEY appendix A "Top-K"); no tie occurs in these inputs.
+  * the one documented deviation is the order / eviction among entries whose depths tie EXACTLY: we keep the total order
+    (z, index) of the reference's CPU and Python implementations, the reference's CUDA queue evicts the first maximum
+    it finds and bubble-sorts by z alone (SURVEY appendix A "Top-K").  Exact ties are common with clipped barycentrics
+    (two faces seen from outside across their shared edge both clip to that edge).  So: zbuf must be bit-equal
+    everywhere, and wherever the index agrees bary / dists must be bit-equal; index differences may only sit in slots
+    whose depth ties with another candidate, their count is printed.
 
 oracle/_ref/p3d_ref_hip.so (hipcc defaults: FMA contraction, like nvcc's -fmad=true) is what a user of the reference would
 run: against it the north_star tolerances apply (indices equal up to tie swaps, floats within 1e-5).
@@ -50,6 +54,29 @@ def _both(mod, fv, first, count, nbr, size, blur, K, bin_size, M, persp=True, cl
     return [o.cpu() for o in ours], [t.cpu() for t in theirs]
 
 
+def _assert_equal_up_to_exact_depth_ties(tag, ours, theirs, max_frac=2e-3):
+    n_idx, bit, diffs = _cmp(tag, ours, theirs)
+    assert bit[0], f"{tag}: zbuf is not bit-equal"
+    assert max(diffs) == 0.0, f"{tag}: bary / dists differ where the index agrees: {diffs}"
+    if n_idx:
+        # a differing slot must tie in depth with a neighbouring slot of its pixel, or be the last slot (the tie partner
+        # is the candidate that was evicted)
+        z = ours[1]
+        K = z.shape[-1]
+        tie_prev = torch.zeros_like(z, dtype=torch.bool)
+        tie_prev[..., 1:] = z[..., 1:] == z[..., :-1]
+        tie_next = torch.zeros_like(z, dtype=torch.bool)
+        tie_next[..., :-1] = z[..., :-1] == z[..., 1:]
+        last = torch.zeros_like(z, dtype=torch.bool)
+        last[..., K - 1] = True
+        diff = ours[0] != theirs[0]
+        unexplained = int((diff & ~(tie_prev | tie_next | last)).sum())
+        print(f"[{tag}] {n_idx} index differences, all at exact depth ties: {unexplained == 0}")
+        assert unexplained == 0
+        assert n_idx <= max_frac * diff.numel()
+    return n_idx
+
+
 def _cmp(tag, ours, theirs):
     same = ours[0] == theirs[0]
     n_idx = int((~same).sum())
@@ -72,8 +99,7 @@ def test_small_soups_bit_equal_to_reference_device_code(persp, clip, cull):
     nbr = torch.full((F,), -1, dtype=torch.int64)
     for size, blur, bs in (((64, 64), 0.0, 0), ((64, 64), 0.01, 16), ((48, 80), 0.003, 0), ((80, 48), 0.003, 8)):
         ours, theirs = _both(mod, fv, first, count, nbr, size, blur, K, bs, 400 if bs else 0, persp, clip, cull)
-        n_idx, bit, _ = _cmp(f"soup {size} blur {blur} bin {bs}", ours, theirs)
-        assert n_idx == 0 and all(bit)
+        _assert_equal_up_to_exact_depth_ties(f"soup {size} blur {blur} bin {bs}", ours, theirs)
 
 
 def test_cow_and_bench_meshes_bit_equal_to_reference_device_code():
@@ -85,8 +111,7 @@ def test_cow_and_bench_meshes_bit_equal_to_reference_device_code():
     count = torch.tensor([F], dtype=torch.int64)
     nbr = torch.full((F,), -1, dtype=torch.int64)
     ours, theirs = _both(mod, fv, first, count, nbr, (256, 256), 1e-4, 8, 16, 10000)
-    n_idx, bit, _ = _cmp("cow 256^2 K=8 (configs[1])", ours, theirs)
-    assert n_idx == 0 and all(bit)
+    _assert_equal_up_to_exact_depth_ties("cow 256^2 K=8 (configs[1])", ours, theirs)
     # configs[2]: four bench meshes incl. the largest, 512^2, K=8, SoftRas blur; bin_size 32, M large enough for 20k faces
     verts, faces = U.hetero_batch(64, seed=0)
     nf = [int(f.shape[0]) for f in faces]
@@ -99,8 +124,7 @@ def test_cow_and_bench_meshes_bit_equal_to_reference_device_code():
     first, count = m.mesh_to_faces_packed_first_idx(), m.num_faces_per_mesh()
     nbr = torch.full((fv.shape[0],), -1, dtype=torch.int64)
     ours, theirs = _both(mod, fv, first, count, nbr, (512, 512), SOFTRAS_BLUR, 8, 32, 10000)
-    n_idx, bit, _ = _cmp("bench meshes 512^2 K=8 (configs[2])", ours, theirs)
-    assert n_idx == 0 and all(bit)
+    _assert_equal_up_to_exact_depth_ties("bench meshes 512^2 K=8 (configs[2])", ours, theirs)
     # backward on the same fragments: the reference's device backward vs ours
     from pytorch3d_amd import _C
 
@@ -130,12 +154,17 @@ def test_points_and_compositors_vs_reference_device_code():
     radius = torch.full((P,), r, device=d)
     a = _C.rasterize_points(pts, first, count, (H, W), radius, K, 32, 100000)
     b = mod.rasterize_points(pts, first, count, (H, W), radius, K, 32, 100000)
-    # the reference's point queue keeps the K nearest by z without an index tie-break: compare as (z, idx) sets per pixel
+    # the reference's point queue orders by z alone; ours by (z, idx): indices may differ only where depths tie exactly
     assert torch.equal(a[1], b[1]), "zbuf"
     same = a[0] == b[0]
-    print(f"[points] idx mismatches {int((~same).sum())} / {same.numel()}")
-    assert int((~same).sum()) == 0
-    assert torch.equal(a[2], b[2])
+    z = a[1]
+    tie = torch.zeros_like(same)
+    tie[..., 1:] |= z[..., 1:] == z[..., :-1]
+    tie[..., :-1] |= z[..., :-1] == z[..., 1:]
+    tie[..., K - 1] = True
+    print(f"[points] idx differences {int((~same).sum())} / {same.numel()}, all at exact depth ties: {bool((same | tie).all())}")
+    assert bool((same | tie).all()) and int((~same).sum()) < 1e-4 * same.numel()
+    assert torch.equal(a[2][same], b[2][same])
     idx = a[0].long().permute(0, 3, 1, 2)
     alphas = (1 - a[2] / (r * r)).clamp(0, 1).permute(0, 3, 1, 2)
     feats = torch.rand(5, P, generator=gen).to(d)
