@@ -48,6 +48,11 @@ def sigmoid_alpha_blend(colors, fragments, blend_params: BlendParams) -> torch.T
 def _background(blend_params, device):
     bg = blend_params.background_color
     if isinstance(bg, torch.Tensor):
+        if bg.requires_grad:
+            # the reference keeps the background in the autograd graph (blending.py:183-186); the fused kernel takes it
+            # as three constants -- refuse rather than return a silently missing gradient
+            raise NotImplementedError("softmax_rgb_blend: a background_color that requires grad is not supported by the "
+                                      "fused kernel (it is passed as constants); detach it or blend with torch ops")
         bg = [float(x) for x in bg.detach().reshape(-1).tolist()]
     bg = [float(x) for x in bg]
     if len(bg) != 3:
@@ -58,6 +63,9 @@ def _background(blend_params, device):
 def _plane(v, N, device):
     """znear / zfar: float, or a per-batch-element tensor (blending.py:205-210).  -> (scalar, device tensor or None)"""
     if torch.is_tensor(v):
+        if v.requires_grad:
+            raise NotImplementedError("softmax_rgb_blend: znear / zfar tensors that require grad are not supported by the "
+                                      "fused kernel; detach them")
         t = v.detach().to(device=device, dtype=torch.float32).reshape(-1)
         if t.numel() == 1:
             t = t.expand(N)

@@ -39,6 +39,11 @@ inline BinGeom make_geom(int H, int W, int bin_size) {
 // streams only primitives that touch its own tile, instead of its whole 32x32 (or larger) bin --
 // doubling the bin side until at most 32 bins span the image, and never coarser than the caller's
 // bin_size.  The test-visible _rasterize_*_coarse / _fine operators keep the caller's geometry.
+// Overflow: the caller's max_faces_per_bin caps every INTERNAL bin's list.  An internal bin that lies inside one user bin
+// (always the case when the user bin_size is a multiple of the internal one, e.g. the reference's defaults 16..128 vs
+// 16) holds a subset of that user bin's faces, so it overflows only where the reference's bin would have ("Bin size
+// was too small", rasterize_coarse.cu:186-201: faces dropped there too); with a non-multiple user bin_size an internal bin
+// can straddle two user bins and reach the cap a little earlier than either of them.
 inline BinGeom make_internal_geom(int H, int W, int user_bin_size) {
   int b = 16;
   const int m = H > W ? H : W;

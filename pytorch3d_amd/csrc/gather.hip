@@ -13,16 +13,22 @@
 namespace p3d {
 namespace {
 
+// Indices follow torch indexing: a negative id wraps once (v + V).  torch device-asserts on ids still out of range;
+// here nothing outside `verts` is ever touched and the face gets NaN coordinates (visible downstream, never silent
+// garbage); the scatters drop such corners.
 __global__ __launch_bounds__(256) void gather_faces_kernel(const float* __restrict__ verts,
-                                                           const int64_t* __restrict__ faces, int64_t n_corners,
+                                                           const int64_t* __restrict__ faces, int64_t V, int64_t n_corners,
                                                            float* __restrict__ face_verts) {
   for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n_corners; c += (int64_t)gridDim.x * 256) {
-    const int64_t v = faces[c];
-    const float* s = verts + v * 3;
+    int64_t v = faces[c];
+    if (v < 0) v += V;
+    const bool ok = v >= 0 && v < V;
+    const float* s = verts + (ok ? v : 0) * 3;
     float* d = face_verts + c * 3;
-    d[0] = s[0];
-    d[1] = s[1];
-    d[2] = s[2];
+    const float nan = __int_as_float(0x7fc00000);
+    d[0] = ok ? s[0] : nan;
+    d[1] = ok ? s[1] : nan;
+    d[2] = ok ? s[2] : nan;
   }
 }
 
@@ -32,8 +38,9 @@ __global__ __launch_bounds__(256) void gather_faces_kernel(const float* __restri
 using VertTable = WaveTable<3, 426>;  // 4 waves x 426 x 24 B = 40 KB
 
 __global__ __launch_bounds__(256) void scatter_face_grads_kernel(const float* __restrict__ grad_face_verts,
-                                                                 const int64_t* __restrict__ faces, int64_t n_corners,
-                                                                 int64_t span, float* __restrict__ grad_verts) {
+                                                                 const int64_t* __restrict__ faces, int64_t V,
+                                                                 int64_t n_corners, int64_t span,
+                                                                 float* __restrict__ grad_verts) {
   __shared__ __align__(16) int s_table[4][VertTable::kLdsInts];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t begin = ((int64_t)blockIdx.x * 4 + w) * span;
@@ -46,7 +53,9 @@ __global__ __launch_bounds__(256) void scatter_face_grads_kernel(const float* __
     int v = -1;
     float g[3] = {0.f, 0.f, 0.f};
     if (c < end) {
-      v = (int)faces[c];
+      int64_t vi = faces[c];
+      if (vi < 0) vi += V;
+      v = (vi >= 0 && vi < V) ? (int)vi : -1;
       const float* s = grad_face_verts + c * 3;
       g[0] = s[0];
       g[1] = s[1];
@@ -72,7 +81,7 @@ P3D_API int p3d_gather_face_verts(const float* verts, const int64_t* faces, int6
   int64_t blocks = ceil_div(n, 256);
   if (blocks > 256 * 16) blocks = 256 * 16;
   LaunchScope ls("gather_face_verts", s);
-  gather_faces_kernel<<<(unsigned)blocks, 256, 0, s>>>(verts, faces, n, face_verts);
+  gather_faces_kernel<<<(unsigned)blocks, 256, 0, s>>>(verts, faces, V, n, face_verts);
   return launch_status();
 }
 
@@ -91,6 +100,6 @@ P3D_API int p3d_scatter_face_grads(const float* grad_face_verts, const int64_t* 
   const int64_t blocks = ceil_div(waves, 4);
   const int64_t span = ceil_div(ceil_div(n, blocks * 4), 64) * 64;
   LaunchScope ls("scatter_face_grads", s);
-  scatter_face_grads_kernel<<<(unsigned)blocks, 256, 0, s>>>(grad_face_verts, faces, n, span, grad_verts);
+  scatter_face_grads_kernel<<<(unsigned)blocks, 256, 0, s>>>(grad_face_verts, faces, V, n, span, grad_verts);
   return launch_status();
 }

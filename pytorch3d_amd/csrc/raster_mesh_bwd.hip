@@ -56,6 +56,7 @@ struct BwdArgs {
   const float* grad_dists;
   float* grad_fv;           // (F,3,3), or (V,3) with `faces`
   const int64_t* faces;     // (F,3) or null: send the partials of face f to grad_verts[faces[f]] instead of grad_face_verts[f]
+  int64_t V;  // vertices behind `faces` (index check of the fused scatter), -1 without
   int N, H, W, K;
   int RY, RX;  // regions per image
   int persp, clip;
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
   Table tab;
   tab.init(s_table[w], lane);
   tab.index = a.faces;
+  tab.index_limit = a.V;
   tab.no_atomics = (P3D_DBG(a) & 8) != 0;
   tab.dbg = P3D_DBG(a);
   const bool persp = a.persp != 0, clip = a.clip != 0;
@@ -272,10 +274,11 @@ __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
 using namespace p3d;
 
 namespace {
-int launch_mesh_backward(const float* face_verts, const int64_t* faces, const int64_t* p2f, const float* grad_zbuf,
+int launch_mesh_backward(const float* face_verts, const int64_t* faces, int64_t V, const int64_t* p2f, const float* grad_zbuf,
                          const float* grad_bary, const float* grad_dists, int N, int H, int W, int K, int persp, int clip,
                          float* grad_out, hipStream_t s) {
   BwdArgs a;
+  a.V = V;
   a.face_verts = face_verts;
   a.p2f = p2f;
   a.grad_zbuf = grad_zbuf;
@@ -330,7 +333,7 @@ P3D_API int p3d_rasterize_meshes_backward(const float* face_verts, const int64_t
   if (hipMemsetAsync(grad_face_verts, 0, (size_t)F * 9 * sizeof(float), s) != hipSuccess) return P3D_ERR_LAUNCH;
   if ((int64_t)N * H * W * K == 0) return P3D_OK;
   if (!p2f || !grad_zbuf || !grad_bary || !grad_dists) return P3D_ERR_INVALID_ARG;
-  return launch_mesh_backward(face_verts, nullptr, p2f, grad_zbuf, grad_bary, grad_dists, N, H, W, K, persp, clip,
+  return launch_mesh_backward(face_verts, nullptr, -1, p2f, grad_zbuf, grad_bary, grad_dists, N, H, W, K, persp, clip,
                               grad_face_verts, s);
 }
 
@@ -345,6 +348,6 @@ P3D_API int p3d_rasterize_meshes_backward_verts(const float* face_verts, const i
   if (hipMemsetAsync(grad_verts, 0, (size_t)V * 3 * sizeof(float), s) != hipSuccess) return P3D_ERR_LAUNCH;
   if (F == 0 || (int64_t)N * H * W * K == 0) return P3D_OK;
   if (!face_verts || !faces || !p2f || !grad_zbuf || !grad_bary || !grad_dists) return P3D_ERR_INVALID_ARG;
-  return launch_mesh_backward(face_verts, faces, p2f, grad_zbuf, grad_bary, grad_dists, N, H, W, K, persp, clip,
+  return launch_mesh_backward(face_verts, faces, V, p2f, grad_zbuf, grad_bary, grad_dists, N, H, W, K, persp, clip,
                               grad_verts, s);
 }

@@ -32,10 +32,10 @@ struct TexArgs {
   int64_t HWK;
 };
 
-// torch.lerp(start, end, w): start + w * (end - start) below 0.5, end - (end - start) * (1 - w) from 0.5 on
+// torch.lerp(start, end, w) (ATen/native/Lerp.h): start + w * (end - start) where |w| < 0.5, end - (end - start) * (1 - w) elsewhere
 __device__ __forceinline__ float lerp_t(float start, float end, float w) {
   const float diff = end - start;
-  return w < 0.5f ? start + w * diff : end - diff * (1.0f - w);
+  return fabsf(w) < 0.5f ? start + w * diff : end - diff * (1.0f - w);
 }
 
 // GridSampler.h: grid_sampler_compute_source_index_set_grad for padding zeros / border.  mult = d index / d coord.

@@ -53,12 +53,21 @@ struct WaveTable {
   int pitch = 0;            // kChunk: floats between the NV/4 sub-rows of a record
   int nlive = NV;           // kPlanar: planes that exist; kChunk: live columns of the chunk (others are never flushed)
   const int64_t* index = nullptr;  // kCorners: (P, NV/3) vertex ids
+  int64_t index_limit = -1;        // kCorners: number of vertices; ids outside [0, limit) have no destination (negative
+                                   // ids wrap once, as torch indexing does).  -1: unchecked
 
   // address of value j of primitive f, or nullptr when that value has no destination
   __device__ __forceinline__ float* dest(float* __restrict__ out, int f, int j) const {
     if constexpr (LAYOUT == kPlanar) return j < nlive ? out + j * plane + f : nullptr;
     if constexpr (LAYOUT == kChunk) return (j & 3) < nlive ? out + (int64_t)f * plane + (j >> 2) * pitch + (j & 3) : nullptr;
-    if constexpr (LAYOUT == kCorners) return out + index[(int64_t)f * (NV / 3) + j / 3] * 3 + j % 3;
+    if constexpr (LAYOUT == kCorners) {
+      int64_t v = index[(int64_t)f * (NV / 3) + j / 3];
+      if (index_limit >= 0) {
+        if (v < 0) v += index_limit;
+        if (v < 0 || v >= index_limit) return nullptr;
+      }
+      return out + v * 3 + j % 3;
+    }
     return out + (int64_t)f * NV + j;
   }
   bool no_atomics = false;  // ablation only (profiles/ablate.py): drop the global atomics of flush()

@@ -107,7 +107,9 @@ def rasterize_meshes(
 
 def _gatherable(verts_packed, faces_packed):
     return (verts_packed.is_cuda and verts_packed.dtype == torch.float32 and faces_packed.dtype == torch.int64
-            and faces_packed.device == verts_packed.device and verts_packed.dim() == 2 and faces_packed.dim() == 2)
+            and faces_packed.device == verts_packed.device and verts_packed.dim() == 2 and faces_packed.dim() == 2
+            # the kernels move xyz triples of triangle corners: anything else ((V, C) attributes, quads) takes torch indexing
+            and verts_packed.shape[1] == 3 and faces_packed.shape[1] == 3)
 
 
 def gather_face_verts(verts_packed, faces_packed):

@@ -462,3 +462,38 @@ def test_operators_are_reentrant_across_threads_and_streams():
     for (o_ref, g_ref), (o, g) in zip(ref, got):
         assert all(torch.equal(a, b) for a, b in zip(o_ref, o))
         assert torch.allclose(g, g_ref, rtol=1e-4, atol=1e-5 * g_ref.abs().max().item())
+
+
+def test_gather_face_verts_index_and_shape_rules():
+    """`verts_packed[faces_packed]` replacement: negative ids wrap like torch indexing, ids out of range never touch memory
+    outside `verts` (NaN forward, dropped in the backward), and anything that is not (V,3) x (F,3) takes torch indexing."""
+    from pytorch3d_amd.rasterize_meshes import gather_face_verts
+
+    d = _dev()
+    gen = torch.Generator().manual_seed(4)
+    V, F = 50, 80
+    verts = torch.randn(V, 3, generator=gen).to(d).requires_grad_(True)
+    faces = torch.randint(0, V, (F, 3), generator=gen).to(d)
+    neg = faces.clone()
+    neg[::3] -= V  # the same vertices, addressed from the end
+    a = gather_face_verts(verts, neg)
+    assert torch.equal(a, verts[faces])
+    g = torch.randn(F, 3, 3, generator=gen).to(d)
+    (ga,) = torch.autograd.grad(a, verts, g)
+    (gr,) = torch.autograd.grad(verts[faces], verts, g)
+    assert torch.allclose(ga, gr, atol=1e-5)
+    bad = faces.clone()
+    bad[5, 1] = V + 7
+    bad[9, 2] = -V - 3
+    b = gather_face_verts(verts, bad)
+    assert torch.isnan(b[5, 1]).all() and torch.isnan(b[9, 2]).all()
+    ok = torch.ones(F, 3, dtype=torch.bool, device=d)
+    ok[5, 1] = ok[9, 2] = False
+    assert torch.equal(b[ok], verts[faces][ok])
+    (gb,) = torch.autograd.grad(b, verts, g)
+    assert torch.isfinite(gb).all()
+    # (V, C != 3) attributes and non-triangles: plain torch semantics
+    attrs = torch.randn(V, 5, generator=gen).to(d)
+    assert torch.equal(gather_face_verts(attrs, faces), attrs[faces])
+    quads = torch.randint(0, V, (F, 4), generator=gen).to(d)
+    assert torch.equal(gather_face_verts(verts, quads), verts[quads])
