@@ -36,8 +36,12 @@ struct PointArgs {
   float* dists;
 };
 
-template <typename Queue, int KT, bool IN_REGS, bool BINNED>
-__global__ __launch_bounds__(kStage) void point_raster_kernel(PointArgs a) {
+// PAYLOAD: the queue carries dist2 next to (z, idx).  Without it (long queues: 2 registers per entry instead of 3) the
+// distance is recomputed from the point's coordinates when the pixel is written -- the same two subtractions, two
+// products and one sum as in the test (rasterize_points.cu:55-60), so the same bits.
+// WAVES: minimum waves per SIMD the register allocation has to leave room for (512 / WAVES VGPRs per lane).
+template <typename Queue, int KT, bool IN_REGS, bool BINNED, bool PAYLOAD = true, int WAVES = 2>
+__global__ __launch_bounds__(kStage, WAVES) void point_raster_kernel(PointArgs a) {
   __shared__ float4 s_box[kStage];  // x-r, x+r, y-r, y+r
   __shared__ float4 s_pt[kStage];   // x, y, z, r*r
   __shared__ int s_idx[kStage];
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(kStage) void point_raster_kernel(PointArgs a) {
           if (pix_ok && dist2 < pt.w) {
             const int id = s_idx[jj];
             if (q.admits(K, pt.z, id)) {
-              const float pl[1] = {dist2};
+              const float pl[1] = {dist2};  // ignored by a queue without payload
               q.insert(K, pt.z, id, pl);
             }
           }
@@ -169,7 +173,18 @@ __global__ __launch_bounds__(kStage) void point_raster_kernel(PointArgs a) {
           const bool ok = q.valid(k);
           a.idxs[base + k] = ok ? q.idx[k] : -1;
           a.zbuf[base + k] = ok ? q.z[k] : -1.0f;
-          a.dists[base + k] = ok ? q.pl[0][k] : -1.0f;
+          if constexpr (PAYLOAD) {
+            a.dists[base + k] = ok ? q.pl[0][k] : -1.0f;
+          } else {
+            float d2 = -1.0f;
+            if (ok) {
+              const float* g = a.points + (int64_t)q.idx[k] * 3;
+              const float dx = xf - g[0];
+              const float dy = yf - g[1];
+              d2 = dx * dx + dy * dy;
+            }
+            a.dists[base + k] = d2;
+          }
         }
       }
     } else {
@@ -206,7 +221,16 @@ int launch_point_raster(const PointArgs& a, hipStream_t stream) {
     point_raster_kernel<TopKReg<24, 1>, 24, true, BINNED><<<grid, kStage, 0, stream>>>(a);
   else if (K <= 32)
     point_raster_kernel<TopKReg<32, 1>, 32, true, BINNED><<<grid, kStage, 0, stream>>>(a);
-  else
+  // Longer queues stay in registers too, without the payload.  A dense cloud keeps the queue full (~80 splats cover a
+  // pixel at the BASELINE density), so a queue in private memory shifts O(K) entries through scratch for every
+  // admitted splat (K = 50: 7.8 ms, K = 100: 14.7 ms); here an insertion is ~5 VALU per slot on registers.
+  else if (K <= 48)
+    point_raster_kernel<TopKReg<48, 0>, 48, true, BINNED, false, 2><<<grid, kStage, 0, stream>>>(a);
+  else if (K <= 64)
+    point_raster_kernel<TopKReg<64, 0>, 64, true, BINNED, false, 2><<<grid, kStage, 0, stream>>>(a);
+  else if (K <= 100)  // one wave per SIMD: 200 queue registers, the upper ones in AGPRs
+    point_raster_kernel<TopKReg<100, 0>, 100, true, BINNED, false, 1><<<grid, kStage, 0, stream>>>(a);
+  else  // 101..150: 300 queue registers do not fit the 256 VGPRs + 256 AGPRs of a lane without scratch
     point_raster_kernel<TopKMem<P3D_MAX_K, 1>, P3D_MAX_K, false, BINNED><<<grid, kStage, 0, stream>>>(a);
   return launch_status();
 }

@@ -25,9 +25,10 @@ constexpr int kEmptyIdx = 0x7fffffff;
 
 template <int KT, int NP>
 struct TopKReg {
+  static constexpr int NPS = NP > 0 ? NP : 1;  // storage rows; NP = 0: no payload (the one row is never touched and costs no register)
   float z[KT];
   int idx[KT];
-  float pl[NP][KT];
+  float pl[NPS][KT];
 
   // (kz, ki): the K-th entry of the live queue -- what a candidate has to beat -- cached so that the
   // admission test is one compare also when K < KT (+inf / kEmptyIdx while the queue has room).
@@ -67,7 +68,7 @@ struct TopKReg {
   // slots update independently of each other (select depth 2) -- a compare-exchange chain that
   // carries the displaced entry from slot to slot has the same instruction count but a dependency
   // chain 2*KT long, which a SIMD with 3-4 resident waves cannot hide.
-  P3D_HDM void insert(int K, float cz, int cidx, const float (&cpl)[NP]) {
+  P3D_HDM void insert(int K, float cz, int cidx, const float (&cpl)[NPS]) {
     bool lt[KT];
 #pragma unroll
     // bitwise, not short-circuit: `||` / `&&` compile to exec-masked branches (12 instructions per slot instead of 5)

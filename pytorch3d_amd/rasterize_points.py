@@ -1,77 +1,89 @@
-"""Host-side mirror of pytorch3d/renderer/points/rasterize_points.py:24-242 over pytorch3d_amd._C."""
-from typing import List, Optional, Tuple, Union
+"""Point-cloud rasterization over `PackedPointclouds` (pytorch3d_amd/structures.py) on the HIP kernels.
 
-import numpy as np
+Same call as the reference's `rasterize_points` (pytorch3d/renderer/points/rasterize_points.py:24-132: argument names,
+defaults, the returned `(idx int32, zbuf, dists2)` of shape (N, H, W, points_per_pixel), the bin-size heuristic and its
+error), so code written against the reference keeps working; the unmodified reference wrapper itself also runs on these
+kernels through `pytorch3d_amd.shim`.  What differs is the host side: everything is derived from the packed layout, the
+radius may also be given per packed point, and a scalar radius is materialised on the device.
+"""
+import math
+from typing import Optional, Sequence, Tuple, Union
+
 import torch
 
 from . import _C
 from .rasterize_meshes import parse_image_size
 
-kMaxPointsPerBin = 22  # rasterize_points.py:21
+MAX_BINS_PER_SIDE = 22  # rasterize_points.py:21 (kMaxPointsPerBin): bins along the longer image side must stay below this
+
+Radius = Union[float, int, Sequence[float], torch.Tensor]
 
 
-def rasterize_points(
-    pointclouds,
-    image_size: Union[int, List[int], Tuple[int, int]] = 256,
-    radius: Union[float, List, Tuple, torch.Tensor] = 0.01,
-    points_per_pixel: int = 8,
-    bin_size: Optional[int] = None,
-    max_points_per_bin: Optional[int] = None,
-):
-    """Returns (idx int32, zbuf, dists2), each (N, H, W, points_per_pixel)."""
-    points_packed = pointclouds.points_packed()
-    cloud_to_packed_first_idx = pointclouds.cloud_to_packed_first_idx()
-    num_points_per_cloud = pointclouds.num_points_per_cloud()
-    radius = _format_radius(radius, pointclouds)
-    im_size = parse_image_size(image_size)
-    max_image_size = max(*im_size)
-    if bin_size is None:
-        # rasterize_points.py:104-113 -- unlike meshes there is no "<= 64 -> 8" special case
-        bin_size = int(2 ** max(np.ceil(np.log2(max_image_size)) - 4, 4))
-    if bin_size != 0:
-        points_per_bin = 1 + (max_image_size - 1) // bin_size
-        if points_per_bin >= kMaxPointsPerBin:
-            raise ValueError("bin_size too small, number of points per bin must be less than %d; got %d" %
-                             (kMaxPointsPerBin, points_per_bin))
-    if max_points_per_bin is None:
-        max_points_per_bin = int(max(10000, pointclouds._P / 5))
-    return _RasterizePoints.apply(points_packed, cloud_to_packed_first_idx, num_points_per_cloud, im_size, radius,
-                                  points_per_pixel, bin_size, max_points_per_bin)
+def default_bin_size(longest_side: int) -> int:
+    """The reference's choice when bin_size is None (rasterize_points.py:104-113): 2^max(ceil(log2(side)) - 4, 4)."""
+    return 1 << max(int(math.ceil(math.log2(longest_side))) - 4, 4)
 
 
-def _format_radius(radius, pointclouds) -> torch.Tensor:
-    """rasterize_points.py:145-184: float / list / tuple / (N, P_padded) tensor -> (P_packed,)."""
-    N, P_padded = pointclouds._N, pointclouds._P
-    points_packed = pointclouds.points_packed()
-    P_packed = points_packed.shape[0]
+def radius_per_packed_point(radius: Radius, clouds) -> torch.Tensor:
+    """One float32 radius per packed point, on the points' device.
+
+    scalar                  every point
+    tensor / list (P_pack,) already per packed point
+    tensor / list (N, P)    the reference's padded form (rasterize_points.py:145-184); P = the largest cloud.  A 1-D
+                            input of length P with a single cloud is read as (1, P), as the reference does.
+    """
+    pts = clouds.points_packed()
+    n_packed = pts.shape[0]
+    if isinstance(radius, (float, int)) and not isinstance(radius, bool):
+        return torch.full((n_packed,), float(radius), dtype=pts.dtype, device=pts.device)
     if isinstance(radius, (list, tuple)):
-        radius = torch.tensor(radius).type_as(points_packed)
-    if isinstance(radius, torch.Tensor):
-        if N == 1 and radius.ndim == 1:
-            radius = radius[None, ...]
-        if radius.shape != (N, P_padded):
-            raise ValueError("radius must be of shape (N, P): got %s" % repr(radius.shape))
-        radius = radius.view(-1)[pointclouds.padded_to_packed_idx()]
-    elif isinstance(radius, float):
-        # same values as the reference's CPU-side fill + type_as, without the host buffer and the H2D copy
-        radius = torch.full((P_packed,), radius, dtype=points_packed.dtype, device=points_packed.device)
-    else:
+        radius = torch.as_tensor(radius)
+    if not torch.is_tensor(radius):
         raise ValueError("radius must be a float, list, tuple or tensor; got %s" % type(radius))
-    return radius
+    r = radius.to(device=pts.device, dtype=pts.dtype)
+    if r.dim() == 0:
+        return r.expand(n_packed).contiguous()
+    n_clouds, p_max = len(clouds), clouds._P
+    if r.dim() == 1 and n_clouds == 1 and r.shape[0] == p_max:
+        r = r[None]
+    if r.dim() == 1 and r.shape[0] == n_packed:
+        return r.contiguous()
+    if tuple(r.shape) != (n_clouds, p_max):
+        raise ValueError("radius must be of shape (N, P): got %s" % repr(tuple(radius.shape)))
+    return r.reshape(-1)[clouds.padded_to_packed_idx()].contiguous()
 
 
-class _RasterizePoints(torch.autograd.Function):
+def rasterize_points(pointclouds, image_size: Union[int, Sequence[int]] = 256, radius: Radius = 0.01,
+                     points_per_pixel: int = 8, bin_size: Optional[int] = None,
+                     max_points_per_bin: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    size = parse_image_size(image_size)
+    longest = max(size)
+    if bin_size is None:
+        bin_size = default_bin_size(longest)
+    if bin_size != 0:
+        bins = 1 + (longest - 1) // bin_size
+        if bins >= MAX_BINS_PER_SIDE:
+            raise ValueError("bin_size too small, number of points per bin must be less than %d; got %d" % (MAX_BINS_PER_SIDE, bins))
+    if max_points_per_bin is None:
+        max_points_per_bin = max(10000, pointclouds._P // 5)  # rasterize_points.py:125
+    return _PointFragments.apply(pointclouds.points_packed(), radius_per_packed_point(radius, pointclouds),
+                                 pointclouds.cloud_to_packed_first_idx(), pointclouds.num_points_per_cloud(),
+                                 (size, int(points_per_pixel), int(bin_size), int(max_points_per_bin)))
+
+
+class _PointFragments(torch.autograd.Function):
+    """(points, radius, first, count, static) -> (idx, zbuf, dists2); gradient to the points only (the radius has none in
+    the reference either, rasterize_points.py:236-242)."""
+
     @staticmethod
-    def forward(ctx, points, cloud_to_packed_first_idx, num_points_per_cloud, image_size=(256, 256), radius=0.01,
-                points_per_pixel=8, bin_size=0, max_points_per_bin=0):
-        idx, zbuf, dists = _C.rasterize_points(points, cloud_to_packed_first_idx, num_points_per_cloud, image_size,
-                                               radius, points_per_pixel, bin_size, max_points_per_bin)
+    def forward(ctx, points, radius, first, count, static):
+        size, k, bin_size, cap = static
+        idx, zbuf, dists2 = _C.rasterize_points(points, first, count, size, radius, k, bin_size, cap)
         ctx.save_for_backward(points, idx)
         ctx.mark_non_differentiable(idx)
-        return idx, zbuf, dists
+        return idx, zbuf, dists2
 
     @staticmethod
-    def backward(ctx, grad_idx, grad_zbuf, grad_dists):
+    def backward(ctx, _g_idx, g_zbuf, g_dists2):
         points, idx = ctx.saved_tensors
-        grad_points = _C.rasterize_points_backward(points, idx, grad_zbuf, grad_dists)
-        return (grad_points,) + (None,) * 7
+        return _C.rasterize_points_backward(points, idx, g_zbuf, g_dists2), None, None, None, None

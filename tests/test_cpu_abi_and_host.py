@@ -269,3 +269,33 @@ def test_shared_reciprocal_division_is_exact_and_fast_path_equals_plain_path():
             fast = U.hg_rasterize_meshes(fv, first, count, nbr, size, blur, 8, persp, clip, cull, use_mem=2)
             for a, b in zip(plain, fast):
                 assert torch.equal(a, b), (case, size)
+
+
+def test_point_rasterizer_host_logic():
+    """pytorch3d_amd/rasterize_points.py: radius forms, the reference's bin-size heuristic (rasterize_points.py:104-113, no
+    "<= 64 -> 8" special case as meshes have) and its error; the kernels themselves refuse CPU tensors."""
+    import importlib
+
+    import pytorch3d_amd as p3d
+
+    rp = importlib.import_module("pytorch3d_amd.rasterize_points")  # the package re-exports the function under this name
+
+    assert [rp.default_bin_size(s) for s in (16, 64, 256, 257, 512, 1024)] == [16, 16, 16, 32, 32, 64]
+    pts = [torch.rand(5, 3), torch.rand(3, 3)]
+    pc = p3d.PackedPointclouds(pts)
+    r = rp.radius_per_packed_point(0.25, pc)
+    assert r.shape == (8,) and r.dtype == torch.float32 and bool((r == 0.25).all())
+    packed = torch.arange(8, dtype=torch.float32)
+    assert torch.equal(rp.radius_per_packed_point(packed, pc), packed)
+    padded = torch.arange(10, dtype=torch.float32).reshape(2, 5)
+    assert torch.equal(rp.radius_per_packed_point(padded, pc), torch.tensor([0., 1., 2., 3., 4., 5., 6., 7.]))
+    one = p3d.PackedPointclouds([torch.rand(4, 3)])
+    assert torch.equal(rp.radius_per_packed_point([1.0, 2.0, 3.0, 4.0], one), torch.tensor([1., 2., 3., 4.]))
+    with pytest.raises(ValueError, match="shape"):
+        rp.radius_per_packed_point(torch.rand(2, 4), pc)
+    with pytest.raises(ValueError, match="float, list, tuple or tensor"):
+        rp.radius_per_packed_point("0.1", pc)
+    with pytest.raises(ValueError, match="bin_size too small"):
+        p3d.rasterize_points(pc, image_size=512, bin_size=8)
+    with pytest.raises(RuntimeError, match="GPU path only"):
+        p3d.rasterize_points(pc, image_size=32, radius=0.1)
