@@ -111,6 +111,26 @@ int p3d_gather_face_verts(const float* verts, const int64_t* faces, int64_t V, i
 int p3d_scatter_face_grads(const float* grad_face_verts, const int64_t* faces, int64_t V, int64_t F, float* grad_verts,
                            p3d_stream_t stream);
 
+/* ---- world -> NDC vertex transform fused into the gather ---------------- */
+
+/* replaces MeshRasterizer.transform (pytorch3d/renderer/mesh/rasterizer.py:171-216: two batched 4x4 transform_points
+ * with homogeneous divides on padded vertices, z taken from view space) + the gather `verts_packed[faces_packed]`
+ * (renderer/mesh/rasterize_meshes.py:144-148) by ONE launch: verts_world (V,3) f32, faces (F,3) i64 packed,
+ * mesh_to_face_first_idx (N) i64, matrices (num_matrices,2,4,4) f32 row-major in the reference's row-vector convention
+ * ([.][0] world->view, [.][1] view->NDC), num_matrices = N or 1 -> face_verts (F,3,3) in NDC (x, y) + view depth. */
+int p3d_transform_gather_face_verts(const float* verts_world, const int64_t* faces, const int64_t* mesh_to_face_first_idx,
+                                    const float* matrices, int64_t V, int64_t F, int N, int num_matrices, float* face_verts,
+                                    p3d_stream_t stream);
+/* the same transform per packed vertex (for callers that need the NDC vertices themselves) ... */
+int p3d_transform_verts_forward(const float* verts_world, const int64_t* mesh_to_vert_first_idx, const float* matrices,
+                                int64_t V, int N, int num_matrices, float* verts_ndc, p3d_stream_t stream);
+/* ... and its backward: grad_verts_world (V,3) = J^T grad_verts_ndc (V,3), i.e. what torch autograd computes through the
+ * two transform_points calls; applied to the output of p3d_rasterize_meshes_backward_verts it gives the gradient of the
+ * rasterization wrt world-space vertices. */
+int p3d_transform_verts_backward(const float* verts_world, const int64_t* mesh_to_vert_first_idx, const float* matrices,
+                                 const float* grad_verts_ndc, int64_t V, int N, int num_matrices, float* grad_verts_world,
+                                 p3d_stream_t stream);
+
 /* ---- point clouds -------------------------------------------------------------------- */
 
 size_t p3d_rasterize_points_workspace_bytes(int64_t P, int N, int H, int W, int bin_size, int max_points_per_bin);

@@ -14,10 +14,10 @@ from . import _C  # noqa: F401
 from .blending import BlendParams, sigmoid_alpha_blend, softmax_rgb_blend  # noqa: F401
 from .compositing import alpha_composite, norm_weighted_sum, weighted_sum  # noqa: F401
 from .interp_face_attrs import interpolate_face_attributes  # noqa: F401
-from .rasterize_meshes import rasterize_meshes  # noqa: F401
+from .rasterize_meshes import rasterize_meshes, rasterize_meshes_world  # noqa: F401
 from .rasterize_points import rasterize_points  # noqa: F401
 from .shading import flat_shading, gouraud_shading, phong_shading, phong_shading_vertex_colors  # noqa: F401
 from .structures import PackedMeshes, PackedPointclouds  # noqa: F401
 from .textures import sample_textures_uv  # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"

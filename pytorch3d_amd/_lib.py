@@ -38,6 +38,9 @@ _SIGNATURES = {
                                                     c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
     "p3d_gather_face_verts": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     "p3d_scatter_face_grads": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
+    "p3d_transform_gather_face_verts": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_ptr]),
+    "p3d_transform_verts_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr]),
+    "p3d_transform_verts_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr]),
     "p3d_rasterize_points_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int, c_int, c_int]),
     "p3d_rasterize_points": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr,
                                      c_ptr, c_ptr, c_ptr, c_size, c_ptr]),

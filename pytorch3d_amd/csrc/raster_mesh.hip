@@ -437,8 +437,9 @@ __device__ __forceinline__ void wave_chunk(const MeshArgs& a, int K, Queue& q, i
 
 // EXACT: K == KT is known at compile time (K = 1, 2, 4, 8): the queue's live capacity folds to a constant and the
 // generic epilogue (fill + patch, for K that has no vector-row path) is not even compiled into the hot kernels.
-template <typename Queue, int KT, bool IN_REGS, bool BINNED, bool EXACT>
-__global__ __launch_bounds__(kStage, P3D_FINE_WAVES_PER_SIMD) void mesh_raster_kernel(MeshArgs a) {
+// WAVES: minimum waves per SIMD the register allocation leaves room for (512 / WAVES registers per lane).
+template <typename Queue, int KT, bool IN_REGS, bool BINNED, bool EXACT, int WAVES = P3D_FINE_WAVES_PER_SIMD>
+__global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) {
   __shared__ float4 s_box[kStage];                  // xlo, xhi, ylo, yhi (blur-expanded)
   __shared__ float4 s_rec[kStage][kRecWords];       // see kRecWords
   __shared__ __align__(16) float s_zc[kStage];      // depth-cull key: every sample of the face has z >= s_zc (or -inf)
@@ -599,6 +600,7 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
   LaunchScope ls(name, stream);
   const int K = a.K;
 #define P3D_LAUNCH_FINE(KT_, REGS_, EXACT_, Q_) mesh_raster_kernel<Q_, KT_, REGS_, BINNED, EXACT_><<<grid, kStage, 0, stream>>>(a)
+#define P3D_LAUNCH_FINE_W(KT_, WAVES_, Q_) mesh_raster_kernel<Q_, KT_, true, BINNED, false, WAVES_><<<grid, kStage, 0, stream>>>(a)
   if (K == 1)
     P3D_LAUNCH_FINE(1, true, true, TopKReg<1 P3D_COMMA kMeshPayload>);
   else if (K == 2)
@@ -611,9 +613,14 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
     P3D_LAUNCH_FINE(8, true, false, TopKReg<8 P3D_COMMA kMeshPayload>);
   else if (K == 8)
     P3D_LAUNCH_FINE(8, true, true, TopKReg<8 P3D_COMMA kMeshPayload>);
+  // 9..12: the queue (6 registers per entry: 72) still fits the register file at 3 waves per SIMD; from 16 entries on
+  // the allocator spills hundreds of registers, and the queue in private memory is the better choice
+  else if (K <= 12)
+    P3D_LAUNCH_FINE_W(12, 3, TopKReg<12 P3D_COMMA kMeshPayload>);
   else
     P3D_LAUNCH_FINE(P3D_MAX_K, false, false, TopKMem<P3D_MAX_K P3D_COMMA kMeshPayload>);
 #undef P3D_LAUNCH_FINE
+#undef P3D_LAUNCH_FINE_W
   return launch_status();
 }
 

@@ -246,3 +246,133 @@ class _RasterizeMeshVerts(torch.autograd.Function):
                 faces.shape[0], ctx.V, N, H, W, K, ctx.flags[0], ctx.flags[1], _C._ptr(grad_verts), _C._stream(dev))
             _lib.check(rc, "rasterize_meshes_backward")
         return (grad_verts,) + (None,) * 12
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# World-space entry: the camera transform fused into the face gather
+# ---------------------------------------------------------------------------------------------------------------------
+def _pack_matrices(world_to_view, view_to_ndc, n_meshes, device):
+    """(N or 1, 4, 4) x 2 -> (num, 2, 4, 4) float32 contiguous, num = N or 1.  Row-vector convention, as
+    Transform3d.get_matrix() returns them (pytorch3d/transforms/transform3d.py)."""
+    mats = []
+    for m in (world_to_view, view_to_ndc):
+        m = torch.as_tensor(m, dtype=torch.float32, device=device)
+        if m.dim() == 2:
+            m = m[None]
+        if m.dim() != 3 or m.shape[1:] != (4, 4) or m.shape[0] not in (1, n_meshes):
+            raise ValueError("camera matrices must have shape (4, 4), (1, 4, 4) or (N, 4, 4); got %s" % repr(tuple(m.shape)))
+        mats.append(m)
+    num = max(mats[0].shape[0], mats[1].shape[0])
+    return torch.stack([m.expand(num, 4, 4) for m in mats], 1).contiguous()
+
+
+def transform_points_reference(verts_packed, mesh_idx, world_to_view, view_to_ndc):
+    """MeshRasterizer.transform (renderer/mesh/rasterizer.py:171-216) with torch ops on packed vertices: the differentiable
+    path (cameras that require grad) and the oracle the HIP kernels are tested against."""
+    one = torch.ones_like(verts_packed[:, :1])
+    a = world_to_view[mesh_idx] if world_to_view.shape[0] > 1 else world_to_view.expand(verts_packed.shape[0], 4, 4)
+    b = view_to_ndc[mesh_idx] if view_to_ndc.shape[0] > 1 else view_to_ndc.expand(verts_packed.shape[0], 4, 4)
+    vh = torch.bmm(torch.cat([verts_packed, one], 1)[:, None], a)[:, 0]
+    view = vh[:, :3] / vh[:, 3:]
+    nh = torch.bmm(torch.cat([view, one], 1)[:, None], b)[:, 0]
+    ndc = nh[:, :3] / nh[:, 3:]
+    return torch.cat([ndc[:, :2], view[:, 2:3]], 1)
+
+
+def rasterize_meshes_world(meshes_world, world_to_view, view_to_ndc, image_size=256, blur_radius: float = 0.0,
+                           faces_per_pixel: int = 8, bin_size: Optional[int] = None, max_faces_per_bin: Optional[int] = None,
+                           perspective_correct: bool = False, clip_barycentric_coords: bool = False,
+                           cull_backfaces: bool = False):
+    """`MeshRasterizer.transform` + `rasterize_meshes` on world-space vertices (no z-clipping / frustum culling).
+
+    world_to_view, view_to_ndc: (N, 4, 4) or (1, 4, 4) matrices, `cameras.get_world_to_view_transform().get_matrix()` and
+    `cameras.get_projection_transform().compose(cameras.get_ndc_camera_transform()).get_matrix()`.  The transform runs
+    inside the face gather (one launch); the backward delivers the gradient wrt the WORLD vertices.  Matrices that
+    require grad take the torch formulation of the transform (gradients to the cameras through autograd), followed by
+    the fused gather + rasterization."""
+    verts = meshes_world.verts_packed()
+    faces = meshes_world.faces_packed()
+    n = len(meshes_world)
+    w2v = torch.as_tensor(world_to_view)
+    v2n = torch.as_tensor(view_to_ndc)
+    cams_need_grad = (torch.is_tensor(world_to_view) and world_to_view.requires_grad) or \
+                     (torch.is_tensor(view_to_ndc) and view_to_ndc.requires_grad)
+    if cams_need_grad or not _gatherable(verts, faces):
+        a = w2v.to(verts.device, torch.float32)
+        b = v2n.to(verts.device, torch.float32)
+        a = a[None] if a.dim() == 2 else a
+        b = b[None] if b.dim() == 2 else b
+        ndc = transform_points_reference(verts, meshes_world.verts_packed_to_mesh_idx(), a, b)
+        return rasterize_meshes(meshes_world.update_verts_packed(ndc), image_size, blur_radius, faces_per_pixel, bin_size,
+                                max_faces_per_bin, perspective_correct, clip_barycentric_coords, cull_backfaces)
+    mats = _pack_matrices(w2v, v2n, n, verts.device)
+    im_size = parse_image_size(image_size)
+    max_image_size = max(*im_size)
+    if bin_size is None:
+        bin_size = default_bin_size(max_image_size)
+    if bin_size != 0:
+        faces_per_bin = 1 + (max_image_size - 1) // bin_size
+        if faces_per_bin >= kMaxFacesPerBin:
+            raise ValueError("bin_size too small, number of faces per bin must be less than %d; got %d" %
+                             (kMaxFacesPerBin, faces_per_bin))
+    if max_faces_per_bin is None:
+        max_faces_per_bin = int(max(10000, meshes_world._F / 5))
+    nbr = torch.full((faces.shape[0],), -1, dtype=torch.int64, device=verts.device)
+    return _RasterizeMeshWorld.apply(verts, faces, meshes_world.mesh_to_faces_packed_first_idx(),
+                                     meshes_world.num_faces_per_mesh(), meshes_world.mesh_to_verts_packed_first_idx(), mats, nbr,
+                                     (im_size, blur_radius, faces_per_pixel, bin_size, max_faces_per_bin,
+                                      bool(perspective_correct), bool(clip_barycentric_coords), bool(cull_backfaces)))
+
+
+class _RasterizeMeshWorld(torch.autograd.Function):
+    """world vertices -> fragments as ONE node: p3d_transform_gather_face_verts + the rasterizer; backward =
+    p3d_rasterize_meshes_backward_verts (per-vertex NDC gradient) + p3d_transform_verts_backward."""
+
+    @staticmethod
+    def forward(ctx, verts, faces, face_first, num_faces, vert_first, mats, nbr, static):
+        from . import _lib
+
+        im_size, blur, K, bin_size, cap, persp, clip, cull = static
+        lib = _lib.load()
+        verts_c, faces_c = verts.contiguous(), faces.contiguous()
+        V, F, N = verts_c.shape[0], faces_c.shape[0], face_first.shape[0]
+        dev = verts.device
+        with torch.cuda.device(dev):
+            face_verts = torch.empty((F, 3, 3), dtype=torch.float32, device=dev)
+            if F:
+                rc = lib.p3d_transform_gather_face_verts(_C._ptr(verts_c), _C._ptr(faces_c), _C._ptr(face_first), _C._ptr(mats), V, F,
+                                                         N, mats.shape[0], _C._ptr(face_verts), _C._stream(dev))
+                _lib.check(rc, "transform_gather_face_verts")
+        out = _C.rasterize_meshes(face_verts, face_first, num_faces, nbr, im_size, blur, K, bin_size, cap, persp, clip, cull)
+        ctx.save_for_backward(verts_c, faces_c, vert_first, mats, face_verts, out[0])
+        ctx.mark_non_differentiable(out[0])
+        ctx.set_materialize_grads(False)
+        ctx.flags = (int(persp), int(clip))
+        return out
+
+    @staticmethod
+    def backward(ctx, _g_idx, grad_zbuf, grad_bary, grad_dists):
+        from . import _lib
+
+        verts, faces, vert_first, mats, face_verts, pix_to_face = ctx.saved_tensors
+        if grad_zbuf is None and grad_bary is None and grad_dists is None:
+            return (None,) * 8
+        dev = pix_to_face.device
+        N, H, W, K = pix_to_face.shape
+        zeros = lambda *tail: torch.zeros(tuple(pix_to_face.shape) + tail, dtype=torch.float32, device=dev)
+        gz = grad_zbuf.contiguous() if grad_zbuf is not None else zeros()
+        gd = grad_dists.contiguous() if grad_dists is not None else zeros()
+        gb = grad_bary.contiguous() if grad_bary is not None else zeros(3)
+        lib = _lib.load()
+        V = verts.shape[0]
+        with torch.cuda.device(dev):
+            g_ndc = torch.empty((V, 3), dtype=torch.float32, device=dev)
+            rc = lib.p3d_rasterize_meshes_backward_verts(
+                _C._ptr(face_verts), _C._ptr(faces), _C._ptr(pix_to_face), _C._ptr(gz), _C._ptr(gb), _C._ptr(gd), faces.shape[0], V,
+                N, H, W, K, ctx.flags[0], ctx.flags[1], _C._ptr(g_ndc), _C._stream(dev))
+            _lib.check(rc, "rasterize_meshes_backward")
+            g_world = torch.empty((V, 3), dtype=torch.float32, device=dev)
+            rc = lib.p3d_transform_verts_backward(_C._ptr(verts), _C._ptr(vert_first), _C._ptr(mats), _C._ptr(g_ndc), V,
+                                                  vert_first.shape[0], mats.shape[0], _C._ptr(g_world), _C._stream(dev))
+            _lib.check(rc, "transform_verts_backward")
+        return (g_world,) + (None,) * 7
