@@ -617,6 +617,8 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
   // the allocator spills hundreds of registers, and the queue in private memory is the better choice
   else if (K <= 12)
     P3D_LAUNCH_FINE_W(12, 3, TopKReg<12 P3D_COMMA kMeshPayload>);
+  else if (K <= 16)
+    P3D_LAUNCH_FINE_W(16, 2, TopKReg<16 P3D_COMMA kMeshPayload>);
   else
     P3D_LAUNCH_FINE(P3D_MAX_K, false, false, TopKMem<P3D_MAX_K P3D_COMMA kMeshPayload>);
 #undef P3D_LAUNCH_FINE

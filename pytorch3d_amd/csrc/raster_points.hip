@@ -224,8 +224,10 @@ int launch_point_raster(const PointArgs& a, hipStream_t stream) {
   // Longer queues stay in registers too, without the payload.  A dense cloud keeps the queue full (~80 splats cover a
   // pixel at the BASELINE density), so a queue in private memory shifts O(K) entries through scratch for every
   // admitted splat (K = 50: 7.8 ms, K = 100: 14.7 ms); here an insertion is ~5 VALU per slot on registers.
-  else if (K <= 48)
-    point_raster_kernel<TopKReg<48, 0>, 48, true, BINNED, false, 2><<<grid, kStage, 0, stream>>>(a);
+  else if (K <= 40)
+    point_raster_kernel<TopKReg<40, 0>, 40, true, BINNED, false, 2><<<grid, kStage, 0, stream>>>(a);
+  else if (K <= 50)  // an insertion walks the whole queue: capacities follow the common settings (50, 100) exactly
+    point_raster_kernel<TopKReg<50, 0>, 50, true, BINNED, false, 2><<<grid, kStage, 0, stream>>>(a);
   else if (K <= 64)
     point_raster_kernel<TopKReg<64, 0>, 64, true, BINNED, false, 2><<<grid, kStage, 0, stream>>>(a);
   else if (K <= 100)  // one wave per SIMD: 200 queue registers, the upper ones in AGPRs
