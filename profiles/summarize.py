@@ -32,7 +32,7 @@ def short(name):
 def main():
     src, dst = sys.argv[1], sys.argv[2]
     lines = ["# rocprofv3 summary (" + os.path.basename(dst) + ")", "",
-             "Command: `python bench.py --steps 5 --warmup 2 --no-cpu-baseline` under `rocprofv3` "
+             "Command: `python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs` under `rocprofv3` "
              "(profiles/run_rocprof.sh), MI355X / gfx950.", ""]
     f = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
     if f:
