@@ -267,7 +267,7 @@ constexpr int kRecWords = 5;
 // clipped-neighbour rule (rasterize_meshes.cu:186-215).  Two instantiations, chosen per tile region (see the kernel):
 // with the rule in the common loop body the compiler copies the whole queue (48 moves) after every hit to feed the
 // rule's control flow.
-template <bool GENERAL, typename Queue>
+template <bool GENERAL, typename Queue, bool PC = false>
 __device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue& q, unsigned long long cand, int oj, f2 p,
                                                 bool pix_ok, bool persp, bool clip, const float4* s_box,
                                                 const float4 (*s_rec)[kRecWords], const float* s_zc) {
@@ -295,8 +295,13 @@ __device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue&
         fr.rd_l01 = d0.y;
         fr.rd_l02 = d1.x;
         fr.rd_l12 = d1.y;
-        fr.wide = __float_as_int(r2.w) != 0;
-        hit = face_hit_rec(fr, p, a.blur, persp, clip, &h);
+        if constexpr (PC && !GENERAL) {
+          fr.wide = false;  // wide faces make their chunk general (stage_chunk)
+          hit = face_hit_rec(fr, p, a.blur, true, true, &h);
+        } else {
+          fr.wide = __float_as_int(r2.w) != 0;
+          hit = face_hit_rec(fr, p, a.blur, persp, clip, &h);
+        }
       }
       if (hit) {
         const float pl[kMeshPayload] = {h.dist, h.bary.x, h.bary.y, h.bary.z};
@@ -342,7 +347,7 @@ struct TileRect {
 // Stage up to 256 faces of the tile's list into LDS: per-face setup (done once per workgroup -- the reference redoes it
 // per pixel), tile cull, ordered compaction (ballot + mbcnt), FaceRec.  Returns the number of staged faces;
 // *general = some staged face has a clipped neighbour (workgroup-uniform).  Ends with a barrier.
-template <bool BINNED>
+template <bool BINNED, bool PC = false>
 __device__ __forceinline__ int stage_chunk(const MeshArgs& a, const StageLds& l, const TileRect& tile, int64_t src_base,
                                            int count, int base, int tid, bool cull, bool clip, bool prune, bool* general) {
   const int lane = tid & 63, w = tid >> 6;
@@ -379,7 +384,7 @@ __device__ __forceinline__ int stage_chunk(const MeshArgs& a, const StageLds& l,
   if (keep) {
     FaceRec fr;
     face_rec_make(v0, v1, v2, &fr);
-    gen = nb != -1 || (P3D_DBG(a) & 32768);
+    gen = nb != -1 || (PC && fr.wide) || (P3D_DBG(a) & 32768);
     l.box[pos] = make_float4(fs.xlo, fs.xhi, fs.ylo, fs.yhi);
     l.rec[pos][0] = make_float4(v0.x, v0.y, v1.x, v1.y);
     l.rec[pos][1] = make_float4(v2.x, v2.y, v0.z, v1.z);
@@ -410,7 +415,7 @@ struct SubTile {
 };
 
 // One wave's pass over a staged chunk: sub-tile cull 64 faces at a time (one lane per face), then the per-pixel loop.
-template <bool GENERAL, typename Queue>
+template <bool GENERAL, typename Queue, bool PC = false>
 __device__ __forceinline__ void wave_chunk(const MeshArgs& a, int K, Queue& q, int staged, bool sorted, const SubTile& st, f2 p,
                                            bool pix_ok, int lane, bool persp, bool clip, bool prune, const float4* s_box,
                                            const float4 (*s_rec)[kRecWords], const float* s_zc, const int* s_order,
@@ -431,14 +436,18 @@ __device__ __forceinline__ void wave_chunk(const MeshArgs& a, int K, Queue& q, i
       }
     }
     const unsigned long long cand = __ballot(touch);
-    eval_candidates<GENERAL, Queue>(a, K, q, cand, oj, p, pix_ok, persp, clip, s_box, s_rec, s_zc);
+    eval_candidates<GENERAL, Queue, PC>(a, K, q, cand, oj, p, pix_ok, persp, clip, s_box, s_rec, s_zc);
   }
 }
 
 // EXACT: K == KT is known at compile time (K = 1, 2, 4, 8): the queue's live capacity folds to a constant and the
 // generic epilogue (fill + patch, for K that has no vector-row path) is not even compiled into the hot kernels.
 // WAVES: minimum waves per SIMD the register allocation leaves room for (512 / WAVES registers per lane).
-template <typename Queue, int KT, bool IN_REGS, bool BINNED, bool EXACT, int WAVES = P3D_FINE_WAVES_PER_SIMD>
+// PC: perspective_correct && clip_barycentric_coords are known to be set (what MeshRasterizer uses for perspective
+// cameras with blur): the per-(pixel, face) test of the common loop nest becomes one basic block -- the flag branches
+// between its stages kept the compiler from overlapping the distance arithmetic with the latency of the double-precision
+// reciprocal chains -- and faces with `wide` reciprocals are sent to the general nest instead of being tested per candidate.
+template <typename Queue, int KT, bool IN_REGS, bool BINNED, bool EXACT, int WAVES = P3D_FINE_WAVES_PER_SIMD, bool PC = false>
 __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) {
   __shared__ float4 s_box[kStage];                  // xlo, xhi, ylo, yhi (blur-expanded)
   __shared__ float4 s_rec[kStage][kRecWords];       // see kRecWords
@@ -515,7 +524,7 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
   Queue q;
   q.init();
   const int K = EXACT ? KT : a.K;
-  const bool persp = a.persp != 0, clip = a.clip != 0, cull = a.cull != 0;
+  const bool persp = PC || a.persp != 0, clip = PC || a.clip != 0, cull = a.cull != 0;
   const bool prune = !(P3D_DBG(a) & 256);
   StageLds lds;
   lds.box = s_box;
@@ -547,7 +556,7 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
   bool general = false;
   int staged = 0;
   for (; base < count; base += kStage) {
-    staged = stage_chunk<BINNED>(a, lds, tile, src_base, count, base, tid, cull, clip, prune, &general);
+    staged = stage_chunk<BINNED, PC>(a, lds, tile, src_base, count, base, tid, cull, clip, prune, &general);
     if (general) break;  // uniform
     if (!(P3D_DBG(a) & 32)) {
       chunk_bucket_order(s_zc, staged, s_order, s_qlow, s_ord, tid);
@@ -556,7 +565,7 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
       __syncthreads();
     }
     if (run_waves)
-      wave_chunk<false, Queue>(a, K, q, staged, !(P3D_DBG(a) & 32), st, p, pix_ok, lane, persp, clip, prune, s_box, s_rec, s_zc, s_order,
+      wave_chunk<false, Queue, PC>(a, K, q, staged, !(P3D_DBG(a) & 32), st, p, pix_ok, lane, persp, clip, prune, s_box, s_rec, s_zc, s_order,
                                s_qlow);
     __syncthreads();
   }
@@ -571,7 +580,7 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
       base += kStage;
       if (base >= count) break;
       bool dummy = false;
-      staged = stage_chunk<BINNED>(a, lds, tile, src_base, count, base, tid, cull, clip, prune, &dummy);
+      staged = stage_chunk<BINNED, PC>(a, lds, tile, src_base, count, base, tid, cull, clip, prune, &dummy);
     }
   }
 
@@ -599,7 +608,13 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
   const char* name = BINNED ? "mesh_fine" : "mesh_naive";
   LaunchScope ls(name, stream);
   const int K = a.K;
-#define P3D_LAUNCH_FINE(KT_, REGS_, EXACT_, Q_) mesh_raster_kernel<Q_, KT_, REGS_, BINNED, EXACT_><<<grid, kStage, 0, stream>>>(a)
+#define P3D_LAUNCH_FINE(KT_, REGS_, EXACT_, Q_)                                                                       \
+  do {                                                                                                                \
+    if (REGS_ && EXACT_ && a.persp && a.clip)                                                                         \
+      mesh_raster_kernel<Q_, KT_, REGS_, BINNED, EXACT_, P3D_FINE_WAVES_PER_SIMD, true><<<grid, kStage, 0, stream>>>(a); \
+    else                                                                                                              \
+      mesh_raster_kernel<Q_, KT_, REGS_, BINNED, EXACT_><<<grid, kStage, 0, stream>>>(a);                               \
+  } while (0)
 #define P3D_LAUNCH_FINE_W(KT_, WAVES_, Q_) mesh_raster_kernel<Q_, KT_, true, BINNED, false, WAVES_><<<grid, kStage, 0, stream>>>(a)
   if (K == 1)
     P3D_LAUNCH_FINE(1, true, true, TopKReg<1 P3D_COMMA kMeshPayload>);
