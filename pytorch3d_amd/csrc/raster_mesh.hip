@@ -606,14 +606,18 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
 #endif
   const unsigned grid = tile_grid(a.tm);
   const char* name = BINNED ? "mesh_fine" : "mesh_naive";
+  size_t dyn_lds = 0;  // extra (unused) LDS per workgroup: an occupancy limiter
+#ifdef P3D_ABLATION
+  if (const char* e = getenv("P3D_DEBUG_FWD_LDS")) dyn_lds = (size_t)atoi(e);
+#endif
   LaunchScope ls(name, stream);
   const int K = a.K;
 #define P3D_LAUNCH_FINE(KT_, REGS_, EXACT_, Q_)                                                                       \
   do {                                                                                                                \
     if (REGS_ && EXACT_ && a.persp && a.clip)                                                                         \
-      mesh_raster_kernel<Q_, KT_, REGS_, BINNED, EXACT_, P3D_FINE_WAVES_PER_SIMD, true><<<grid, kStage, 0, stream>>>(a); \
+      mesh_raster_kernel<Q_, KT_, REGS_, BINNED, EXACT_, P3D_FINE_WAVES_PER_SIMD, true><<<grid, kStage, dyn_lds, stream>>>(a); \
     else                                                                                                              \
-      mesh_raster_kernel<Q_, KT_, REGS_, BINNED, EXACT_><<<grid, kStage, 0, stream>>>(a);                               \
+      mesh_raster_kernel<Q_, KT_, REGS_, BINNED, EXACT_><<<grid, kStage, dyn_lds, stream>>>(a);                         \
   } while (0)
 #define P3D_LAUNCH_FINE_W(KT_, WAVES_, Q_) mesh_raster_kernel<Q_, KT_, true, BINNED, false, WAVES_><<<grid, kStage, 0, stream>>>(a)
   if (K == 1)
