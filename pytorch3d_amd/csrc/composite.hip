@@ -316,11 +316,13 @@ template <int MODE>
 int launch_bwd(const CompArgs& a, unsigned grid, hipStream_t s) {
   const int tiles_y = (int)ceil_div(a.H, 8), tiles_x = (int)ceil_div(a.W, 8);
   const int64_t tile_blocks = ceil_div((int64_t)a.N * tiles_y * tiles_x, 4);
-  if (a.K <= 16 && tile_blocks > 0x7fffffff) return P3D_ERR_INVALID_ARG;
+  if (a.K <= 32 && tile_blocks > 0x7fffffff) return P3D_ERR_INVALID_ARG;
   if (a.K <= 8)
     composite_bwd_tile_kernel<MODE, 8><<<(unsigned)tile_blocks, 256, 0, s>>>(a, tiles_y, tiles_x);
   else if (a.K <= 16)
     composite_bwd_tile_kernel<MODE, 16><<<(unsigned)tile_blocks, 256, 0, s>>>(a, tiles_y, tiles_x);
+  else if (a.K <= 32)  // 96 registers of (id, alpha, grad_alpha) rows: still the table path, not per-sample atomics
+    composite_bwd_tile_kernel<MODE, 32><<<(unsigned)tile_blocks, 256, 0, s>>>(a, tiles_y, tiles_x);
   else
     composite_bwd_generic_kernel<MODE><<<grid, 256, 0, s>>>(a);
   return launch_status();

@@ -57,7 +57,7 @@ def test_naive_and_binned_vs_oracle(size, blur, persp, clip, cull):
         _assert_fwd_equal(binned, ref, tag=f"bin_size={bin_size}")
 
 
-@pytest.mark.parametrize("K", [1, 2, 3, 5, 8, 9, 40, 150])
+@pytest.mark.parametrize("K", [1, 2, 3, 5, 8, 9, 12, 14, 16, 40, 150])
 def test_all_queue_capacities(K):
     gen = torch.Generator().manual_seed(K)
     F = 300

@@ -19,7 +19,7 @@ def _cloud(P, gen, zlo=-0.2, zhi=2.0):
 
 
 @pytest.mark.parametrize("size", [(32, 32), (20, 48), (45, 31)])
-@pytest.mark.parametrize("K", [1, 3, 8, 10, 16, 20, 32, 40])
+@pytest.mark.parametrize("K", [1, 3, 8, 10, 16, 20, 32, 40, 50, 64, 100, 120])
 def test_points_naive_and_binned_vs_oracle(size, K):
     from pytorch3d_amd import _C
 
@@ -126,7 +126,7 @@ def test_points_backward_and_autograd(size):
 
 
 @pytest.mark.parametrize("mode", ["alphacomposite", "weightedsumnorm", "weightedsum"])
-@pytest.mark.parametrize("K", [4, 10, 24])
+@pytest.mark.parametrize("K", [4, 10, 24, 40])
 @pytest.mark.parametrize("permuted", [False, True])
 def test_compositors(mode, K, permuted):
     from pytorch3d_amd import _C
