@@ -48,6 +48,7 @@ struct MeshArgs {
   TileMap tm;
   float blur, sqrt_blur;
   int persp, clip, cull;
+  unsigned long long* timeline;  // -DP3D_FWD_TIMELINE builds only: per workgroup (start, end) of s_memrealtime (100 MHz) + face count
   int debug;  // P3D_DEBUG_FWD ablation bits (profiles/ablate.py): 1 no per-pixel evaluation, 2 no queue insertion, 4 no stores, 16 no depth cull, 32 no front-to-back order, 64 background tiles stored per lane instead of cooperatively, 128 no bin permutation, 256 no rectangle-vs-face prune, 512 caller's bin geometry instead of tile-sized bins, 2048 background tiles store nothing, 4096 tiles with faces do nothing, 8192 every tile is background, 16384 staging only (no candidate loop), 32768 every chunk takes the general (neighbour rule) loop
   int64_t* p2f;
   float* zbuf;
@@ -467,6 +468,9 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
   const int ty0 = by * a.tm.bin_size + ty * kTile;
   const int tx0 = bx * a.tm.bin_size + tx * kTile;
   if (ty0 >= y_end || tx0 >= x_end) return;  // tile has no pixel (uniform)
+#ifdef P3D_FWD_TIMELINE
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+#endif
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -510,6 +514,13 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
         write_subtile_fill_patch<Queue, KT, IN_REGS>(a, e, false, n, sy0, sx0, y_end, x_end, lane, pix_ok, yi, xi);
       }
     }
+#ifdef P3D_FWD_TIMELINE
+    if (a.timeline && tid == 0) {
+      a.timeline[3 * (size_t)blockIdx.x] = t_start;
+      a.timeline[3 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+      a.timeline[3 * (size_t)blockIdx.x + 2] = 0;
+    }
+#endif
     return;
   }
 
@@ -591,6 +602,14 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
       if (wave_ok) write_subtile_fill_patch<Queue, KT, IN_REGS>(a, q, true, n, sy0, sx0, y_end, x_end, lane, pix_ok, yi, xi);
     }
   }
+#ifdef P3D_FWD_TIMELINE
+  __syncthreads();
+  if (a.timeline && tid == 0) {
+    a.timeline[3 * (size_t)blockIdx.x] = t_start;
+    a.timeline[3 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    a.timeline[3 * (size_t)blockIdx.x + 2] = (unsigned long long)count;
+  }
+#endif
 }
 
 #define P3D_COMMA ,
@@ -606,6 +625,39 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
 #endif
   const unsigned grid = tile_grid(a.tm);
   const char* name = BINNED ? "mesh_fine" : "mesh_naive";
+#ifdef P3D_FWD_TIMELINE
+  // ablation only: per-workgroup (start, end, faces) written to the file named by P3D_FWD_TIMELINE_OUT (synchronous)
+  struct Timeline {
+    unsigned long long* dev = nullptr;
+    unsigned n = 0;
+    hipStream_t s;
+    ~Timeline() {
+      const char* out = getenv("P3D_FWD_TIMELINE_OUT");
+      if (!dev) return;
+      (void)hipStreamSynchronize(s);
+      if (out) {
+        unsigned long long* h = (unsigned long long*)malloc((size_t)n * 24);
+        (void)hipMemcpy(h, dev, (size_t)n * 24, hipMemcpyDeviceToHost);
+        FILE* f = fopen(out, "wb");
+        if (f) {
+          fwrite(h, 24, n, f);
+          fclose(f);
+        }
+        free(h);
+      }
+      (void)hipFree(dev);
+    }
+  } tl;
+  tl.s = stream;
+  a.timeline = nullptr;
+  if (getenv("P3D_FWD_TIMELINE_OUT") && BINNED) {
+    tl.n = grid;
+    if (hipMalloc(&tl.dev, (size_t)grid * 24) == hipSuccess) {
+      (void)hipMemsetAsync(tl.dev, 0, (size_t)grid * 24, stream);
+      a.timeline = tl.dev;
+    }
+  }
+#endif
   size_t dyn_lds = 0;  // extra (unused) LDS per workgroup: an occupancy limiter
 #ifdef P3D_ABLATION
   if (const char* e = getenv("P3D_DEBUG_FWD_LDS")) dyn_lds = (size_t)atoi(e);
