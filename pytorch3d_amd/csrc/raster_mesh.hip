@@ -33,6 +33,7 @@ namespace {
 constexpr int kTile = 16;       // pixels per tile side (4 waves x 8x8)
 constexpr int kStage = 256;     // faces staged per round = threads per workgroup
 constexpr int kMeshPayload = 4; // dist, bary.x, bary.y, bary.z
+constexpr int kSplitMaxTiles = 1024;  // launches with at most this many 16x16 tiles use the split kernel (see mesh_raster_kernel)
 
 #ifndef P3D_FINE_WAVES_PER_SIMD
 #define P3D_FINE_WAVES_PER_SIMD 4  // caps the fine kernel at 128 VGPRs: 4 waves/SIMD instead of 2
@@ -49,7 +50,7 @@ struct MeshArgs {
   float blur, sqrt_blur;
   int persp, clip, cull;
   unsigned long long* timeline;  // -DP3D_FWD_TIMELINE builds only: per workgroup (start, end) of s_memrealtime (100 MHz) + face count
-  int debug;  // P3D_DEBUG_FWD ablation bits (profiles/ablate.py): 1 no per-pixel evaluation, 2 no queue insertion, 4 no stores, 16 no depth cull, 32 no front-to-back order, 64 background tiles stored per lane instead of cooperatively, 128 no bin permutation, 256 no rectangle-vs-face prune, 512 caller's bin geometry instead of tile-sized bins, 2048 background tiles store nothing, 4096 tiles with faces do nothing, 8192 every tile is background, 16384 staging only (no candidate loop), 32768 every chunk takes the general (neighbour rule) loop
+  int debug;  // P3D_DEBUG_FWD ablation bits (profiles/ablate.py): 1 no per-pixel evaluation, 2 no queue insertion, 4 no stores, 16 no depth cull, 32 no front-to-back order, 64 background tiles stored per lane instead of cooperatively, 128 no bin permutation, 256 no rectangle-vs-face prune, 512 caller's bin geometry instead of tile-sized bins, 2048 background tiles store nothing, 4096 tiles with faces do nothing, 8192 every tile is background, 16384 staging only (no candidate loop), 32768 every chunk takes the general (neighbour rule) loop, 1024 (launcher) never / 131072 always the split kernel
   int64_t* p2f;
   float* zbuf;
   float* bary;
@@ -238,9 +239,9 @@ __device__ __forceinline__ void write_subtile_fill_patch(const MeshArgs& a, cons
 // 3*cols*K floats (bary) and cols*K int64 (pix_to_face) = 7 * cols*K/4 16-byte pieces.
 template <int THREADS, bool NT>
 __device__ __forceinline__ void fill_tile_background(const MeshArgs& a, int n, int ty0, int tx0, int y_end, int x_end,
-                                                     int tid) {
+                                                     int tid, int side = kTile) {
   const int H = a.H, W = a.W, K = a.K;
-  const int rows = min(kTile, y_end - ty0), cols = min(kTile, x_end - tx0);
+  const int rows = min(side, y_end - ty0), cols = min(side, x_end - tx0);
   const int q4 = (cols * K) >> 2;       // 16-byte pieces of one tile row of zbuf
   const int per_row = 7 * q4;           // zbuf q4 | dists q4 | bary 3 q4 | p2f 2 q4
   const int64_t col0 = W - tx0 - cols;  // outputs are stored flipped: x_out = W-1-x
@@ -416,15 +417,20 @@ struct SubTile {
 };
 
 // One wave's pass over a staged chunk: sub-tile cull 64 faces at a time (one lane per face), then the per-pixel loop.
+// DEAL >= 0 (split mode, see the kernel): the four waves of the workgroup share ONE sub-tile and this wave (number DEAL)
+// takes positions 16*(4q + DEAL) .. +15 of the visiting order -- at most one group of 64 per chunk, dealt in blocks of
+// 16 so that every wave sees a front-to-back subsequence of about the same depth range.
 template <bool GENERAL, typename Queue, bool PC = false>
 __device__ __forceinline__ void wave_chunk(const MeshArgs& a, int K, Queue& q, int staged, bool sorted, const SubTile& st, f2 p,
                                            bool pix_ok, int lane, bool persp, bool clip, bool prune, const float4* s_box,
                                            const float4 (*s_rec)[kRecWords], const float* s_zc, const int* s_order,
-                                           const float* s_qlow) {
+                                           const float* s_qlow, int deal = -1) {
   for (int jb = 0; jb < staged; jb += kWave) {
+    const int jfirst = deal >= 0 ? deal * 16 : jb;  // this wave's first position
+    if (jfirst >= staged) break;
     // sorted chunk: once the nearest remaining face is too deep for every pixel of this wave, so is everything behind it
-    if (sorted && __ballot(pix_ok && !(s_qlow[jb] > q.kth_z(K))) == 0) break;
-    const int j = jb + lane;
+    if (sorted && __ballot(pix_ok && !(s_qlow[jfirst] > q.kth_z(K))) == 0) break;
+    const int j = deal >= 0 ? (((lane >> 4) * 4 + deal) * 16 + (lane & 15)) : jb + lane;
     bool touch = false;
     int oj = 0;
     if (j < staged) {
@@ -438,6 +444,35 @@ __device__ __forceinline__ void wave_chunk(const MeshArgs& a, int K, Queue& q, i
     }
     const unsigned long long cand = __ballot(touch);
     eval_candidates<GENERAL, Queue, PC>(a, K, q, cand, oj, p, pix_ok, persp, clip, s_box, s_rec, s_zc);
+    if (deal >= 0) break;  // a chunk holds at most 256 positions: one group per wave
+  }
+}
+
+// Split mode: queue entries of waves 1..3 pass through LDS to wave 0.  Layout [word][entry k][lane] (conflict-free).
+constexpr int kMergeWords = 2 + kMeshPayload;  // z, idx, payload
+
+template <typename Queue, int KT>
+__device__ __forceinline__ void merge_dump(const Queue& q, float* slab, int lane) {
+#pragma unroll
+  for (int k = 0; k < KT; ++k) {
+    slab[(0 * KT + k) * kWave + lane] = q.z[k];
+    slab[(1 * KT + k) * kWave + lane] = __int_as_float(q.idx[k]);
+#pragma unroll
+    for (int pp = 0; pp < kMeshPayload; ++pp) slab[((2 + pp) * KT + k) * kWave + lane] = q.pl[pp][k];
+  }
+}
+
+template <typename Queue, int KT>
+__device__ __forceinline__ void merge_absorb(Queue& q, int K, const float* slab, int lane) {
+#pragma unroll 1
+  for (int k = 0; k < KT; ++k) {
+    const int idx = __float_as_int(slab[(1 * KT + k) * kWave + lane]);
+    if (__ballot(idx != kEmptyIdx) == 0) break;  // entries are sorted: empty ones are last in every lane
+    const float z = slab[(0 * KT + k) * kWave + lane];
+    float pl[kMeshPayload];
+#pragma unroll
+    for (int pp = 0; pp < kMeshPayload; ++pp) pl[pp] = slab[((2 + pp) * KT + k) * kWave + lane];
+    if (idx != kEmptyIdx && q.admits(K, z, idx)) q.insert(K, z, idx, pl);
   }
 }
 
@@ -448,8 +483,16 @@ __device__ __forceinline__ void wave_chunk(const MeshArgs& a, int K, Queue& q, i
 // cameras with blur): the per-(pixel, face) test of the common loop nest becomes one basic block -- the flag branches
 // between its stages kept the compiler from overlapping the distance arithmetic with the latency of the double-precision
 // reciprocal chains -- and faces with `wide` reciprocals are sent to the general nest instead of being tested per candidate.
-template <typename Queue, int KT, bool IN_REGS, bool BINNED, bool EXACT, int WAVES = P3D_FINE_WAVES_PER_SIMD, bool PC = false>
+// SPLIT (few tiles: a single image or a small batch): one workgroup per 8x8 SUB-tile, its four waves share the 64 pixels
+// and each takes a quarter of every staged chunk (wave_chunk's `deal`); the four queues meet in wave 0 through LDS
+// before the pixel is written (the K nearest of a union are among the K nearest of its parts).  A 16x16 tile per
+// workgroup makes every wave walk the tile's whole list for its own sub-tile: with one image on the chip (BASELINE
+// configs[1]: 256 tiles for 256 CUs) the launch lasts as long as the longest such walk (~0.2 ms on the cow), while three
+// quarters of the CUs idle.
+template <typename Queue, int KT, bool IN_REGS, bool BINNED, bool EXACT, int WAVES = P3D_FINE_WAVES_PER_SIMD, bool PC = false,
+          bool SPLIT = false>
 __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) {
+  __shared__ float s_merge[SPLIT ? 3 * kMergeWords * KT * kWave : 1];
   __shared__ float4 s_box[kStage];                  // xlo, xhi, ylo, yhi (blur-expanded)
   __shared__ float4 s_rec[kStage][kRecWords];       // see kRecWords
   __shared__ __align__(16) float s_zc[kStage];      // depth-cull key: every sample of the face has z >= s_zc (or -inf)
@@ -459,7 +502,7 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
   __shared__ int s_wcnt[kStage / kWave];
 
   TileCoord tc;
-  if (!tile_of_block(a.tm, blockIdx.x, &tc)) return;
+  if (!tile_of_block(a.tm, SPLIT ? blockIdx.x >> 2 : blockIdx.x, &tc)) return;
   const int n = tc.n, by = tc.by, bx = tc.bx, ty = tc.ty, tx = tc.tx;
 
   const int H = a.H, W = a.W;
@@ -475,8 +518,10 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = tid >> 6;
-  const int sy0 = ty0 + (w >> 1) * 8;
-  const int sx0 = tx0 + (w & 1) * 8;
+  const int sub = SPLIT ? (int)(blockIdx.x & 3u) : w;  // which 8x8 sub-tile of the tile this wave works on
+  const int sy0 = ty0 + (sub >> 1) * 8;
+  const int sx0 = tx0 + (sub & 1) * 8;
+  if (SPLIT && (sy0 >= y_end || sx0 >= x_end)) return;  // uniform
   const int yi = sy0 + (lane >> 3);
   const int xi = sx0 + (lane & 7);
   const bool pix_ok = yi < y_end && xi < x_end;
@@ -498,7 +543,11 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
   if (count <= 0) {
     // background tile (3 of 5 at the bench workload): nothing but the -1 stores; skip the NDC set-up below
     if (!(P3D_DBG(a) & 4) && !(P3D_DBG(a) & 2048)) {
-      if ((a.K & 3) == 0 && !(P3D_DBG(a) & 64) && P3D_BG_FILL_MODE != 0 && P3D_BG_FILL_MODE != 4) {
+      if (SPLIT && (a.K & 3) == 0) {
+        fill_tile_background<kStage, false>(a, n, sy0, sx0, y_end, x_end, tid, 8);
+      } else if (SPLIT && w != 0) {
+        // the four waves cover the same pixels: wave 0 writes them
+      } else if ((a.K & 3) == 0 && !(P3D_DBG(a) & 64) && P3D_BG_FILL_MODE != 0 && P3D_BG_FILL_MODE != 4) {
         if (P3D_BG_FILL_MODE == 2) {
           if (tid < kWave) fill_tile_background<kWave, false>(a, n, ty0, tx0, y_end, x_end, tid);
         } else {
@@ -545,11 +594,11 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
   lds.qlow = s_qlow;
   lds.ord = &s_ord;
   lds.wcnt = s_wcnt;
-  TileRect tile;
-  tile.x0 = tile_x0;
-  tile.x1 = tile_x1;
-  tile.y0 = tile_y0;
-  tile.y1 = tile_y1;
+  TileRect tile;  // what a face has to touch to be staged: the tile, or (split mode) the workgroup's one sub-tile
+  tile.x0 = SPLIT ? sub_x0 : tile_x0;
+  tile.x1 = SPLIT ? sub_x1 : tile_x1;
+  tile.y0 = SPLIT ? sub_y0 : tile_y0;
+  tile.y1 = SPLIT ? sub_y1 : tile_y1;
   SubTile st;
   st.x0 = sub_x0;
   st.x1 = sub_x1;
@@ -577,15 +626,25 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
     }
     if (run_waves)
       wave_chunk<false, Queue, PC>(a, K, q, staged, !(P3D_DBG(a) & 32), st, p, pix_ok, lane, persp, clip, prune, s_box, s_rec, s_zc, s_order,
-                               s_qlow);
+                               s_qlow, SPLIT ? w : -1);
     __syncthreads();
+  }
+  if constexpr (SPLIT) {
+    // the queues of waves 1..3 join wave 0's: before the general nest (its neighbour rule must see every entry queued so
+    // far, and only wave 0 walks it), or before the pixels are written
+    if (w != 0) merge_dump<Queue, KT>(q, s_merge + (w - 1) * kMergeWords * KT * kWave, lane);
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll 1
+      for (int src = 0; src < 3; ++src) merge_absorb<Queue, KT>(q, K, s_merge + src * kMergeWords * KT * kWave, lane);
+    }
   }
   if (general) {
     for (;;) {
       // chunk `base` is staged; faces keep ascending index order (the neighbour rule depends on it)
       if (tid < staged) s_order[tid] = tid;
       __syncthreads();
-      if (run_waves)
+      if (run_waves && (!SPLIT || w == 0))
         wave_chunk<true, Queue>(a, K, q, staged, false, st, p, pix_ok, lane, persp, clip, prune, s_box, s_rec, s_zc, s_order, s_qlow);
       __syncthreads();
       base += kStage;
@@ -597,7 +656,8 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
 
   if (!(P3D_DBG(a) & 4)) {
     if constexpr (EXACT) {
-      if (pix_ok) write_pixel<Queue, KT, IN_REGS, P3D_ACTIVE_NT != 0>(a, q, ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi));
+      if (pix_ok && (!SPLIT || w == 0))
+        write_pixel<Queue, KT, IN_REGS, P3D_ACTIVE_NT != 0>(a, q, ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi));
     } else {
       if (wave_ok) write_subtile_fill_patch<Queue, KT, IN_REGS>(a, q, true, n, sy0, sx0, y_end, x_end, lane, pix_ok, yi, xi);
     }
@@ -610,6 +670,24 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
     a.timeline[3 * (size_t)blockIdx.x + 2] = (unsigned long long)count;
   }
 #endif
+}
+
+// The instantiations one (Queue, K) pair can run as: split (few tiles), compile-time persp & clip, or plain.
+template <typename Q, int KT, bool REGS, bool BINNED, bool EXACT>
+void launch_fine_variant(const MeshArgs& a, unsigned grid, bool split, size_t dyn_lds, hipStream_t stream) {
+  if constexpr (REGS && EXACT && BINNED) {
+    if (split) {
+      mesh_raster_kernel<Q, KT, REGS, BINNED, EXACT, P3D_FINE_WAVES_PER_SIMD, false, true><<<grid * 4, kStage, 0, stream>>>(a);
+      return;
+    }
+  }
+  if constexpr (REGS && EXACT) {
+    if (a.persp && a.clip) {
+      mesh_raster_kernel<Q, KT, REGS, BINNED, EXACT, P3D_FINE_WAVES_PER_SIMD, true><<<grid, kStage, dyn_lds, stream>>>(a);
+      return;
+    }
+  }
+  mesh_raster_kernel<Q, KT, REGS, BINNED, EXACT><<<grid, kStage, dyn_lds, stream>>>(a);
 }
 
 #define P3D_COMMA ,
@@ -664,13 +742,13 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
 #endif
   LaunchScope ls(name, stream);
   const int K = a.K;
-#define P3D_LAUNCH_FINE(KT_, REGS_, EXACT_, Q_)                                                                       \
-  do {                                                                                                                \
-    if (REGS_ && EXACT_ && a.persp && a.clip)                                                                         \
-      mesh_raster_kernel<Q_, KT_, REGS_, BINNED, EXACT_, P3D_FINE_WAVES_PER_SIMD, true><<<grid, kStage, dyn_lds, stream>>>(a); \
-    else                                                                                                              \
-      mesh_raster_kernel<Q_, KT_, REGS_, BINNED, EXACT_><<<grid, kStage, dyn_lds, stream>>>(a);                         \
-  } while (0)
+  // few tiles (one image, a small batch): one workgroup per sub-tile with the candidate list dealt to its four waves
+  bool split = BINNED && grid <= (unsigned)kSplitMaxTiles;
+#ifdef P3D_ABLATION
+  if (P3D_DBG(a) & 1024) split = false;
+  if (P3D_DBG(a) & 131072) split = BINNED;
+#endif
+#define P3D_LAUNCH_FINE(KT_, REGS_, EXACT_, Q_) launch_fine_variant<Q_, KT_, REGS_, BINNED, EXACT_>(a, grid, split, dyn_lds, stream)
 #define P3D_LAUNCH_FINE_W(KT_, WAVES_, Q_) mesh_raster_kernel<Q_, KT_, true, BINNED, false, WAVES_><<<grid, kStage, 0, stream>>>(a)
   if (K == 1)
     P3D_LAUNCH_FINE(1, true, true, TopKReg<1 P3D_COMMA kMeshPayload>);
