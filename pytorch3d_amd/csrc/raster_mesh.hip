@@ -33,7 +33,10 @@ namespace {
 constexpr int kTile = 16;       // pixels per tile side (4 waves x 8x8)
 constexpr int kStage = 256;     // faces staged per round = threads per workgroup
 constexpr int kMeshPayload = 4; // dist, bary.x, bary.y, bary.z
-constexpr int kSplitMaxTiles = 1024;  // launches with at most this many 16x16 tiles use the split kernel (see mesh_raster_kernel)
+// Launches with at most this many 16x16 tiles (two per CU) use the split kernel (see mesh_raster_kernel).  Measured with
+// bench meshes under SoftRas blur (full queues): 256 tiles 0.151 -> 0.084 ms, 1024 tiles 0.095 -> 0.115 ms (four queues
+// per pixel cull later than one), 2048 tiles 0.094 -> 0.224 ms.
+constexpr int kSplitMaxTiles = 512;
 
 #ifndef P3D_FINE_WAVES_PER_SIMD
 #define P3D_FINE_WAVES_PER_SIMD 4  // caps the fine kernel at 128 VGPRs: 4 waves/SIMD instead of 2
