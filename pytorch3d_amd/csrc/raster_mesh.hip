@@ -11,10 +11,18 @@
 //   * each wave then culls the staged faces against its own 8x8 sub-tile 64 faces at a time
 //     (one lane per face, conflict-free LDS reads), and only the surviving faces are evaluated
 //     per pixel, their vertex records read as LDS broadcasts;
+//   * the per-(pixel, face) test runs on a per-face record with shared reciprocals (p3d_geom.h: FaceRec,
+//     face_hit_rec -- bit-identical to the reference's twelve IEEE divisions, a third of their instructions);
+//     faces with a clipped neighbour are handled by a second loop nest that a tile enters at most once;
 //   * the per-pixel queue lives in VGPRs (topk.h); every output element, -1 padding included, is
-//     written exactly once by the kernel, a pixel's K values as 16-byte stores.
+//     written exactly once by the kernel, a pixel's K values as 16-byte stores; tiles without faces are
+//     filled cooperatively in memory order;
+//   * launches of few tiles (one image) run one workgroup per 8x8 sub-tile with the list dealt to its four
+//     waves (SPLIT, see mesh_raster_kernel).
 // The naive operator is the same kernel with "the bin" being the whole image and "the list"
-// being the mesh's face range, so naive and binned results are identical by construction.
+// being the mesh's face range.  Naive and binned results agree by construction, which is why neither is
+// tested against the other alone: both are compared with the C oracle and with the reference's own CPU and
+// device kernels (tests/test_gpu_baseline_sizes.py, tests/test_gpu_vs_reference_device_kernels.py).
 //
 // The SoftRas backward lives in raster_mesh_bwd.hip.
 #include "binning.h"
