@@ -56,6 +56,17 @@ def parse():
     return ap.parse_args()
 
 
+def sub_batches_of_rank(jobs, batch, rank, world):
+    """BASELINE configs[4] (SURVEY.md 8d config 5): `jobs` render jobs = jobs / batch sub-batches (generator seeds 0, 1, ...);
+    rank r owns sub-batches r, r + world, ...  Raises when the sub-batches do not divide over the ranks."""
+    if jobs % batch:
+        raise SystemExit("--jobs must be a multiple of --batch")
+    n_sub = jobs // batch
+    if n_sub % world:
+        raise SystemExit(f"--jobs {jobs}: {n_sub} sub-batches do not divide over {world} ranks")
+    return list(range(rank, n_sub, world))
+
+
 def build_batch(n_meshes, seed, device):
     import _util as U
     import pytorch3d_amd as p3d
@@ -288,12 +299,7 @@ def main():
     # ---- which sub-batches this rank owns ---------------------------------------------------------------------
     jobs_mode = args.jobs > 0
     if jobs_mode:
-        if args.jobs % B:
-            raise SystemExit("--jobs must be a multiple of --batch")
-        n_sub = args.jobs // B
-        if n_sub % world:
-            raise SystemExit(f"--jobs {args.jobs}: {n_sub} sub-batches do not divide over {world} ranks")
-        seeds = list(range(rank, n_sub, world))  # sub-batch s = generator seed s
+        seeds = sub_batches_of_rank(args.jobs, B, rank, world)  # sub-batch s = generator seed s
         steps = len(seeds)
     else:
         seeds = [rank]
