@@ -1,46 +1,48 @@
-"""Host-side mirror of pytorch3d/renderer/compositing.py:19-247 over pytorch3d_amd._C.
+"""Point compositing on the HIP kernels: `alpha_composite`, `norm_weighted_sum`, `weighted_sum`.
 
-Differences from the reference wrapper, all invisible to callers: no `.clone()` of the three
-inputs for backward (compositing.py:50 -- the kernels never write their inputs) and no forced
-contiguous copies of the permuted (N,H,W,K) views (the C ABI takes strides).
+Same call signatures as the reference (pytorch3d/renderer/compositing.py:68-96, 148-175, 227-247): indices and alphas of
+shape (N, K, H, W), features (C, P), result (N, C, H, W).  One autograd node serves the three modes; it keeps references
+to its inputs (the kernels never write them, so the reference's three `.clone()`s are not needed) and hands the
+renderer's permuted (N, H, W, K) views to the C ABI as they are (it takes strides, no `.contiguous()` copies).
 """
 import torch
 
 from . import _C
 
-
-def _make(forward_op, backward_op):
-    class _Composite(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, features, alphas, points_idx):
-            pt_cld = forward_op(features, alphas, points_idx)
-            ctx.save_for_backward(features, alphas, points_idx)
-            return pt_cld
-
-        @staticmethod
-        def backward(ctx, grad_output):
-            features, alphas, points_idx = ctx.saved_tensors
-            grad_features, grad_alphas = backward_op(grad_output, features, alphas, points_idx)
-            return grad_features, grad_alphas, None
-
-    return _Composite
+_KERNELS = {
+    "alpha": (_C.accum_alphacomposite, _C.accum_alphacomposite_backward),
+    "norm": (_C.accum_weightedsumnorm, _C.accum_weightedsumnorm_backward),
+    "sum": (_C.accum_weightedsum, _C.accum_weightedsum_backward),
+}
 
 
-_CompositeAlphaPoints = _make(_C.accum_alphacomposite, _C.accum_alphacomposite_backward)
-_CompositeNormWeightedSumPoints = _make(_C.accum_weightedsumnorm, _C.accum_weightedsumnorm_backward)
-_CompositeWeightedSumPoints = _make(_C.accum_weightedsum, _C.accum_weightedsum_backward)
+class _Compose(torch.autograd.Function):
+    """(mode, features (C,P), alphas (N,K,H,W), point indices (N,K,H,W)) -> images (N,C,H,W); gradients to the features
+    and the alphas."""
+
+    @staticmethod
+    def forward(ctx, mode, features, alphas, indices):
+        ctx.mode = mode
+        ctx.save_for_backward(features, alphas, indices)
+        return _KERNELS[mode][0](features, alphas, indices)
+
+    @staticmethod
+    def backward(ctx, grad_images):
+        features, alphas, indices = ctx.saved_tensors
+        g_features, g_alphas = _KERNELS[ctx.mode][1](grad_images, features, alphas, indices)
+        return None, g_features, g_alphas, None
 
 
 def alpha_composite(pointsidx, alphas, pt_clds) -> torch.Tensor:
-    """compositing.py:68-96.  pointsidx/alphas (N,K,H,W), pt_clds (C,P) -> (N,C,H,W)."""
-    return _CompositeAlphaPoints.apply(pt_clds, alphas, pointsidx)
+    """Front-to-back alpha compositing: sum_k f[idx_k] * a_k * prod_{l<k} (1 - a_l)."""
+    return _Compose.apply("alpha", pt_clds, alphas, pointsidx)
 
 
 def norm_weighted_sum(pointsidx, alphas, pt_clds) -> torch.Tensor:
-    """compositing.py:148-175."""
-    return _CompositeNormWeightedSumPoints.apply(pt_clds, alphas, pointsidx)
+    """sum_k a_k f[idx_k] / max(sum_k a_k, 1e-4)."""
+    return _Compose.apply("norm", pt_clds, alphas, pointsidx)
 
 
 def weighted_sum(pointsidx, alphas, pt_clds) -> torch.Tensor:
-    """compositing.py:227-247."""
-    return _CompositeWeightedSumPoints.apply(pt_clds, alphas, pointsidx)
+    """sum_k a_k f[idx_k]."""
+    return _Compose.apply("sum", pt_clds, alphas, pointsidx)
