@@ -311,6 +311,25 @@ int p3d_sample_uv_backward(const float* grad_texels, const int64_t* pix_to_face,
                            int C, int align_corners, int padding_mode, int sampling_mode, float* grad_bary_coords,
                            float* grad_face_uvs, float* grad_maps, p3d_stream_t stream);
 
+/* replaces TexturesAtlas.sample_textures (pytorch3d/renderer/mesh/textures.py:565-612): the nearest-cell lookup of a
+ * per-face R x R atlas (F,R,R,C) by the first two barycentrics of each of the P = N*H*W*K samples -> texels (P,C), fully
+ * written (zero for pix_to_face < 0).  Cell arithmetic: csrc/atlas_cell.h.  Indices the reference fails on (torch raises
+ * IndexError: face >= F, cell outside [-R, R-1]) read as zero.  Backward: grad_atlas (F,R,R,C) zeroed and accumulated;
+ * the barycentrics have no gradient (nearest sampling), as in the reference. */
+int p3d_sample_atlas_forward(const int64_t* pix_to_face, const float* bary_coords, const float* atlas, int64_t P, int64_t F,
+                             int R, int C, float* texels, p3d_stream_t stream);
+int p3d_sample_atlas_backward(const float* grad_texels, const int64_t* pix_to_face, const float* bary_coords, int64_t P,
+                              int64_t F, int R, int C, float* grad_atlas, p3d_stream_t stream);
+
+/* replaces hard_rgb_blend (pytorch3d/renderer/blending.py:54-88: mask, masked_scatter of the background colour, cat with
+ * the alpha channel): colors (npix,K,3), pix_to_face (npix,K) -> out (npix,4), 16-byte aligned: RGB of slot 0 and
+ * alpha 1 where pix_to_face[...,0] >= 0, else the background colour and alpha 0.  Backward: grad_colors (npix,K,3)
+ * fully written (slot 0 of covered pixels = grad_out[..., :3], zero elsewhere). */
+int p3d_hard_rgb_blend_forward(const float* colors, const int64_t* pix_to_face, const float background[3], int64_t npix,
+                               int K, float* out, p3d_stream_t stream);
+int p3d_hard_rgb_blend_backward(const float* grad_out, const int64_t* pix_to_face, int64_t npix, int K, float* grad_colors,
+                                p3d_stream_t stream);
+
 /* ---- built-in per-kernel timing (HIP events on the launch stream) --------------------- */
 
 /* enable != 0: every kernel launch is bracketed by hipEventRecord on its stream. */

@@ -314,6 +314,41 @@ def sample_uv_backward(grad_texels, pix_to_face, bary, face_uvs, maps, align_cor
     return gb, gfu, gm
 
 
+def sample_atlas(pix_to_face, bary, atlas):
+    """TexturesAtlas.sample_textures restated (oracle/p3d_oracle.c: orc_sample_atlas_forward)."""
+    p2f, b, at = _i64(pix_to_face), _f32(bary), _f32(atlas)
+    F, R, _, C = at.shape
+    out = torch.zeros(tuple(p2f.shape) + (C,), dtype=torch.float32)
+    lib().orc_sample_atlas_forward(_p(p2f), _p(b), _p(at), ctypes.c_int64(p2f.numel()), ctypes.c_int64(F), R, C, _p(out))
+    return out
+
+
+def sample_atlas_backward(grad_texels, pix_to_face, bary, atlas_shape):
+    g, p2f, b = _f32(grad_texels), _i64(pix_to_face), _f32(bary)
+    F, R, _, C = atlas_shape
+    ga = torch.zeros((F, R, R, C), dtype=torch.float32)
+    lib().orc_sample_atlas_backward(_p(g), _p(p2f), _p(b), ctypes.c_int64(p2f.numel()), ctypes.c_int64(F), R, C, _p(ga))
+    return ga
+
+
+def hard_rgb_blend(colors, pix_to_face, background):
+    """hard_rgb_blend restated (oracle/p3d_oracle.c: orc_hard_rgb_blend_forward)."""
+    c, p2f = _f32(colors), _i64(pix_to_face)
+    N, H, W, K = p2f.shape
+    bg = _f32(torch.as_tensor(background, dtype=torch.float32))
+    out = torch.zeros((N, H, W, 4), dtype=torch.float32)
+    lib().orc_hard_rgb_blend_forward(_p(c), _p(p2f), _p(bg), ctypes.c_int64(N * H * W), K, _p(out))
+    return out
+
+
+def hard_rgb_blend_backward(grad_out, pix_to_face):
+    g, p2f = _f32(grad_out), _i64(pix_to_face)
+    N, H, W, K = p2f.shape
+    gc = torch.zeros((N, H, W, K, 3), dtype=torch.float32)
+    lib().orc_hard_rgb_blend_backward(_p(g), _p(p2f), ctypes.c_int64(N * H * W), K, _p(gc))
+    return gc
+
+
 _ref_hip = {}
 
 

@@ -1,5 +1,7 @@
 """Host-side mirror of pytorch3d/renderer/blending.py:43-244 over the C ABI.
 
+`hard_rgb_blend` (blending.py:54-88) is one kernel each way (p3d_hard_rgb_blend_forward / _backward).
+
 `sigmoid_alpha_blend` goes through `pytorch3d_amd._C.sigmoid_alpha_blend[_backward]` exactly like the
 reference's wrapper (blending.py:95-140).  `softmax_rgb_blend`, ~20 elementwise torch ops plus their autograd
 graph in the reference (blending.py:147-244), is ONE kernel forward and ONE backward here
@@ -45,13 +47,13 @@ def sigmoid_alpha_blend(colors, fragments, blend_params: BlendParams) -> torch.T
     return pixel_colors
 
 
-def _background(blend_params, device):
+def _background(blend_params, device, who="softmax_rgb_blend"):
     bg = blend_params.background_color
     if isinstance(bg, torch.Tensor):
         if bg.requires_grad:
             # the reference keeps the background in the autograd graph (blending.py:183-186); the fused kernel takes it
             # as three constants -- refuse rather than return a silently missing gradient
-            raise NotImplementedError("softmax_rgb_blend: a background_color that requires grad is not supported by the "
+            raise NotImplementedError(who + ": a background_color that requires grad is not supported by the "
                                       "fused kernel (it is passed as constants); detach it or blend with torch ops")
         bg = [float(x) for x in bg.detach().reshape(-1).tolist()]
     bg = [float(x) for x in bg]
@@ -129,3 +131,45 @@ def softmax_rgb_blend(colors, fragments, blend_params: BlendParams, znear: Union
     bg = _background(blend_params, colors.device)
     return _SoftmaxRGBBlend.apply(colors, fragments.dists, fragments.zbuf, fragments.pix_to_face, blend_params.sigma,
                                   blend_params.gamma, bg, znear, zfar)
+
+
+class _HardRGBBlend(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, colors, pix_to_face, bg):
+        N, H, W, K = pix_to_face.shape
+        dev = colors.device
+        c, p2f = colors.contiguous(), pix_to_face.contiguous()
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            out = torch.empty((N, H, W, 4), dtype=torch.float32, device=dev)
+            if out.numel():
+                rc = lib.p3d_hard_rgb_blend_forward(_C._ptr(c), _C._ptr(p2f), bg, N * H * W, K, _C._ptr(out), _C._stream(dev))
+                _lib.check(rc, "hard_rgb_blend")
+        ctx.save_for_backward(p2f)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (p2f,) = ctx.saved_tensors
+        N, H, W, K = p2f.shape
+        dev = p2f.device
+        g = grad_out.contiguous()
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            gc = torch.empty((N, H, W, K, 3), dtype=torch.float32, device=dev)
+            if gc.numel():
+                rc = lib.p3d_hard_rgb_blend_backward(_C._ptr(g), _C._ptr(p2f), N * H * W, K, _C._ptr(gc), _C._stream(dev))
+                _lib.check(rc, "hard_rgb_blend_backward")
+        return gc, None, None
+
+
+def hard_rgb_blend(colors, fragments, blend_params: BlendParams) -> torch.Tensor:
+    """blending.py:54-88: RGB of the closest face (slot 0), the background colour where no face covers the pixel;
+    alpha 1 / 0.  colors (N,H,W,K,3) -> RGBA (N,H,W,4)."""
+    for name, t in (("colors", colors), ("pix_to_face", fragments.pix_to_face)):
+        _C._need_gpu(t, name)
+    if colors.dtype != torch.float32:
+        raise RuntimeError("hard_rgb_blend: colors must be float32")
+    if colors.shape != tuple(fragments.pix_to_face.shape) + (3,) or fragments.pix_to_face.shape[3] < 1:
+        raise ValueError("colors must have shape (N, H, W, K, 3) with K >= 1 matching pix_to_face")
+    return _HardRGBBlend.apply(colors, fragments.pix_to_face, _background(blend_params, colors.device, "hard_rgb_blend"))

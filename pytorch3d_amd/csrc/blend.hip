@@ -424,6 +424,38 @@ unsigned blend_grid(int64_t npix) {
   return (unsigned)(b < 1 ? 1 : b);
 }
 
+// ---- hard_rgb_blend (blending.py:54-88): colour of the closest face, the background colour where there is none,
+// alpha = 1 / 0.  A thread per pixel reads pix_to_face[..., 0] and the first of the K colour slots.
+__global__ __launch_bounds__(kBlendBlock) void hard_blend_fwd_kernel(const float* __restrict__ colors,
+                                                                      const int64_t* __restrict__ p2f, float bg0, float bg1,
+                                                                      float bg2, int64_t npix, int K,
+                                                                      float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlendBlock + threadIdx.x; i < npix; i += (int64_t)gridDim.x * kBlendBlock) {
+    const bool hit = p2f[i * K] >= 0;
+    const float* c = colors + i * K * 3;
+    float4 o;
+    o.x = hit ? c[0] : bg0;
+    o.y = hit ? c[1] : bg1;
+    o.z = hit ? c[2] : bg2;
+    o.w = hit ? 1.0f : 0.0f;
+    reinterpret_cast<float4*>(out)[i] = o;
+  }
+}
+
+// grad_colors (npix, K, 3) fully written: slot 0 of covered pixels takes grad_out[..., :3], everything else is zero
+__global__ __launch_bounds__(kBlendBlock) void hard_blend_bwd_kernel(const float* __restrict__ grad_out,
+                                                                      const int64_t* __restrict__ p2f, int64_t npix, int K,
+                                                                      float* __restrict__ grad_colors) {
+  const int64_t per_pix = (int64_t)K * 3, total = npix * per_pix;
+  for (int64_t e = (int64_t)blockIdx.x * kBlendBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlendBlock) {
+    const int64_t pix = e / per_pix;
+    const int r = (int)(e - pix * per_pix);
+    float g = 0.0f;
+    if (r < 3 && p2f[pix * K] >= 0) g = grad_out[pix * 4 + r];
+    grad_colors[e] = g;
+  }
+}
+
 // smallest instantiated capacity >= K (0 when K is too large for the register kernels)
 int blend_capacity(int K) { return K <= 1 ? 1 : K <= 2 ? 2 : K <= 4 ? 4 : K <= 8 ? 8 : K <= 16 ? 16 : K <= 32 ? 32 : 0; }
 
@@ -531,5 +563,29 @@ P3D_API int p3d_softmax_rgb_blend_backward(const float* grad_out, const float* c
   const unsigned grid = blend_grid(a.npix);
   LaunchScope ls("softmax_blend_bwd", s);
   P3D_BLEND_DISPATCH(softmax_blend_bwd_kernel, softmax_blend_generic<true>, K, a)
+  return launch_status();
+}
+
+P3D_API int p3d_hard_rgb_blend_forward(const float* colors, const int64_t* pix_to_face, const float background[3],
+                                       int64_t npix, int K, float* out, p3d_stream_t stream) {
+  if (npix < 0 || K < 1 || !background) return P3D_ERR_INVALID_ARG;
+  if (npix == 0) return P3D_OK;
+  if (!colors || !pix_to_face || !out || ((uintptr_t)out & 15) != 0) return P3D_ERR_INVALID_ARG;  // float4 stores
+  hipStream_t s = (hipStream_t)stream;
+  LaunchScope ls("hard_blend_fwd", s);
+  hard_blend_fwd_kernel<<<blend_grid(npix), kBlendBlock, 0, s>>>(colors, pix_to_face, background[0], background[1],
+                                                                 background[2], npix, K, out);
+  return launch_status();
+}
+
+P3D_API int p3d_hard_rgb_blend_backward(const float* grad_out, const int64_t* pix_to_face, int64_t npix, int K,
+                                        float* grad_colors, p3d_stream_t stream) {
+  if (npix < 0 || K < 1) return P3D_ERR_INVALID_ARG;
+  if (npix == 0) return P3D_OK;
+  if (!grad_out || !pix_to_face || !grad_colors) return P3D_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  LaunchScope ls("hard_blend_bwd", s);
+  hard_blend_bwd_kernel<<<blend_grid(npix * K * 3), kBlendBlock, 0, s>>>(grad_out, pix_to_face, npix, K,
+                                                                               grad_colors);
   return launch_status();
 }

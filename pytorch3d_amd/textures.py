@@ -1,5 +1,9 @@
-"""Host-side mirror of TexturesUV.sample_textures (pytorch3d/renderer/mesh/textures.py:1190-1268)
-over the C ABI: uv interpolation + grid_sample fused into one kernel each way (include/p3d_amd.h:
+"""Host-side mirror of the texture classes' sample_textures over the C ABI.
+
+TexturesAtlas.sample_textures (pytorch3d/renderer/mesh/textures.py:565-612): `sample_textures_atlas`, one kernel each way
+(include/p3d_amd.h: p3d_sample_atlas_forward / _backward), gradient to the atlas only -- as in the reference.
+
+TexturesUV.sample_textures (textures.py:1190-1268): uv interpolation + grid_sample fused into one kernel each way (include/p3d_amd.h:
 p3d_sample_uv_forward / _backward).  One texture map per mesh (`maps_ids` is not provided); padding "zeros" or
 "border", sampling "bilinear" or "nearest", as F.grid_sample defines them.  Gradients flow to the maps, the per-face uvs
 and the barycentric coordinates.
@@ -70,3 +74,54 @@ def sample_textures_uv(fragments, faces_verts_uvs, maps, align_corners: bool = T
         raise RuntimeError("sample_textures_uv: faces_verts_uvs and maps must be float32")
     return _SampleUV.apply(fragments.pix_to_face, fragments.bary_coords, faces_verts_uvs, maps, int(bool(align_corners)),
                            _PAD[padding_mode], _MODE[sampling_mode])
+
+
+class _SampleAtlas(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pix_to_face, bary, atlas):
+        dev = atlas.device
+        p2f, b, at = pix_to_face.contiguous(), bary.contiguous(), atlas.contiguous()
+        F, R, _, C = at.shape
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            out = torch.empty(tuple(p2f.shape) + (C,), dtype=torch.float32, device=dev)
+            if out.numel():
+                rc = lib.p3d_sample_atlas_forward(_C._ptr(p2f), _C._ptr(b), _C._ptr(at), p2f.numel(), F, R, C, _C._ptr(out),
+                                                  _C._stream(dev))
+                _lib.check(rc, "sample_textures_atlas")
+        ctx.save_for_backward(p2f, b)
+        ctx.atlas_shape = (F, R, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_texels):
+        p2f, b = ctx.saved_tensors
+        F, R, C = ctx.atlas_shape
+        dev = b.device
+        g = grad_texels.contiguous()
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            ga = torch.empty((F, R, R, C), dtype=torch.float32, device=dev)
+            if ga.numel():
+                rc = lib.p3d_sample_atlas_backward(_C._ptr(g), _C._ptr(p2f), _C._ptr(b), p2f.numel(), F, R, C, _C._ptr(ga),
+                                                   _C._stream(dev))
+                _lib.check(rc, "sample_textures_atlas_backward")
+        return None, None, ga
+
+
+def sample_textures_atlas(fragments, atlas_packed) -> torch.Tensor:
+    """TexturesAtlas.sample_textures(fragments) for atlas_packed = atlas_packed() (F,R,R,C) -> texels (N,H,W,K,C): the
+    cell of the face's R x R grid nearest to the barycentric sample (textures.py:565-612).  Differentiable with respect
+    to the atlas, not to the barycentric coordinates."""
+    for name, t in (("pix_to_face", fragments.pix_to_face), ("bary_coords", fragments.bary_coords),
+                    ("atlas_packed", atlas_packed)):
+        _C._need_gpu(t, name)
+    if atlas_packed.dim() != 4 or atlas_packed.shape[1] != atlas_packed.shape[2] or atlas_packed.shape[1] < 1:
+        raise ValueError("atlas_packed must have shape (F, R, R, C)")
+    if atlas_packed.dtype != torch.float32 or fragments.bary_coords.dtype != torch.float32:
+        raise RuntimeError("sample_textures_atlas: atlas_packed and bary_coords must be float32")
+    if fragments.bary_coords.shape != tuple(fragments.pix_to_face.shape) + (3,):
+        raise ValueError("bary_coords must have shape pix_to_face.shape + (3,)")
+    if atlas_packed.shape[3] < 1:
+        raise ValueError("atlas_packed needs at least one channel")
+    return _SampleAtlas.apply(fragments.pix_to_face, fragments.bary_coords, atlas_packed)

@@ -7,6 +7,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include "../../pytorch3d_amd/csrc/atlas_cell.h"
 #include "../../pytorch3d_amd/csrc/p3d_geom.h"
 #include "../../pytorch3d_amd/csrc/topk.h"
 
@@ -177,4 +178,12 @@ extern "C" int64_t hg_exact_div_check(int64_t trials, uint64_t seed) {
     }
   }
   return bad;
+}
+
+// the atlas cell (atlas_cell.h) of P barycentric samples: cells[p] = row * R + col, or -1 where not addressable
+extern "C" void hg_atlas_cells(const float* bary, int64_t P, int R, int64_t* cells) {
+  for (int64_t p = 0; p < P; ++p) {
+    int row, col;
+    cells[p] = atlas_cell(bary[p * 3], bary[p * 3 + 1], R, &row, &col) ? (int64_t)row * R + col : -1;
+  }
 }
