@@ -44,10 +44,8 @@ __global__ __launch_bounds__(kAtlasBlock) void atlas_fwd_kernel(AtlasArgs a) {
     const int64_t off = cell_offset(a, i);
     float* out = a.texels + i * C;
     if (off < 0) {
-#pragma unroll
       for (int c = 0; c < C; ++c) out[c] = 0.0f;
     } else {
-#pragma unroll
       for (int c = 0; c < C; ++c) out[c] = a.atlas[off + c];
     }
   }
@@ -60,7 +58,6 @@ __global__ __launch_bounds__(kAtlasBlock) void atlas_bwd_kernel(AtlasArgs a) {
     const int64_t off = cell_offset(a, i);
     if (off < 0) continue;
     const float* g = a.gtex + i * C;
-#pragma unroll
     for (int c = 0; c < C; ++c) atomicAdd(a.gatlas + off + c, g[c]);
   }
 }

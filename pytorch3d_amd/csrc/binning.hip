@@ -63,15 +63,42 @@ struct ChunkCtx {
   BinRect u;    // union over the wave
 };
 
-// Shared prologue of the count and fill kernels.
+// Small launches (N <= kSelfPlanMax, see bin_build) skip the plan kernel: every workgroup derives the chunk table
+// itself, one wave scanning ceil(count / 1024) into LDS.  cs: kSelfPlanMax + 1 ints.  Ends with a barrier.
+constexpr int kSelfPlanMax = 64;
+
+__device__ __forceinline__ void plan_in_lds(const int64_t* __restrict__ count, int N, int* cs) {
+  const int tid = threadIdx.x;
+  if (tid < kWave) {
+    int v = 0;
+    if (tid < N) {
+      const int64_t c = count[tid];
+      v = c > 0 ? (int)((c + kBinChunk - 1) / kBinChunk) : 0;
+    }
+    int x = v;
+    for (int d = 1; d < kWave; d <<= 1) {
+      const int y = __shfl_up(x, d);
+      if (tid >= d) x += y;
+    }
+    cs[tid + 1] = x;
+    if (tid == 0) cs[0] = 0;
+  }
+  __syncthreads();
+}
+
+// Shared prologue of the count and fill kernels.  chunk_start == nullptr: plan in LDS (cs_l) instead.
 template <int KIND>
 __device__ __forceinline__ bool chunk_prologue(const float* __restrict__ elems, const float* __restrict__ aux,
                                                const int64_t* __restrict__ first, const int64_t* __restrict__ count,
-                                               const int* __restrict__ chunk_start, int N, int H, int W, int bin_size,
+                                               const int* chunk_start, int* cs_l, int N, int H, int W, int bin_size,
                                                int BH, int BW, float sqrt_blur, float* xlo_t, float* xhi_t,
                                                float* ylo_t, float* yhi_t, ChunkCtx* c) {
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x;
+  if (chunk_start == nullptr) {
+    plan_in_lds(count, N, cs_l);
+    chunk_start = cs_l;
+  }
   if (chunk >= chunk_start[N]) return false;
   // largest n with chunk_start[n] <= chunk
   int lo = 0, hi = N;
@@ -173,16 +200,17 @@ __global__ __launch_bounds__(kBinChunk) void bin_count_kernel(const float* __res
                                                               const float* __restrict__ aux,
                                                               const int64_t* __restrict__ first,
                                                               const int64_t* __restrict__ count,
-                                                              const int* __restrict__ chunk_start, int N, int H, int W,
+                                                              const int* chunk_start, int N, int H, int W,
                                                               int bin_size, int BH, int BW, float sqrt_blur,
                                                               int* __restrict__ counts) {
   __shared__ float xlo_t[32], xhi_t[32], ylo_t[32], yhi_t[32];
+  __shared__ int cs_l[kSelfPlanMax + 1];
   __shared__ int blk_cnt[kMaxBins];
   const int nbins = BH * BW;
   for (int b = threadIdx.x; b < nbins; b += kBinChunk) blk_cnt[b] = 0;
   ChunkCtx c;
-  if (!chunk_prologue<KIND>(elems, aux, first, count, chunk_start, N, H, W, bin_size, BH, BW, sqrt_blur, xlo_t, xhi_t,
-                            ylo_t, yhi_t, &c))
+  if (!chunk_prologue<KIND>(elems, aux, first, count, chunk_start, cs_l, N, H, W, bin_size, BH, BW, sqrt_blur, xlo_t,
+                            xhi_t, ylo_t, yhi_t, &c))
     return;
   const int lane = lane_id();
   if (ORDERED) {
@@ -290,6 +318,45 @@ __global__ __launch_bounds__(1024) void bin_scan_offsets_kernel(const int* __res
 }
 
 // ---------------------------------------------------------------------------------------
+// Small launches (bin_build: N <= 64, <= 4096 rows, <= 128 chunks -- a single image or a small batch, where launch
+// latency is the cost): the row scan, the block sums and the offsets scan in ONE workgroup, planning in LDS.  A thread
+// per row walks its batch element's few chunks, then the 1024 rows of the step are scanned together.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void bin_scan_small_kernel(int* __restrict__ counts, const int64_t* __restrict__ count,
+                                                              int N, int nbins, int M, int* __restrict__ total,
+                                                              int64_t* __restrict__ offset) {
+  __shared__ int cs[kSelfPlanMax + 1];
+  __shared__ long long wsum[16];
+  plan_in_lds(count, N, cs);
+  const int tid = threadIdx.x;
+  const int64_t rows = (int64_t)N * nbins;
+  long long carry = 0;
+  for (int64_t base = 0; base < rows; base += 1024) {
+    const int64_t row = base + tid;
+    int t = 0;
+    if (row < rows) {
+      const int n = (int)(row / nbins), b = (int)(row % nbins);
+      const int c0 = cs[n], nch = cs[n + 1] - c0;
+      int run = 0;
+      for (int i = 0; i < nch; ++i) {
+        int* p = counts + (int64_t)(c0 + i) * nbins + b;
+        const int v = *p;
+        *p = run;
+        run += v;
+      }
+      t = run < M ? run : M;
+      total[row] = t;
+    }
+    long long all;
+    const long long ex = block_exclusive_scan_1024(t, wsum, &all);
+    if (row < rows) offset[row] = carry + ex;
+    carry += all;
+    __syncthreads();  // wsum is rewritten by the next step
+  }
+  if (tid == 0) offset[rows] = carry;
+}
+
+// ---------------------------------------------------------------------------------------
 // fill: re-derive the ballots and write ids at offset + row prefix + wave prefix + lane rank.
 // ---------------------------------------------------------------------------------------
 template <int KIND, bool ORDERED>
@@ -297,12 +364,13 @@ __global__ __launch_bounds__(kBinChunk) void bin_fill_kernel(const float* __rest
                                                              const float* __restrict__ aux,
                                                              const int64_t* __restrict__ first,
                                                              const int64_t* __restrict__ count,
-                                                             const int* __restrict__ chunk_start, int N, int H, int W,
+                                                             const int* chunk_start, int N, int H, int W,
                                                              int bin_size, int BH, int BW, float sqrt_blur, int M,
                                                              const int* __restrict__ counts,
                                                              const int64_t* __restrict__ offset,
                                                              int* __restrict__ list) {
   __shared__ float xlo_t[32], xhi_t[32], ylo_t[32], yhi_t[32];
+  __shared__ int cs_l[kSelfPlanMax + 1];
   __shared__ unsigned short wpre[ORDERED ? kWavesPerChunk : 1][kMaxBins];  // per-wave counts, then prefixes (<= 1024)
   __shared__ int base_t[kMaxBins];                                         // this chunk's row prefix per bin
   const int nbins = BH * BW;
@@ -310,8 +378,8 @@ __global__ __launch_bounds__(kBinChunk) void bin_fill_kernel(const float* __rest
     for (int i = threadIdx.x; i < kWavesPerChunk * kMaxBins / 2; i += kBinChunk)
       reinterpret_cast<unsigned*>(&wpre[0][0])[i] = 0u;
   ChunkCtx c;
-  if (!chunk_prologue<KIND>(elems, aux, first, count, chunk_start, N, H, W, bin_size, BH, BW, sqrt_blur, xlo_t, xhi_t,
-                            ylo_t, yhi_t, &c))
+  if (!chunk_prologue<KIND>(elems, aux, first, count, chunk_start, cs_l, N, H, W, bin_size, BH, BW, sqrt_blur, xlo_t,
+                            xhi_t, ylo_t, yhi_t, &c))
     return;
   const int lane = lane_id();
   const int w = threadIdx.x / kWave;
@@ -433,7 +501,10 @@ int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t*
               int N, const BinGeom& g, int M, float sqrt_blur, const BinWorkspace& ws, hipStream_t stream, bool ordered) {
   if (N <= 0) return P3D_OK;
   const int64_t rows = (int64_t)N * g.nbins;
-  {
+  // small launches: three kernels instead of six (no plan kernel, one scan kernel) -- see bin_scan_small_kernel
+  const bool small = N <= kSelfPlanMax && rows <= 4096 && ws.max_chunks <= 128;
+  const int* cs = small ? nullptr : ws.chunk_start;
+  if (!small) {
     LaunchScope ls("bin_plan", stream);
     bin_plan_kernel<<<1, 1024, 0, stream>>>(count, N, ws.chunk_start);
   }
@@ -441,23 +512,24 @@ int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t*
   {
     LaunchScope ls("bin_count", stream);
     if (kind == kTriangles)
-      bin_count_kernel<kTriangles, true><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, ws.chunk_start, N,
-                                                                          g.H, g.W, g.bin_size, g.BH, g.BW, sqrt_blur,
-                                                                          ws.counts);
+      bin_count_kernel<kTriangles, true><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, cs, N, g.H, g.W,
+                                                                          g.bin_size, g.BH, g.BW, sqrt_blur, ws.counts);
     else if (ordered)
-      bin_count_kernel<kPoints, true><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, ws.chunk_start, N, g.H,
-                                                                       g.W, g.bin_size, g.BH, g.BW, sqrt_blur, ws.counts);
+      bin_count_kernel<kPoints, true><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, cs, N, g.H, g.W,
+                                                                       g.bin_size, g.BH, g.BW, sqrt_blur, ws.counts);
     else
-      bin_count_kernel<kPoints, false><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, ws.chunk_start, N,
-                                                                        g.H, g.W, g.bin_size, g.BH, g.BW, sqrt_blur,
-                                                                        ws.counts);
+      bin_count_kernel<kPoints, false><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, cs, N, g.H, g.W,
+                                                                        g.bin_size, g.BH, g.BW, sqrt_blur, ws.counts);
   }
-  {
-    LaunchScope ls("bin_scan_rows", stream);
-    bin_scan_rows_kernel<<<(unsigned)ceil_div(rows, 4), 256, 0, stream>>>(ws.counts, ws.chunk_start, N, g.nbins, M,
-                                                                         ws.total);
-  }
-  {
+  if (small) {
+    LaunchScope ls("bin_scan_small", stream);
+    bin_scan_small_kernel<<<1, 1024, 0, stream>>>(ws.counts, count, N, g.nbins, M, ws.total, ws.offset);
+  } else {
+    {
+      LaunchScope ls("bin_scan_rows", stream);
+      bin_scan_rows_kernel<<<(unsigned)ceil_div(rows, 4), 256, 0, stream>>>(ws.counts, ws.chunk_start, N, g.nbins, M,
+                                                                           ws.total);
+    }
     LaunchScope ls("bin_scan_offsets", stream);
     const unsigned nb = (unsigned)ceil_div(rows, 1024);
     bin_block_sums_kernel<<<nb, 1024, 0, stream>>>(ws.total, rows, ws.blocksum);
@@ -466,17 +538,17 @@ int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t*
   {
     LaunchScope ls("bin_fill", stream);
     if (kind == kTriangles)
-      bin_fill_kernel<kTriangles, true><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, ws.chunk_start, N,
-                                                                         g.H, g.W, g.bin_size, g.BH, g.BW, sqrt_blur, M,
-                                                                         ws.counts, ws.offset, ws.list);
+      bin_fill_kernel<kTriangles, true><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, cs, N, g.H, g.W,
+                                                                         g.bin_size, g.BH, g.BW, sqrt_blur, M, ws.counts,
+                                                                         ws.offset, ws.list);
     else if (ordered)
-      bin_fill_kernel<kPoints, true><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, ws.chunk_start, N, g.H,
-                                                                      g.W, g.bin_size, g.BH, g.BW, sqrt_blur, M,
-                                                                      ws.counts, ws.offset, ws.list);
+      bin_fill_kernel<kPoints, true><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, cs, N, g.H, g.W,
+                                                                      g.bin_size, g.BH, g.BW, sqrt_blur, M, ws.counts,
+                                                                      ws.offset, ws.list);
     else
-      bin_fill_kernel<kPoints, false><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, ws.chunk_start, N, g.H,
-                                                                       g.W, g.bin_size, g.BH, g.BW, sqrt_blur, M,
-                                                                       ws.counts, ws.offset, ws.list);
+      bin_fill_kernel<kPoints, false><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, cs, N, g.H, g.W,
+                                                                       g.bin_size, g.BH, g.BW, sqrt_blur, M, ws.counts,
+                                                                       ws.offset, ws.list);
   }
   return launch_status();
 }
