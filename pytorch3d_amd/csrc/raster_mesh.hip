@@ -34,6 +34,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 namespace p3d {
 
 namespace {
@@ -60,6 +62,7 @@ struct MeshArgs {
   TileMap tm;
   float blur, sqrt_blur;
   int persp, clip, cull;
+  int skip_background;  // background tiles are written by mesh_fill_background_kernel on the side stream (concurrent fill)
   unsigned long long* timeline;  // -DP3D_FWD_TIMELINE builds only: per workgroup (start, end) of s_memrealtime (100 MHz) + face count
   int debug;  // P3D_DEBUG_FWD ablation bits (profiles/ablate.py): 1 no per-pixel evaluation, 2 no queue insertion, 4 no stores, 16 no depth cull, 32 no front-to-back order, 64 background tiles stored per lane instead of cooperatively, 128 no bin permutation, 256 no rectangle-vs-face prune, 512 caller's bin geometry instead of tile-sized bins, 2048 background tiles store nothing, 4096 tiles with faces do nothing, 8192 every tile is background, 16384 staging only (no candidate loop), 32768 every chunk takes the general (neighbour rule) loop, 1024 (launcher) never / 131072 always the split kernel
   int64_t* p2f;
@@ -528,7 +531,7 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int w = tid >> 6;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: the sub-tile origin stays in SGPRs
   const int sub = SPLIT ? (int)(blockIdx.x & 3u) : w;  // which 8x8 sub-tile of the tile this wave works on
   const int sy0 = ty0 + (sub >> 1) * 8;
   const int sx0 = tx0 + (sub & 1) * 8;
@@ -552,13 +555,15 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
   if (P3D_DBG(a) & 8192) count = 0;            // ablation: every tile is treated as background (pure fill)
   if ((P3D_DBG(a) & 4096) && count > 0) return;  // ablation: tiles with faces do nothing at all
   if (count <= 0) {
+    if (a.skip_background) return;  // uniform
+    const int Kbg = EXACT ? KT : a.K;  // compile-time where it can be: the row-fill branch is then the only one left
     // background tile (3 of 5 at the bench workload): nothing but the -1 stores; skip the NDC set-up below
     if (!(P3D_DBG(a) & 4) && !(P3D_DBG(a) & 2048)) {
-      if (SPLIT && (a.K & 3) == 0) {
+      if (SPLIT && (Kbg & 3) == 0) {
         fill_tile_background<kStage, false>(a, n, sy0, sx0, y_end, x_end, tid, 8);
       } else if (SPLIT && w != 0) {
         // the four waves cover the same pixels: wave 0 writes them
-      } else if ((a.K & 3) == 0 && !(P3D_DBG(a) & 64) && P3D_BG_FILL_MODE != 0 && P3D_BG_FILL_MODE != 4) {
+      } else if ((Kbg & 3) == 0 && !(P3D_DBG(a) & 64) && P3D_BG_FILL_MODE != 0 && P3D_BG_FILL_MODE != 4) {
         if (P3D_BG_FILL_MODE == 2) {
           if (tid < kWave) fill_tile_background<kWave, false>(a, n, ty0, tx0, y_end, x_end, tid);
         } else {
@@ -667,8 +672,14 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
 
   if (!(P3D_DBG(a) & 4)) {
     if constexpr (EXACT) {
-      if (pix_ok && (!SPLIT || w == 0))
-        write_pixel<Queue, KT, IN_REGS, P3D_ACTIVE_NT != 0>(a, q, ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi));
+      if (pix_ok && (!SPLIT || w == 0)) {
+        // the pixel's coordinates are rebuilt from a fresh lane id: keeping yi / xi alive across the chunk loops costs the
+        // two registers that separate this kernel from the 120-VGPR allocation step
+        int l2;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l2));
+        const int yo = sy0 + (l2 >> 3), xo = sx0 + (l2 & 7);
+        write_pixel<Queue, KT, IN_REGS, P3D_ACTIVE_NT != 0>(a, q, ((int64_t)n * H + (H - 1 - yo)) * W + (W - 1 - xo));
+      }
     } else {
       if (wave_ok) write_subtile_fill_patch<Queue, KT, IN_REGS>(a, q, true, n, sy0, sx0, y_end, x_end, lane, pix_ok, yi, xi);
     }
@@ -681,6 +692,57 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
     a.timeline[3 * (size_t)blockIdx.x + 2] = (unsigned long long)count;
   }
 #endif
+}
+
+// ---- concurrent background fill (-DP3D_CONCURRENT_FILL=1) -----------------------------------------------------------
+// The tiles with faces are VALU-bound, the background tiles are pure stores; inside one launch they do not overlap,
+// because a workgroup that only stores still occupies a full slot of the fine kernel (256 threads x 120 registers; the
+// chip holds 1024 of them).  With the fine kernel at <= 120 registers, four of its workgroups per CU leave 32 registers
+// per SIMD lane and ~45 KB of LDS free: a second, tiny kernel on a side stream walks the same tile map, returns at once
+// for tiles with faces and fills the background tiles with one wave each, while the fine kernel (which now returns at
+// once for background tiles) keeps all its slots for tiles with faces.  The fill workgroups ask for 40 KB of LDS they
+// never touch: at most one of them fits beside the fine kernel's workgroups on a CU, so they cannot crowd those out.
+#ifndef P3D_CONCURRENT_FILL
+#define P3D_CONCURRENT_FILL 0
+#endif
+constexpr size_t kFillLimiterLds = 40 * 1024;
+
+__global__ __launch_bounds__(kWave) void mesh_fill_background_kernel(MeshArgs a) {
+  TileCoord tc;
+  if (!tile_of_block(a.tm, blockIdx.x, &tc)) return;
+  const int y_end = min(a.H, (tc.by + 1) * a.tm.bin_size);
+  const int x_end = min(a.W, (tc.bx + 1) * a.tm.bin_size);
+  const int ty0 = tc.by * a.tm.bin_size + tc.ty * kTile;
+  const int tx0 = tc.bx * a.tm.bin_size + tc.tx * kTile;
+  if (ty0 >= y_end || tx0 >= x_end) return;
+  const int64_t row = ((int64_t)tc.n * a.tm.BH + tc.by) * a.tm.BW + tc.bx;
+  if (a.csr.total[row] > 0) return;  // the fine kernel's tile
+  fill_tile_background<kWave, false>(a, tc.n, ty0, tx0, y_end, x_end, (int)threadIdx.x);
+}
+
+// One side stream (lowest priority: the fine kernel's workgroups are placed first) and a fork / join event pair per
+// device, created on first use.  The mutex covers a whole fork .. join sequence: the events are shared.
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool ok = false, tried = false;
+};
+std::mutex g_side_mutex;
+SideStream g_side[64];
+
+SideStream* side_stream_locked() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  SideStream& s = g_side[dev];
+  if (!s.tried) {
+    s.tried = true;
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    s.ok = hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, P3D_CONCURRENT_FILL == 2 ? greatest : least) == hipSuccess &&
+           hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess;
+  }
+  return s.ok ? &s : nullptr;
 }
 
 // The instantiations one (Queue, K) pair can run as: split (few tiles), compile-time persp & clip, or plain.
@@ -759,6 +821,20 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
   if (P3D_DBG(a) & 1024) split = false;
   if (P3D_DBG(a) & 131072) split = BINNED;
 #endif
+  // concurrent fill: K % 4 == 0 (fill_tile_background's 16-byte pieces), not the 12-entry queue (168 registers x 3 waves
+  // leave no room beside it), not the split kernel (small launches: nothing to overlap)
+  std::unique_lock<std::mutex> side_lock(g_side_mutex, std::defer_lock);
+  SideStream* side = nullptr;
+  if (P3D_CONCURRENT_FILL && BINNED && !split && (K & 3) == 0 && K != 12) {
+    side_lock.lock();
+    side = side_stream_locked();
+    if (side && hipEventRecord(side->fork, stream) == hipSuccess && hipStreamWaitEvent(side->stream, side->fork, 0) == hipSuccess)
+      a.skip_background = 1;
+    else
+      side = nullptr;
+    // mode 2 (experiment): highest priority and launched before the fine kernel
+    if (side && P3D_CONCURRENT_FILL == 2) mesh_fill_background_kernel<<<grid, kWave, kFillLimiterLds, side->stream>>>(a);
+  }
 #define P3D_LAUNCH_FINE(KT_, REGS_, EXACT_, Q_) launch_fine_variant<Q_, KT_, REGS_, BINNED, EXACT_>(a, grid, split, dyn_lds, stream)
 #define P3D_LAUNCH_FINE_W(KT_, WAVES_, Q_) mesh_raster_kernel<Q_, KT_, true, BINNED, false, WAVES_><<<grid, kStage, 0, stream>>>(a)
   if (K == 1)
@@ -783,6 +859,12 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
     P3D_LAUNCH_FINE(P3D_MAX_K, false, false, TopKMem<P3D_MAX_K P3D_COMMA kMeshPayload>);
 #undef P3D_LAUNCH_FINE
 #undef P3D_LAUNCH_FINE_W
+  if (side) {
+    // after the fine kernel, so that its workgroups take their slots first; the caller's stream continues after both
+    if (P3D_CONCURRENT_FILL != 2) mesh_fill_background_kernel<<<grid, kWave, kFillLimiterLds, side->stream>>>(a);
+    if (hipEventRecord(side->join, side->stream) != hipSuccess || hipStreamWaitEvent(stream, side->join, 0) != hipSuccess)
+      return P3D_ERR_LAUNCH;
+  }
   return launch_status();
 }
 
