@@ -311,6 +311,22 @@ int p3d_sample_uv_backward(const float* grad_texels, const int64_t* pix_to_face,
                            int C, int align_corners, int padding_mode, int sampling_mode, float* grad_bary_coords,
                            float* grad_face_uvs, float* grad_maps, p3d_stream_t stream);
 
+/* replaces the maps_ids branch of TexturesUV.sample_textures (pytorch3d/renderer/mesh/textures.py:1270-1313, several
+ * texture maps per mesh): maps (N,M,Hm,Wm,C) with M >= 2; maps_ids = the flattened maps_ids_padded (L entries), indexed
+ * by the packed face index as the reference's gather does; background samples use face 0's map at uv = (0,0).  The map
+ * index is the z coordinate of the reference's 3-D grid_sample: "bilinear" blends neighbouring maps wherever the
+ * un-normalised z is not an integer (always with align_corners = 0) -- restated in csrc/uvm_sample.h.  Outputs as
+ * p3d_sample_uv_forward / _backward (grad_maps (N,M,Hm,Wm,C)); faces >= L or >= F read as zero. */
+int p3d_sample_uv_multi_forward(const int64_t* pix_to_face, const float* bary_coords, const float* face_uvs,
+                                const float* maps, const int64_t* maps_ids, int64_t L, int N, int H, int W, int K, int64_t F,
+                                int M, int Hm, int Wm, int C, int align_corners, int padding_mode, int sampling_mode,
+                                float* texels, p3d_stream_t stream);
+int p3d_sample_uv_multi_backward(const float* grad_texels, const int64_t* pix_to_face, const float* bary_coords,
+                                 const float* face_uvs, const float* maps, const int64_t* maps_ids, int64_t L, int N, int H,
+                                 int W, int K, int64_t F, int M, int Hm, int Wm, int C, int align_corners, int padding_mode,
+                                 int sampling_mode, float* grad_bary_coords, float* grad_face_uvs, float* grad_maps,
+                                 p3d_stream_t stream);
+
 /* replaces TexturesAtlas.sample_textures (pytorch3d/renderer/mesh/textures.py:565-612): the nearest-cell lookup of a
  * per-face R x R atlas (F,R,R,C) by the first two barycentrics of each of the P = N*H*W*K samples -> texels (P,C), fully
  * written (zero for pix_to_face < 0).  Cell arithmetic: csrc/atlas_cell.h.  Indices the reference fails on (torch raises

@@ -314,6 +314,36 @@ def sample_uv_backward(grad_texels, pix_to_face, bary, face_uvs, maps, align_cor
     return gb, gfu, gm
 
 
+def sample_uv_multi(pix_to_face, bary, face_uvs, maps, maps_ids, align_corners=True, padding_mode="border",
+                    sampling_mode="bilinear"):
+    """TexturesUV.sample_textures with maps_ids restated (oracle/p3d_oracle.c: orc_sample_uv_multi_forward).  maps
+    (N,M,Hm,Wm,C); maps_ids: maps_ids_padded (N,Fmax), flattened as the reference does."""
+    p2f, b, fu, mp, ids = _i64(pix_to_face), _f32(bary), _f32(face_uvs), _f32(maps), _i64(maps_ids).reshape(-1)
+    N, H, W, K = p2f.shape
+    _, M, Hm, Wm, C = mp.shape
+    out = torch.zeros((N, H, W, K, C), dtype=torch.float32)
+    lib().orc_sample_uv_multi_forward(_p(p2f), _p(b), _p(fu), _p(mp), _p(ids), ctypes.c_int64(ids.numel()), N,
+                                      ctypes.c_int64(H * W * K), M, Hm, Wm, C, int(align_corners), _PAD[padding_mode],
+                                      _SMODE[sampling_mode], _p(out))
+    return out
+
+
+def sample_uv_multi_backward(grad_texels, pix_to_face, bary, face_uvs, maps, maps_ids, align_corners=True,
+                             padding_mode="border", sampling_mode="bilinear"):
+    g, p2f, b, fu, mp = _f32(grad_texels), _i64(pix_to_face), _f32(bary), _f32(face_uvs), _f32(maps)
+    ids = _i64(maps_ids).reshape(-1)
+    N, H, W, K = p2f.shape
+    _, M, Hm, Wm, C = mp.shape
+    F = fu.shape[0]
+    gb = torch.zeros((N, H, W, K, 3), dtype=torch.float32)
+    gfu = torch.zeros((F, 3, 2), dtype=torch.float32)
+    gm = torch.zeros_like(mp)
+    lib().orc_sample_uv_multi_backward(_p(g), _p(p2f), _p(b), _p(fu), _p(mp), _p(ids), ctypes.c_int64(ids.numel()), N,
+                                       ctypes.c_int64(H * W * K), ctypes.c_int64(F), M, Hm, Wm, C, int(align_corners),
+                                       _PAD[padding_mode], _SMODE[sampling_mode], _p(gb), _p(gfu), _p(gm))
+    return gb, gfu, gm
+
+
 def sample_atlas(pix_to_face, bary, atlas):
     """TexturesAtlas.sample_textures restated (oracle/p3d_oracle.c: orc_sample_atlas_forward)."""
     p2f, b, at = _i64(pix_to_face), _f32(bary), _f32(atlas)

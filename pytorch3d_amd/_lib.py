@@ -85,6 +85,11 @@ _SIGNATURES = {
                                       c_int, c_int, c_int, c_ptr, c_ptr]),
     "p3d_sample_uv_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_i64, c_int, c_int,
                                        c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "p3d_sample_uv_multi_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_i64,
+                                            c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
+    "p3d_sample_uv_multi_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int,
+                                             c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr,
+                                             c_ptr]),
     "p3d_sample_atlas_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_ptr]),
     "p3d_sample_atlas_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_ptr]),
     "p3d_hard_rgb_blend_forward": (c_int, [c_ptr, c_ptr, ctypes.POINTER(c_f32), c_i64, c_int, c_ptr, c_ptr]),

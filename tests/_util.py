@@ -150,7 +150,8 @@ def hostgeom():
         so = os.path.join(d, "libhostgeom.so")
         srcs = [os.path.join(d, "hostgeom.cpp"), os.path.join(ROOT, "pytorch3d_amd", "csrc", "p3d_geom.h"),
                 os.path.join(ROOT, "pytorch3d_amd", "csrc", "topk.h"),
-                os.path.join(ROOT, "pytorch3d_amd", "csrc", "atlas_cell.h")]
+                os.path.join(ROOT, "pytorch3d_amd", "csrc", "atlas_cell.h"),
+                os.path.join(ROOT, "pytorch3d_amd", "csrc", "uvm_sample.h")]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off",
                                    "-Wno-unknown-pragmas", srcs[0], "-o", so])

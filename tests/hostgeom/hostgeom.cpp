@@ -10,6 +10,7 @@
 #include "../../pytorch3d_amd/csrc/atlas_cell.h"
 #include "../../pytorch3d_amd/csrc/p3d_geom.h"
 #include "../../pytorch3d_amd/csrc/topk.h"
+#include "../../pytorch3d_amd/csrc/uvm_sample.h"
 
 using namespace p3d;
 
@@ -185,5 +186,65 @@ extern "C" void hg_atlas_cells(const float* bary, int64_t P, int R, int64_t* cel
   for (int64_t p = 0; p < P; ++p) {
     int row, col;
     cells[p] = atlas_cell(bary[p * 3], bary[p * 3 + 1], R, &row, &col) ? (int64_t)row * R + col : -1;
+  }
+}
+
+// Multi-map UV sampling: the per-sample code of texture_multi.hip (uvm_sample.h) in a plain loop, with the kernels'
+// sample set-up (background -> face 0's map at uv (0,0); faces beyond L or F read as zero) and a plain add in place of
+// the atomics.  gmaps / gfuv are accumulated in float, in sample order.
+struct PlainAdd {
+  void operator()(float* dst, float v) const { *dst += v; }
+};
+
+extern "C" void hg_uvm(const int64_t* p2f, const float* bary, const float* fuv, const float* maps, const int64_t* ids,
+                       int64_t L, int64_t F, int N, int64_t HWK, int M, int Hm, int Wm, int C, int align, int border,
+                       int nearest, const float* gtex, float* texels, float* gbary, float* gfuv, float* gmaps) {
+  uvm::Volume v;
+  v.M = M;
+  v.Hm = Hm;
+  v.Wm = Wm;
+  v.C = C;
+  v.align = align != 0;
+  v.border = border != 0;
+  v.nearest = nearest != 0;
+  const int64_t per = (int64_t)M * Hm * Wm * C;
+  for (int n = 0; n < N; ++n) {
+    const float* vol = maps + n * per;
+    float* gvol = gmaps ? gmaps + n * per : nullptr;
+    for (int64_t i = 0; i < HWK; ++i) {
+      const int64_t p = (int64_t)n * HWK + i;
+      const int64_t f = p2f[p];
+      float u = 0.0f, vv = 0.0f;
+      const bool has_uv = f >= 0 && f < F;
+      if (has_uv) {
+        const float* b = bary + p * 3;
+        const float* r = fuv + f * 6;
+        u = (b[0] * r[0] + b[1] * r[2]) + b[2] * r[4];
+        vv = (b[0] * r[1] + b[1] * r[3]) + b[2] * r[5];
+      }
+      const int64_t fi = f < 0 ? 0 : f;
+      const bool valid = fi < L && (f < 0 || f < F);
+      if (texels)
+        for (int ch = 0; ch < C; ++ch) texels[p * C + ch] = 0.0f;
+      if (gbary)
+        for (int j = 0; j < 3; ++j) gbary[p * 3 + j] = 0.0f;
+      if (!valid) continue;
+      const uvm::Coords c = uvm::coords_of(v, u, vv, ids[fi]);
+      const uvm::Footprint fp = uvm::footprint_of(v, c);
+      if (texels) uvm::sample_forward(v, vol, fp, texels + p * C);
+      if (gtex) {
+        float du, dv;
+        uvm::sample_backward(v, vol, gvol, fp, c, gtex + p * C, PlainAdd(), &du, &dv);
+        if (f >= 0 && !v.nearest) {
+          const float* b = bary + p * 3;
+          const float* r = fuv + f * 6;
+          for (int j = 0; j < 3; ++j) {
+            gfuv[f * 6 + 2 * j] += b[j] * du;
+            gfuv[f * 6 + 2 * j + 1] += b[j] * dv;
+            gbary[p * 3 + j] = r[2 * j] * du + r[2 * j + 1] * dv;
+          }
+        }
+      }
+    }
   }
 }
