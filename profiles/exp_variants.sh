@@ -1,0 +1,44 @@
+#!/bin/bash
+# Build-flag experiments of the fine rasterizer, prepared at the end of round 2 (no GPU time was left to measure them):
+#   -DP3D_QUEUE_PAIRS=1   K = 4 / 8 queues in 64-bit register pairs, insertion by v_pk_mov_b32 under the lane mask
+#                         (csrc/topk.h: TopKPairs; inner loop of the K = 8 kernel 278 -> 233 VALU instructions)
+#   -DP3D_GEOM_PACKED=1   the (x, y) arithmetic of the per-(pixel, face) test on two-float vectors
+#                         (csrc/p3d_geom.h: face_hit_rec_pk; 278 -> 251, both together 206)
+# Both are bit-exact by construction; the host builds of the same code are checked in tests/test_cpu_abi_and_host.py.
+#
+# 1. HERE (hipcc cross-compiles):      bash profiles/exp_variants.sh build
+# 2. on the GPU box through gpurun:    bash profiles/exp_variants.sh run     (writes gpurun_out/exp/*.json, *.txt)
+set -u
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+cd "$ROOT"
+declare -A FLAGS=( [pairs]="-DP3D_QUEUE_PAIRS=1" [packed]="-DP3D_GEOM_PACKED=1" [both]="-DP3D_QUEUE_PAIRS=1 -DP3D_GEOM_PACKED=1" )
+case "${1:-}" in
+  build)
+    for v in pairs packed both; do
+      P3D_LIB_PATH=$ROOT/pytorch3d_amd/libp3d_$v.so P3D_EXTRA_FLAGS="${FLAGS[$v]}" python -m pytorch3d_amd.build > /dev/null || exit 1
+      echo "built libp3d_$v.so (${FLAGS[$v]})"
+    done ;;
+  run)
+    mkdir -p gpurun_out/exp
+    B="python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-other-configs"
+    $B > gpurun_out/exp/bench_product.json 2> gpurun_out/exp/bench_product.err
+    for v in pairs packed both; do
+      export P3D_LIB_PATH=$ROOT/pytorch3d_amd/libp3d_$v.so P3D_EXTRA_FLAGS="${FLAGS[$v]}"
+      $B > gpurun_out/exp/bench_$v.json 2> gpurun_out/exp/bench_$v.err
+      # parity of the variant: the mesh suite (oracle, fixtures, large images) and the device-vs-device comparison
+      timeout 300 python -m pytest tests/test_gpu_meshes.py tests/test_gpu_vs_reference_device_kernels.py -x -q > gpurun_out/exp/tests_$v.txt 2>&1
+      tail -2 gpurun_out/exp/tests_$v.txt
+      unset P3D_LIB_PATH P3D_EXTRA_FLAGS
+    done
+    python - <<'PY'
+import json
+for t in ("product", "pairs", "packed", "both"):
+    try:
+        j = json.loads(open("gpurun_out/exp/bench_%s.json" % t).read().strip().splitlines()[-1])
+        print(t, round(j["value"]), "Mpix/s", j["ms_per_step"], "ms/step", {k: v for k, v in j["kernels_ms"].items() if k.startswith("mesh")})
+    except Exception as e:
+        print(t, "ERR", e)
+PY
+    ;;
+  *) echo "usage: $0 build|run"; exit 2 ;;
+esac

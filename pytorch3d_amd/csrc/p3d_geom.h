@@ -358,6 +358,87 @@ P3D_HD bool face_hit_rec(const FaceRec& r, f2 p, float blur_radius, bool perspec
 }
 
 // ---------------------------------------------------------------------------
+// face_hit_rec with the (x, y) arithmetic written on two-float vectors (-DP3D_GEOM_PACKED=1, an experiment: the fine
+// rasterizer is bound by VALU issue, and gfx950 executes v_pk_mul / v_pk_add / v_pk_fma on two floats per lane at the
+// rate of one scalar instruction).  Every component goes through the same operations in the same order as in
+// face_hit_rec -- a packed multiply or add is the two scalar ones -- so the results are the same bits; the host build
+// (tests/hostgeom) checks that.  hipcc's own SLP pairing of the scalar code lost 3.5 % to operand shuffles
+// (-fno-slp-vectorize in build.py); here the pairs are the natural ones: (x, y) of a difference vector.
+// ---------------------------------------------------------------------------
+#ifndef P3D_GEOM_PACKED
+#define P3D_GEOM_PACKED 0
+#endif
+#if defined(__clang__)
+typedef float v2f __attribute__((ext_vector_type(2)));
+#else
+typedef float v2f __attribute__((vector_size(8)));
+#endif
+
+P3D_HD v2f mkv(float x, float y) {
+  v2f r;
+  r[0] = x;
+  r[1] = y;
+  return r;
+}
+P3D_HD v2f swap2(v2f a) { return mkv(a[1], a[0]); }
+
+// seg_dist2_rec on vectors: pa = p - a, pb = p - b (shared with the edge functions), ba = b - a
+P3D_HD float seg_dist2_pk(v2f p, v2f a, v2f pa, v2f pb, v2f ba, double rd_l2) {
+  const v2f m = ba * pa;                      // bax * (p.x - a.x), bay * (p.y - a.y)
+  float t = exact_div(m[0] + m[1], rd_l2);
+  const v2f e2 = pb * pb;                     // ex * ex, ey * ey
+  const float d_point = e2[0] + e2[1];
+  t = sat01(t);
+  const v2f tt = mkv(t, t);
+  const v2f d = (a + tt * ba) - p;            // (a.x + t * bax) - p.x, (a.y + t * bay) - p.y
+  const v2f d2 = d * d;
+  const float d_seg = d2[0] + d2[1];
+  return (rd_l2 < 0.0) ? d_point : d_seg;
+}
+
+P3D_HD bool face_hit_rec_pk(const FaceRec& r, f2 pp, float blur_radius, bool perspective_correct, bool clip_bary,
+                            FaceHit* out) {
+  const v2f p = mkv(pp.x, pp.y);
+  const v2f a = mkv(r.v0.x, r.v0.y), b = mkv(r.v1.x, r.v1.y), c = mkv(r.v2.x, r.v2.y);
+  const v2f pa = p - a, pb = p - b, pc = p - c;
+  const v2f ab = b - a, bc = c - b, ca = a - c, ac = c - a;
+  // edge_fn(p, u, v) = (p.x - u.x) * (v.y - u.y) - (p.y - u.y) * (v.x - u.x)
+  const v2f m0 = pb * swap2(bc), m1 = pc * swap2(ca), m2 = pa * swap2(ab);
+  const f3 bw = mk3(exact_div(m0[0] - m0[1], r.rd_area), exact_div(m1[0] - m1[1], r.rd_area),
+                    exact_div(m2[0] - m2[1], r.rd_area));
+  f3 bp = bw;
+  if (perspective_correct) {
+    const float t0 = bw.x * r.v1.z * r.v2.z;
+    const float t1 = r.v0.z * bw.y * r.v2.z;
+    const float t2 = r.v0.z * r.v1.z * bw.z;
+    const float denom = fmaxf(t0 + t1 + t2, (float)P3D_KEPS);
+    const double rd = r.wide ? recip_for_div_wide(denom) : recip_for_div(denom);
+    bp = mk3(exact_div(t0, rd), exact_div(t1, rd), exact_div(t2, rd));
+  }
+  f3 bcl = bp;
+  if (clip_bary) {
+    const float w0 = bp.x > 0.0f ? bp.x : 0.0f;
+    const float w1 = bp.y > 0.0f ? bp.y : 0.0f;
+    const float w2 = bp.z > 0.0f ? bp.z : 0.0f;
+    float s = w0 + w1 + w2;
+    s = fmaxf(s, 1e-5f);
+    const double rd = r.wide ? recip_for_div_wide(s) : recip_for_div(s);
+    bcl = mk3(exact_div(w0, rd), exact_div(w1, rd), exact_div(w2, rd));
+  }
+  const float pz = bcl.x * r.v0.z + bcl.y * r.v1.z + bcl.z * r.v2.z;
+  const float e01 = seg_dist2_pk(p, a, pa, pb, ab, r.rd_l01);
+  const float e02 = seg_dist2_pk(p, a, pa, pc, ac, r.rd_l02);
+  const float e12 = seg_dist2_pk(p, b, pb, pc, bc, r.rd_l12);
+  const float dist = fminf(fminf(e01, e02), e12);
+  const bool inside = (bp.x > 0.0f) & (bp.y > 0.0f) & (bp.z > 0.0f);
+  const bool hit = !(pz < 0.0f) & (inside | !(dist >= blur_radius));
+  out->z = pz;
+  out->dist = inside ? -dist : dist;
+  out->bary = bcl;
+  return hit;
+}
+
+// ---------------------------------------------------------------------------
 // Conservative rectangle-vs-face reject for the fine rasterizers' culling stages: true only if NO pixel centre
 // in [x0, x1] x [y0, y1] can be hit by the face, i.e. every point of the rectangle is outside the triangle AND
 // farther than sqrt(blur) from it.  Two sufficient conditions: (1) the rectangle is farther than r from the

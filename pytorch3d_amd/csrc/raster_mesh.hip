@@ -74,6 +74,9 @@ struct MeshArgs {
 // P3D_BG_FILL_MODE (ablation builds): how background tiles are stored.  0 every lane its own pixel's rows, 1 cooperative
 // fill in memory order (fill_tile_background), 2 the same by one wave of the workgroup, 3 / 4 = 1 / 0 with non-temporal
 // stores.
+#ifndef P3D_QUEUE_PAIRS
+#define P3D_QUEUE_PAIRS 0  // 1: the exact K = 4 and K = 8 kernels keep their queue in register pairs (topk.h: TopKPairs), an experiment
+#endif
 #ifndef P3D_BG_FILL_MODE
 #define P3D_BG_FILL_MODE 1
 #endif
@@ -123,12 +126,12 @@ __device__ __forceinline__ void write_pixel(const MeshArgs& a, const Queue& q, i
 #pragma unroll
   for (int k = 0; k < KT; ++k) {
     const bool ok = q.valid(k);
-    iv[k] = ok ? (long long)q.idx[k] : -1ll;
-    zv[k] = ok ? q.z[k] : -1.0f;
-    dv[k] = ok ? q.pl[0][k] : -1.0f;
-    bv[3 * k + 0] = ok ? q.pl[1][k] : -1.0f;
-    bv[3 * k + 1] = ok ? q.pl[2][k] : -1.0f;
-    bv[3 * k + 2] = ok ? q.pl[3][k] : -1.0f;
+    iv[k] = ok ? (long long)q.ix(k) : -1ll;
+    zv[k] = ok ? q.zf(k) : -1.0f;
+    dv[k] = ok ? q.pay(0, k) : -1.0f;
+    bv[3 * k + 0] = ok ? q.pay(1, k) : -1.0f;
+    bv[3 * k + 1] = ok ? q.pay(2, k) : -1.0f;
+    bv[3 * k + 2] = ok ? q.pay(3, k) : -1.0f;
   }
   if constexpr (KT % 4 == 0) {
 #pragma unroll
@@ -225,23 +228,23 @@ __device__ __forceinline__ void write_subtile_fill_patch(const MeshArgs& a, cons
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
         if (k < K && q.valid(k)) {
-          a.p2f[base + k] = (int64_t)q.idx[k];
-          a.zbuf[base + k] = q.z[k];
-          a.dists[base + k] = q.pl[0][k];
-          a.bary[(base + k) * 3 + 0] = q.pl[1][k];
-          a.bary[(base + k) * 3 + 1] = q.pl[2][k];
-          a.bary[(base + k) * 3 + 2] = q.pl[3][k];
+          a.p2f[base + k] = (int64_t)q.ix(k);
+          a.zbuf[base + k] = q.zf(k);
+          a.dists[base + k] = q.pay(0, k);
+          a.bary[(base + k) * 3 + 0] = q.pay(1, k);
+          a.bary[(base + k) * 3 + 1] = q.pay(2, k);
+          a.bary[(base + k) * 3 + 2] = q.pay(3, k);
         }
       }
     } else {
       for (int k = 0; k < K; ++k) {
         if (!q.valid(k)) break;
-        a.p2f[base + k] = (int64_t)q.idx[k];
-        a.zbuf[base + k] = q.z[k];
-        a.dists[base + k] = q.pl[0][k];
-        a.bary[(base + k) * 3 + 0] = q.pl[1][k];
-        a.bary[(base + k) * 3 + 1] = q.pl[2][k];
-        a.bary[(base + k) * 3 + 2] = q.pl[3][k];
+        a.p2f[base + k] = (int64_t)q.ix(k);
+        a.zbuf[base + k] = q.zf(k);
+        a.dists[base + k] = q.pay(0, k);
+        a.bary[(base + k) * 3 + 0] = q.pay(1, k);
+        a.bary[(base + k) * 3 + 1] = q.pay(2, k);
+        a.bary[(base + k) * 3 + 2] = q.pay(3, k);
       }
     }
   }
@@ -313,7 +316,11 @@ __device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue&
         fr.rd_l12 = d1.y;
         if constexpr (PC && !GENERAL) {
           fr.wide = false;  // wide faces make their chunk general (stage_chunk)
+#if P3D_GEOM_PACKED
+          hit = face_hit_rec_pk(fr, p, a.blur, true, true, &h);
+#else
           hit = face_hit_rec(fr, p, a.blur, true, true, &h);
+#endif
         } else {
           fr.wide = __float_as_int(r2.w) != 0;
           hit = face_hit_rec(fr, p, a.blur, persp, clip, &h);
@@ -469,10 +476,10 @@ template <typename Queue, int KT>
 __device__ __forceinline__ void merge_dump(const Queue& q, float* slab, int lane) {
 #pragma unroll
   for (int k = 0; k < KT; ++k) {
-    slab[(0 * KT + k) * kWave + lane] = q.z[k];
-    slab[(1 * KT + k) * kWave + lane] = __int_as_float(q.idx[k]);
+    slab[(0 * KT + k) * kWave + lane] = q.zf(k);
+    slab[(1 * KT + k) * kWave + lane] = __int_as_float(q.ix(k));
 #pragma unroll
-    for (int pp = 0; pp < kMeshPayload; ++pp) slab[((2 + pp) * KT + k) * kWave + lane] = q.pl[pp][k];
+    for (int pp = 0; pp < kMeshPayload; ++pp) slab[((2 + pp) * KT + k) * kWave + lane] = q.pay(pp, k);
   }
 }
 
@@ -844,11 +851,19 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
   else if (K == 3)
     P3D_LAUNCH_FINE(4, true, false, TopKReg<4 P3D_COMMA kMeshPayload>);
   else if (K == 4)
+#if P3D_QUEUE_PAIRS
+    P3D_LAUNCH_FINE(4, true, true, TopKPairs<4>);
+#else
     P3D_LAUNCH_FINE(4, true, true, TopKReg<4 P3D_COMMA kMeshPayload>);
+#endif
   else if (K < 8)
     P3D_LAUNCH_FINE(8, true, false, TopKReg<8 P3D_COMMA kMeshPayload>);
   else if (K == 8)
+#if P3D_QUEUE_PAIRS
+    P3D_LAUNCH_FINE(8, true, true, TopKPairs<8>);
+#else
     P3D_LAUNCH_FINE(8, true, true, TopKReg<8 P3D_COMMA kMeshPayload>);
+#endif
   // 9..12: the queue (6 registers per entry: 72) still fits the register file at 3 waves per SIMD; from 16 entries on
   // the allocator spills hundreds of registers, and the queue in private memory is the better choice
   else if (K <= 12)

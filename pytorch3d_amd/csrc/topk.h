@@ -144,6 +144,11 @@ struct TopKReg {
   }
 
   P3D_HDM bool valid(int k) const { return idx[k] != kEmptyIdx; }
+
+  // entry accessors (the kernels read entries through these, so that queue layouts can differ: see TopKPairs)
+  P3D_HDM float zf(int k) const { return z[k]; }
+  P3D_HDM int ix(int k) const { return idx[k]; }
+  P3D_HDM float pay(int p, int k) const { return pl[p][k]; }
 };
 
 template <int KMAX, int NP>
@@ -196,6 +201,189 @@ struct TopKMem {
   }
 
   P3D_HDM bool valid(int k) const { return k < n; }
+
+  P3D_HDM float zf(int k) const { return z[k]; }
+  P3D_HDM int ix(int k) const { return idx[k]; }
+  P3D_HDM float pay(int p, int k) const { return pl[p][k]; }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// TopKPairs -- TopKReg<KT, 4> with every entry held as three 64-bit register PAIRS (z | idx, payload 0 | 1, payload
+// 2 | 3) and the sorted insertion done with v_pk_mov_b32 under the lane mask instead of v_cndmask_b32 (an experiment,
+// -DP3D_QUEUE_PAIRS=1: the fine rasterizer is bound by VALU issue and the 8-entry insertion network is 97 of the 278
+// VALU instructions of its inner loop).  lt[k] = "the candidate sorts before entry k" is monotone in k, so top-down
+//     lanes with lt[k]:    entry k <- candidate            (3 pair moves)
+//     lanes with lt[k-1]:  entry k <- entry k-1            (3 pair moves; lt[k-1] implies lt[k])
+// leaves entry k = lt[k-1] ? old k-1 : (lt[k] ? candidate : itself) -- TopKReg::insert's result -- in 6 instructions
+// per entry instead of 12.  Same interface and semantics as TopKReg<KT, 4> for K == KT (the exact-K kernels).  On the
+// host the two masked moves are plain ifs, so tests/hostgeom can check the scheme against TopKReg.
+// ---------------------------------------------------------------------------------------------------------------
+#if defined(__clang__)
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#else
+typedef unsigned int u32x2 __attribute__((vector_size(8)));
+#endif
+
+P3D_HDM unsigned f32_bits(float v) {
+  union {
+    float f;
+    unsigned u;
+  } c;
+  c.f = v;
+  return c.u;
+}
+P3D_HDM float bits_f32(unsigned v) {
+  union {
+    float f;
+    unsigned u;
+  } c;
+  c.u = v;
+  return c.f;
+}
+P3D_HDM u32x2 mk_pair(unsigned lo, unsigned hi) {
+  u32x2 r;
+  r[0] = lo;
+  r[1] = hi;
+  return r;
+}
+
+template <int KT>
+struct TopKPairs {
+  u32x2 zi[KT];  // z bits, idx
+  u32x2 pa[KT];  // payload 0, 1
+  u32x2 pb[KT];  // payload 2, 3
+  float kz;
+  int ki;
+
+  P3D_HDM void init() {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      zi[k] = mk_pair(f32_bits(INFINITY), (unsigned)kEmptyIdx);
+      pa[k] = mk_pair(f32_bits(-1.0f), f32_bits(-1.0f));
+      pb[k] = pa[k];
+    }
+    kz = INFINITY;
+    ki = kEmptyIdx;
+  }
+
+  P3D_HDM float zf(int k) const { return bits_f32(zi[k][0]); }
+  P3D_HDM int ix(int k) const { return (int)zi[k][1]; }
+  P3D_HDM float pay(int p, int k) const { return bits_f32(p == 0 ? pa[k][0] : (p == 1 ? pa[k][1] : (p == 2 ? pb[k][0] : pb[k][1]))); }
+  P3D_HDM bool valid(int k) const { return ix(k) != kEmptyIdx; }
+  P3D_HDM bool admits(int /*K*/, float cz, int cidx) const { return (cz < kz) | ((cz == kz) & (cidx < ki)); }
+  P3D_HDM float kth_z(int /*K*/) const { return kz; }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef unsigned long long LaneMask;
+  // three compares straight into lane masks, combined on the scalar unit (a ballot of the combined bool goes through
+  // a v_cndmask + v_cmp pair)
+  __device__ __forceinline__ LaneMask sorts_before(float cz, int cidx, int k) const {
+    const LaneMask lt = __builtin_amdgcn_ballot_w64(cz < zf(k));
+    const LaneMask eq = __builtin_amdgcn_ballot_w64(cz == zf(k));
+    const LaneMask il = __builtin_amdgcn_ballot_w64(cidx < ix(k));
+    return lt | (eq & il);
+  }
+  // entry k <- candidate where m, then entry k <- entry k-1 where m1
+  __device__ __forceinline__ void place_and_shift(int k, LaneMask m, LaneMask m1, u32x2 czi, u32x2 cpa, u32x2 cpb) {
+    LaneMask saved;
+    asm volatile(
+        "s_and_saveexec_b64 %[sv], %[m]\n\t"
+        "v_pk_mov_b32 %[z], %[cz], %[cz] op_sel:[0,1]\n\t"
+        "v_pk_mov_b32 %[a], %[ca], %[ca] op_sel:[0,1]\n\t"
+        "v_pk_mov_b32 %[b], %[cb], %[cb] op_sel:[0,1]\n\t"
+        "s_and_b64 exec, exec, %[m1]\n\t"
+        "v_pk_mov_b32 %[z], %[pz], %[pz] op_sel:[0,1]\n\t"
+        "v_pk_mov_b32 %[a], %[pa_], %[pa_] op_sel:[0,1]\n\t"
+        "v_pk_mov_b32 %[b], %[pb_], %[pb_] op_sel:[0,1]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [z] "+v"(zi[k]), [a] "+v"(pa[k]), [b] "+v"(pb[k]), [sv] "=&s"(saved)
+        : [m] "s"(m), [m1] "s"(m1), [cz] "v"(czi), [ca] "v"(cpa), [cb] "v"(cpb), [pz] "v"(zi[k - 1]), [pa_] "v"(pa[k - 1]),
+          [pb_] "v"(pb[k - 1]));
+  }
+  __device__ __forceinline__ void place(int k, LaneMask m, u32x2 czi, u32x2 cpa, u32x2 cpb) {
+    LaneMask saved;
+    asm volatile(
+        "s_and_saveexec_b64 %[sv], %[m]\n\t"
+        "v_pk_mov_b32 %[z], %[cz], %[cz] op_sel:[0,1]\n\t"
+        "v_pk_mov_b32 %[a], %[ca], %[ca] op_sel:[0,1]\n\t"
+        "v_pk_mov_b32 %[b], %[cb], %[cb] op_sel:[0,1]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [z] "+v"(zi[k]), [a] "+v"(pa[k]), [b] "+v"(pb[k]), [sv] "=&s"(saved)
+        : [m] "s"(m), [cz] "v"(czi), [ca] "v"(cpa), [cb] "v"(cpb));
+  }
+#else
+  typedef bool LaneMask;
+  LaneMask sorts_before(float cz, int cidx, int k) const { return (cz < zf(k)) | ((cz == zf(k)) & (cidx < ix(k))); }
+  void place_and_shift(int k, LaneMask m, LaneMask m1, u32x2 czi, u32x2 cpa, u32x2 cpb) {
+    if (m) {
+      zi[k] = czi;
+      pa[k] = cpa;
+      pb[k] = cpb;
+    }
+    if (m1) {
+      zi[k] = zi[k - 1];
+      pa[k] = pa[k - 1];
+      pb[k] = pb[k - 1];
+    }
+  }
+  void place(int k, LaneMask m, u32x2 czi, u32x2 cpa, u32x2 cpb) {
+    if (m) {
+      zi[k] = czi;
+      pa[k] = cpa;
+      pb[k] = cpb;
+    }
+  }
+#endif
+
+  // K == KT only (exact-K kernels)
+  P3D_HDM void insert(int /*K*/, float cz, int cidx, const float (&cpl)[4]) {
+    const u32x2 czi = mk_pair(f32_bits(cz), (unsigned)cidx);
+    const u32x2 cpa = mk_pair(f32_bits(cpl[0]), f32_bits(cpl[1]));
+    const u32x2 cpb = mk_pair(f32_bits(cpl[2]), f32_bits(cpl[3]));
+    LaneMask mk = sorts_before(cz, cidx, KT - 1);
+#pragma unroll
+    for (int k = KT - 1; k >= 1; --k) {
+      const LaneMask mk1 = sorts_before(cz, cidx, k - 1);  // reads entry k-1 before it can change
+      place_and_shift(k, mk, mk1, czi, cpa, cpb);
+      mk = mk1;
+    }
+    place(0, mk, czi, cpa, cpb);
+    kz = zf(KT - 1);
+    ki = ix(KT - 1);
+  }
+
+  P3D_HDM int find(int want) const {
+    int at = -1;
+#pragma unroll
+    for (int k = KT - 1; k >= 0; --k) {
+      if (ix(k) == want) at = k;
+    }
+    return at;
+  }
+
+  P3D_HDM float payload_at(int p, int at) const {
+    float v = 0.0f;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      if (k == at) v = pay(p, k);
+    }
+    return v;
+  }
+
+  // Remove entry `at` (keeps order).
+  P3D_HDM void erase(int at) {
+#pragma unroll
+    for (int k = 0; k < KT - 1; ++k) {
+      if (k >= at) {
+        zi[k] = zi[k + 1];
+        pa[k] = pa[k + 1];
+        pb[k] = pb[k + 1];
+      }
+    }
+    zi[KT - 1] = mk_pair(f32_bits(INFINITY), (unsigned)kEmptyIdx);
+    kz = INFINITY;
+    ki = kEmptyIdx;
+  }
 };
 
 }  // namespace p3d

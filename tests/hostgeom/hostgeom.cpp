@@ -32,7 +32,8 @@ static void raster_pixel(const float* fv, const int64_t* nbr, int64_t f0, int64_
         continue;
       FaceRec fr;
       face_rec_make(v0, v1, v2, &fr);
-      if (!face_hit_rec(fr, p, blur, persp, clip, &h)) continue;
+      // rect[4] != 0: the packed-arithmetic form of the same test (p3d_geom.h: face_hit_rec_pk)
+      if (!(rect[4] != 0.0f ? face_hit_rec_pk(fr, p, blur, persp, clip, &h) : face_hit_rec(fr, p, blur, persp, clip, &h))) continue;
     } else if (!face_hit(v0, v1, v2, p, blur, persp, clip, &h)) {
       continue;
     }
@@ -77,7 +78,7 @@ extern "C" int hg_rasterize_meshes(const float* fv, const int64_t* first, const 
         const int64_t o = (((int64_t)n * H + yo) * W + xo) * K;
         const int64_t f0 = first[n], f1 = first[n] + count[n];
         // use_mem bit 1: the fast path, with the 8x8 pixel block around the pixel as the culling rectangle
-        float rect_v[4];
+        float rect_v[5];  // x0, x1, y0, y1, packed-arithmetic flag (use_mem bit 2)
         const float* rect = nullptr;
         if (use_mem & 2) {
           const int bx0 = xi & ~7, by0 = yi & ~7;
@@ -86,6 +87,7 @@ extern "C" int hg_rasterize_meshes(const float* fv, const int64_t* first, const 
           rect_v[1] = pix_to_ndc(bx1, W, H);
           rect_v[2] = pix_to_ndc(by0, H, W);
           rect_v[3] = pix_to_ndc(by1, H, W);
+          rect_v[4] = (use_mem & 4) ? 1.0f : 0.0f;
           rect = rect_v;
         }
         if (!(use_mem & 1) && K <= 8) {
@@ -247,4 +249,56 @@ extern "C" void hg_uvm(const int64_t* p2f, const float* bary, const float* fuv, 
       }
     }
   }
+}
+
+// TopKPairs<8> (the pair-register queue, masked moves as plain ifs on the host) against TopKReg<8, 4> on random
+// operation sequences: inserts gated by admits() as the kernels do, depth ties, repeated indices, find + erase.
+// Returns the number of states in which the two queues differ.
+extern "C" int64_t hg_queue_pairs_check(int64_t sequences, uint64_t seed) {
+  uint64_t s = seed * 0x9E3779B97F4A7C15ull + 7;
+  auto next = [&]() {
+    s ^= s << 13;
+    s ^= s >> 7;
+    s ^= s << 17;
+    return s;
+  };
+  int64_t bad = 0;
+  for (int64_t t = 0; t < sequences; ++t) {
+    TopKReg<8, 4> a;
+    TopKPairs<8> b;
+    a.init();
+    b.init();
+    const int ops = 4 + (int)(next() % 40);
+    const int zlevels = 1 + (int)(next() % 12);  // few distinct depths: many exact ties
+    for (int o = 0; o < ops; ++o) {
+      const uint64_t r = next();
+      const float z = (float)(r % zlevels) * 0.25f + ((r >> 8) % 5 == 0 ? 0.0f : 1e-3f * (float)((r >> 12) % 3));
+      const int idx = (int)((r >> 20) % 64);
+      const float pl[4] = {(float)(r >> 30 & 1023) * 0.5f - 100.0f, (float)(o), (float)(t & 255), -(float)idx};
+      if ((r >> 40) % 7 == 0) {
+        const int want = (int)((r >> 44) % 64);
+        const int fa = a.find(want), fb = b.find(want);
+        if (fa != fb) ++bad;
+        if (fa >= 0) {
+          if (a.payload_at(0, fa) != b.payload_at(0, fb)) ++bad;
+          a.erase(fa);
+          b.erase(fb);
+        }
+      } else {
+        const bool ad_a = a.admits(8, z, idx), ad_b = b.admits(8, z, idx);
+        if (ad_a != ad_b) ++bad;
+        if (ad_a) a.insert(8, z, idx, pl);
+        if (ad_b) b.insert(8, z, idx, pl);
+      }
+      if (a.kth_z(8) != b.kth_z(8) && !(a.kth_z(8) != a.kth_z(8))) ++bad;
+      for (int k = 0; k < 8; ++k) {
+        if (a.valid(k) != b.valid(k) || a.ix(k) != b.ix(k)) ++bad;
+        if (!a.valid(k)) continue;
+        if (a.zf(k) != b.zf(k)) ++bad;
+        for (int p = 0; p < 4; ++p)
+          if (a.pay(p, k) != b.pay(p, k)) ++bad;
+      }
+    }
+  }
+  return bad;
 }
