@@ -356,3 +356,21 @@ def test_pair_register_queue_scheme_matches_the_register_queue():
     hg.hg_queue_pairs_check.restype = ctypes.c_int64
     hg.hg_queue_pairs_check.argtypes = [ctypes.c_int64, ctypes.c_uint64]
     assert hg.hg_queue_pairs_check(200_000, 99) == 0
+
+
+def test_experiment_flags_of_the_fine_rasterizer_still_compile(tmp_path):
+    """The build-flag variants that profiles/exp_variants.sh and profiles/r02_concurrent_fill.txt refer to must keep
+    compiling for gfx950 (device code only, no link): they are measured on the GPU at the start of a round."""
+    import shutil
+    import subprocess
+
+    from pytorch3d_amd import build as B
+
+    hipcc = B._hipcc()
+    if shutil.which(hipcc) is None and not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(B.CSRC, "raster_mesh.hip")
+    cmd = [hipcc] + B.FLAGS + ["-DP3D_QUEUE_PAIRS=1", "-DP3D_GEOM_PACKED=1", "-DP3D_CONCURRENT_FILL=1", "-x", "hip",
+                               "--cuda-device-only", "-c", src, "-o", str(tmp_path / "variant.o")]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-2000:]
