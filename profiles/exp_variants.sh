@@ -4,6 +4,8 @@
 #                         (csrc/topk.h: TopKPairs; inner loop of the K = 8 kernel 278 -> 233 VALU instructions)
 #   -DP3D_GEOM_PACKED=1   the (x, y) arithmetic of the per-(pixel, face) test on two-float vectors
 #                         (csrc/p3d_geom.h: face_hit_rec_pk; 278 -> 251, both together 206)
+#   -DP3D_QUEUE_PAIRS=2   as 1, and the perspective + clip kernels order queue entries by ONE unsigned 64-bit compare of
+#                         (z bits, idx) instead of three 32-bit compares (their depths are never -0.0): 189 with packed
 # Both are bit-exact by construction; the host builds of the same code are checked in tests/test_cpu_abi_and_host.py.
 #
 # 1. HERE (hipcc cross-compiles):      bash profiles/exp_variants.sh build
@@ -11,10 +13,10 @@
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"
-declare -A FLAGS=( [pairs]="-DP3D_QUEUE_PAIRS=1" [packed]="-DP3D_GEOM_PACKED=1" [both]="-DP3D_QUEUE_PAIRS=1 -DP3D_GEOM_PACKED=1" )
+declare -A FLAGS=( [pairs]="-DP3D_QUEUE_PAIRS=1" [packed]="-DP3D_GEOM_PACKED=1" [both]="-DP3D_QUEUE_PAIRS=1 -DP3D_GEOM_PACKED=1" [key64]="-DP3D_QUEUE_PAIRS=2 -DP3D_GEOM_PACKED=1" )
 case "${1:-}" in
   build)
-    for v in pairs packed both; do
+    for v in pairs packed both key64; do
       P3D_LIB_PATH=$ROOT/pytorch3d_amd/libp3d_$v.so P3D_EXTRA_FLAGS="${FLAGS[$v]}" python -m pytorch3d_amd.build > /dev/null || exit 1
       echo "built libp3d_$v.so (${FLAGS[$v]})"
     done ;;
@@ -22,7 +24,7 @@ case "${1:-}" in
     mkdir -p gpurun_out/exp
     B="python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-other-configs"
     $B > gpurun_out/exp/bench_product.json 2> gpurun_out/exp/bench_product.err
-    for v in pairs packed both; do
+    for v in pairs packed both key64; do
       export P3D_LIB_PATH=$ROOT/pytorch3d_amd/libp3d_$v.so P3D_EXTRA_FLAGS="${FLAGS[$v]}"
       $B > gpurun_out/exp/bench_$v.json 2> gpurun_out/exp/bench_$v.err
       # parity of the variant: the mesh suite (oracle, fixtures, large images) and the device-vs-device comparison
@@ -32,7 +34,7 @@ case "${1:-}" in
     done
     python - <<'PY'
 import json
-for t in ("product", "pairs", "packed", "both"):
+for t in ("product", "pairs", "packed", "both", "key64"):
     try:
         j = json.loads(open("gpurun_out/exp/bench_%s.json" % t).read().strip().splitlines()[-1])
         print(t, round(j["value"]), "Mpix/s", j["ms_per_step"], "ms/step", {k: v for k, v in j["kernels_ms"].items() if k.startswith("mesh")})

@@ -75,7 +75,8 @@ struct MeshArgs {
 // fill in memory order (fill_tile_background), 2 the same by one wave of the workgroup, 3 / 4 = 1 / 0 with non-temporal
 // stores.
 #ifndef P3D_QUEUE_PAIRS
-#define P3D_QUEUE_PAIRS 0  // 1: the exact K = 4 and K = 8 kernels keep their queue in register pairs (topk.h: TopKPairs), an experiment
+#define P3D_QUEUE_PAIRS 0  // 1: the exact K = 4 and K = 8 kernels keep their queue in register pairs (topk.h: TopKPairs), an experiment;
+                           // 2: ... and the perspective + clip kernels order entries by one 64-bit key compare
 #endif
 #ifndef P3D_BG_FILL_MODE
 #define P3D_BG_FILL_MODE 1
@@ -763,7 +764,7 @@ void launch_fine_variant(const MeshArgs& a, unsigned grid, bool split, size_t dy
   }
   if constexpr (REGS && EXACT) {
     if (a.persp && a.clip) {
-      mesh_raster_kernel<Q, KT, REGS, BINNED, EXACT, P3D_FINE_WAVES_PER_SIMD, true><<<grid, kStage, dyn_lds, stream>>>(a);
+      mesh_raster_kernel<typename PcQueue<Q>::type, KT, REGS, BINNED, EXACT, P3D_FINE_WAVES_PER_SIMD, true><<<grid, kStage, dyn_lds, stream>>>(a);
       return;
     }
   }

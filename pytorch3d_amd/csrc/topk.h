@@ -247,18 +247,26 @@ P3D_HDM u32x2 mk_pair(unsigned lo, unsigned hi) {
   return r;
 }
 
-template <int KT>
+// KEY64 (-DP3D_QUEUE_PAIRS=2, kernels whose depths are never -0.0: perspective-correct + clipped barycentrics give
+// z = sum of products of non-negative numbers): the pair is laid out idx | z so that, as one unsigned 64-bit number, it
+// orders like (z, idx) for z >= +0 -- "sorts before" is then ONE 64-bit compare instead of three 32-bit ones.  NaN
+// depths compare above +inf (the empty entry) as bit patterns and are never admitted, as with the float compares.
+template <int KT, bool KEY64 = false>
 struct TopKPairs {
-  u32x2 zi[KT];  // z bits, idx
+  u32x2 zi[KT];  // z bits, idx (KEY64: idx, z bits)
   u32x2 pa[KT];  // payload 0, 1
   u32x2 pb[KT];  // payload 2, 3
   float kz;
   int ki;
+  static constexpr int kZ = KEY64 ? 1 : 0, kI = KEY64 ? 0 : 1;  // which half holds what
+
+  P3D_HDM static u32x2 mk_entry(float z, int idx) { return KEY64 ? mk_pair((unsigned)idx, f32_bits(z)) : mk_pair(f32_bits(z), (unsigned)idx); }
+  P3D_HDM static unsigned long long key_of(u32x2 e) { return ((unsigned long long)e[1] << 32) | (unsigned long long)e[0]; }
 
   P3D_HDM void init() {
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
-      zi[k] = mk_pair(f32_bits(INFINITY), (unsigned)kEmptyIdx);
+      zi[k] = mk_entry(INFINITY, kEmptyIdx);
       pa[k] = mk_pair(f32_bits(-1.0f), f32_bits(-1.0f));
       pb[k] = pa[k];
     }
@@ -266,11 +274,14 @@ struct TopKPairs {
     ki = kEmptyIdx;
   }
 
-  P3D_HDM float zf(int k) const { return bits_f32(zi[k][0]); }
-  P3D_HDM int ix(int k) const { return (int)zi[k][1]; }
+  P3D_HDM float zf(int k) const { return bits_f32(zi[k][kZ]); }
+  P3D_HDM int ix(int k) const { return (int)zi[k][kI]; }
   P3D_HDM float pay(int p, int k) const { return bits_f32(p == 0 ? pa[k][0] : (p == 1 ? pa[k][1] : (p == 2 ? pb[k][0] : pb[k][1]))); }
   P3D_HDM bool valid(int k) const { return ix(k) != kEmptyIdx; }
-  P3D_HDM bool admits(int /*K*/, float cz, int cidx) const { return (cz < kz) | ((cz == kz) & (cidx < ki)); }
+  P3D_HDM bool admits(int /*K*/, float cz, int cidx) const {
+    if (KEY64) return key_of(mk_entry(cz, cidx)) < key_of(mk_entry(kz, ki));
+    return (cz < kz) | ((cz == kz) & (cidx < ki));
+  }
   P3D_HDM float kth_z(int /*K*/) const { return kz; }
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -278,6 +289,7 @@ struct TopKPairs {
   // three compares straight into lane masks, combined on the scalar unit (a ballot of the combined bool goes through
   // a v_cndmask + v_cmp pair)
   __device__ __forceinline__ LaneMask sorts_before(float cz, int cidx, int k) const {
+    if (KEY64) return __builtin_amdgcn_ballot_w64(key_of(mk_entry(cz, cidx)) < key_of(zi[k]));
     const LaneMask lt = __builtin_amdgcn_ballot_w64(cz < zf(k));
     const LaneMask eq = __builtin_amdgcn_ballot_w64(cz == zf(k));
     const LaneMask il = __builtin_amdgcn_ballot_w64(cidx < ix(k));
@@ -313,7 +325,10 @@ struct TopKPairs {
   }
 #else
   typedef bool LaneMask;
-  LaneMask sorts_before(float cz, int cidx, int k) const { return (cz < zf(k)) | ((cz == zf(k)) & (cidx < ix(k))); }
+  LaneMask sorts_before(float cz, int cidx, int k) const {
+    if (KEY64) return key_of(mk_entry(cz, cidx)) < key_of(zi[k]);
+    return (cz < zf(k)) | ((cz == zf(k)) & (cidx < ix(k)));
+  }
   void place_and_shift(int k, LaneMask m, LaneMask m1, u32x2 czi, u32x2 cpa, u32x2 cpb) {
     if (m) {
       zi[k] = czi;
@@ -337,7 +352,7 @@ struct TopKPairs {
 
   // K == KT only (exact-K kernels)
   P3D_HDM void insert(int /*K*/, float cz, int cidx, const float (&cpl)[4]) {
-    const u32x2 czi = mk_pair(f32_bits(cz), (unsigned)cidx);
+    const u32x2 czi = mk_entry(cz, cidx);
     const u32x2 cpa = mk_pair(f32_bits(cpl[0]), f32_bits(cpl[1]));
     const u32x2 cpb = mk_pair(f32_bits(cpl[2]), f32_bits(cpl[3]));
     LaneMask mk = sorts_before(cz, cidx, KT - 1);
@@ -380,10 +395,24 @@ struct TopKPairs {
         pb[k] = pb[k + 1];
       }
     }
-    zi[KT - 1] = mk_pair(f32_bits(INFINITY), (unsigned)kEmptyIdx);
+    zi[KT - 1] = mk_entry(INFINITY, kEmptyIdx);
     kz = INFINITY;
     ki = kEmptyIdx;
   }
+};
+
+// the queue a kernel with compile-time perspective-correct + clipped barycentrics may use in place of Q
+template <typename Q>
+struct PcQueue {
+  typedef Q type;
+};
+template <int KT>
+struct PcQueue<TopKPairs<KT, false>> {
+#if defined(P3D_QUEUE_PAIRS) && P3D_QUEUE_PAIRS == 2
+  typedef TopKPairs<KT, true> type;
+#else
+  typedef TopKPairs<KT, false> type;
+#endif
 };
 
 }  // namespace p3d

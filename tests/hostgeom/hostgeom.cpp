@@ -266,8 +266,10 @@ extern "C" int64_t hg_queue_pairs_check(int64_t sequences, uint64_t seed) {
   for (int64_t t = 0; t < sequences; ++t) {
     TopKReg<8, 4> a;
     TopKPairs<8> b;
+    TopKPairs<8, true> c;  // one 64-bit key compare per entry (depths here are >= +0, as in the kernels that use it)
     a.init();
     b.init();
+    c.init();
     const int ops = 4 + (int)(next() % 40);
     const int zlevels = 1 + (int)(next() % 12);  // few distinct depths: many exact ties
     for (int o = 0; o < ops; ++o) {
@@ -277,26 +279,28 @@ extern "C" int64_t hg_queue_pairs_check(int64_t sequences, uint64_t seed) {
       const float pl[4] = {(float)(r >> 30 & 1023) * 0.5f - 100.0f, (float)(o), (float)(t & 255), -(float)idx};
       if ((r >> 40) % 7 == 0) {
         const int want = (int)((r >> 44) % 64);
-        const int fa = a.find(want), fb = b.find(want);
-        if (fa != fb) ++bad;
+        const int fa = a.find(want), fb = b.find(want), fc = c.find(want);
+        if (fa != fb || fa != fc) ++bad;
         if (fa >= 0) {
-          if (a.payload_at(0, fa) != b.payload_at(0, fb)) ++bad;
+          if (a.payload_at(0, fa) != b.payload_at(0, fb) || a.payload_at(0, fa) != c.payload_at(0, fc)) ++bad;
           a.erase(fa);
           b.erase(fb);
+          c.erase(fc);
         }
       } else {
-        const bool ad_a = a.admits(8, z, idx), ad_b = b.admits(8, z, idx);
-        if (ad_a != ad_b) ++bad;
+        const bool ad_a = a.admits(8, z, idx), ad_b = b.admits(8, z, idx), ad_c = c.admits(8, z, idx);
+        if (ad_a != ad_b || ad_a != ad_c) ++bad;
         if (ad_a) a.insert(8, z, idx, pl);
         if (ad_b) b.insert(8, z, idx, pl);
+        if (ad_c) c.insert(8, z, idx, pl);
       }
-      if (a.kth_z(8) != b.kth_z(8) && !(a.kth_z(8) != a.kth_z(8))) ++bad;
+      if ((a.kth_z(8) != b.kth_z(8) || a.kth_z(8) != c.kth_z(8)) && !(a.kth_z(8) != a.kth_z(8))) ++bad;
       for (int k = 0; k < 8; ++k) {
-        if (a.valid(k) != b.valid(k) || a.ix(k) != b.ix(k)) ++bad;
+        if (a.valid(k) != b.valid(k) || a.ix(k) != b.ix(k) || a.ix(k) != c.ix(k)) ++bad;
         if (!a.valid(k)) continue;
-        if (a.zf(k) != b.zf(k)) ++bad;
+        if (a.zf(k) != b.zf(k) || a.zf(k) != c.zf(k)) ++bad;
         for (int p = 0; p < 4; ++p)
-          if (a.pay(p, k) != b.pay(p, k)) ++bad;
+          if (a.pay(p, k) != b.pay(p, k) || a.pay(p, k) != c.pay(p, k)) ++bad;
       }
     }
   }
