@@ -13,10 +13,13 @@
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"
-declare -A FLAGS=( [pairs]="-DP3D_QUEUE_PAIRS=1" [packed]="-DP3D_GEOM_PACKED=1" [both]="-DP3D_QUEUE_PAIRS=1 -DP3D_GEOM_PACKED=1" [key64]="-DP3D_QUEUE_PAIRS=2 -DP3D_GEOM_PACKED=1" )
+# Point rasterizer (csrc/raster_points.hip): -DP3D_POINT_QUEUE_PAIRS=1|2 -- K = 8, 10, 16, 32, 40, 50, 64, 100 as payload-free
+# pair queues (2: one 64-bit key compare per entry).  Static counts of the whole K = 100 kernel: 5958 -> 2291 VALU
+# instructions, 256 + 241 AGPRs -> 256 registers (two waves per SIMD instead of one); K = 50: 3073 -> 1441, 199 -> 156.
+declare -A FLAGS=( [pairs]="-DP3D_QUEUE_PAIRS=1" [packed]="-DP3D_GEOM_PACKED=1" [both]="-DP3D_QUEUE_PAIRS=1 -DP3D_GEOM_PACKED=1" [key64]="-DP3D_QUEUE_PAIRS=2 -DP3D_GEOM_PACKED=1" [ppairs]="-DP3D_POINT_QUEUE_PAIRS=1" [pkey64]="-DP3D_POINT_QUEUE_PAIRS=2" )
 case "${1:-}" in
   build)
-    for v in pairs packed both key64; do
+    for v in pairs packed both key64 ppairs pkey64; do
       P3D_LIB_PATH=$ROOT/pytorch3d_amd/libp3d_$v.so P3D_EXTRA_FLAGS="${FLAGS[$v]}" python -m pytorch3d_amd.build > /dev/null || exit 1
       echo "built libp3d_$v.so (${FLAGS[$v]})"
     done ;;
@@ -32,6 +35,16 @@ case "${1:-}" in
       tail -2 gpurun_out/exp/tests_$v.txt
       unset P3D_LIB_PATH P3D_EXTRA_FLAGS
     done
+    # point rasterizer variants: K sweep on the 1M-point config + the point / compositor suite
+    python profiles/points_k_sweep.py 8 10 16 32 40 50 64 100 > gpurun_out/exp/points_product.txt 2>&1
+    for v in ppairs pkey64; do
+      export P3D_LIB_PATH=$ROOT/pytorch3d_amd/libp3d_$v.so P3D_EXTRA_FLAGS="${FLAGS[$v]}"
+      python profiles/points_k_sweep.py 8 10 16 32 40 50 64 100 > gpurun_out/exp/points_$v.txt 2>&1
+      timeout 300 python -m pytest tests/test_gpu_points_composite_interp.py tests/test_gpu_vs_reference_device_kernels.py -x -q > gpurun_out/exp/tests_$v.txt 2>&1
+      tail -2 gpurun_out/exp/tests_$v.txt
+      unset P3D_LIB_PATH P3D_EXTRA_FLAGS
+    done
+    tail -n 12 gpurun_out/exp/points_product.txt gpurun_out/exp/points_ppairs.txt gpurun_out/exp/points_pkey64.txt
     python - <<'PY'
 import json
 for t in ("product", "pairs", "packed", "both", "key64"):

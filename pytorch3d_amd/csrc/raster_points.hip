@@ -36,6 +36,14 @@ struct PointArgs {
   float* dists;
 };
 
+// P3D_POINT_QUEUE_PAIRS (experiment, see topk.h: TopKPairs): K = 8, 10, 16, 32, 40, 50, 64, 100 (exactly) as payload-free
+// queues of one 64-bit register pair per entry, insertion by masked v_pk_mov_b32; 2: entries ordered by one unsigned 64-bit
+// compare of (z bits, idx) -- then a staged depth of -0.0 is stored as +0.0 (the sign of a zero depth is the one thing
+// that differs from the reference with that setting).
+#ifndef P3D_POINT_QUEUE_PAIRS
+#define P3D_POINT_QUEUE_PAIRS 0
+#endif
+
 // PAYLOAD: the queue carries dist2 next to (z, idx).  Without it (long queues: 2 registers per entry instead of 3) the
 // distance is recomputed from the point's coordinates when the pixel is written -- the same two subtractions, two
 // products and one sum as in the test (rasterize_points.cu:55-60), so the same bits.
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(kStage, WAVES) void point_raster_kernel(PointArgs a
     }
     if (keep) {
       s_box[pos] = make_float4(px - r, px + r, py - r, py + r);
-      s_pt[pos] = make_float4(px, py, pz, r * r);
+      s_pt[pos] = make_float4(px, py, P3D_POINT_QUEUE_PAIRS == 2 ? pz + 0.0f : pz, r * r);
       s_idx[pos] = pid;
       s_key[pos] = pz;
     }
@@ -171,14 +179,14 @@ __global__ __launch_bounds__(kStage, WAVES) void point_raster_kernel(PointArgs a
       for (int k = 0; k < KT; ++k) {
         if (k < K) {
           const bool ok = q.valid(k);
-          a.idxs[base + k] = ok ? q.idx[k] : -1;
-          a.zbuf[base + k] = ok ? q.z[k] : -1.0f;
+          a.idxs[base + k] = ok ? q.ix(k) : -1;
+          a.zbuf[base + k] = ok ? q.zf(k) : -1.0f;
           if constexpr (PAYLOAD) {
-            a.dists[base + k] = ok ? q.pl[0][k] : -1.0f;
+            a.dists[base + k] = ok ? q.pay(0, k) : -1.0f;
           } else {
             float d2 = -1.0f;
             if (ok) {
-              const float* g = a.points + (int64_t)q.idx[k] * 3;
+              const float* g = a.points + (int64_t)q.ix(k) * 3;
               const float dx = xf - g[0];
               const float dy = yf - g[1];
               d2 = dx * dx + dy * dy;
@@ -190,19 +198,37 @@ __global__ __launch_bounds__(kStage, WAVES) void point_raster_kernel(PointArgs a
     } else {
       for (int k = 0; k < K; ++k) {
         const bool ok = q.valid(k);
-        a.idxs[base + k] = ok ? q.idx[k] : -1;
-        a.zbuf[base + k] = ok ? q.z[k] : -1.0f;
-        a.dists[base + k] = ok ? q.pl[0][k] : -1.0f;
+        a.idxs[base + k] = ok ? q.ix(k) : -1;
+        a.zbuf[base + k] = ok ? q.zf(k) : -1.0f;
+        a.dists[base + k] = ok ? q.pay(0, k) : -1.0f;
       }
     }
   }
 }
 
+#define P3D_COMMA ,
 template <bool BINNED>
 int launch_point_raster(const PointArgs& a, hipStream_t stream) {
   const unsigned grid = tile_grid(a.tm);
   LaunchScope ls(BINNED ? "points_fine" : "points_naive", stream);
   const int K = a.K;
+#if P3D_POINT_QUEUE_PAIRS
+  // experiment: exact capacities as payload-free pair queues (the distance is recomputed at the store)
+#define P3D_PQ(KT_, WAVES_) \
+  point_raster_kernel<TopKPairs<KT_ P3D_COMMA P3D_POINT_QUEUE_PAIRS == 2 P3D_COMMA 0>, KT_, true, BINNED, false, WAVES_><<<grid, kStage, 0, stream>>>(a)
+  switch (K) {
+    case 8: P3D_PQ(8, 2); return launch_status();
+    case 10: P3D_PQ(10, 2); return launch_status();
+    case 16: P3D_PQ(16, 2); return launch_status();
+    case 32: P3D_PQ(32, 2); return launch_status();
+    case 40: P3D_PQ(40, 2); return launch_status();
+    case 50: P3D_PQ(50, 2); return launch_status();
+    case 64: P3D_PQ(64, 2); return launch_status();
+    case 100: P3D_PQ(100, 1); return launch_status();
+    default: break;
+  }
+#undef P3D_PQ
+#endif
   if (K == 1)
     point_raster_kernel<TopKReg<1, 1>, 1, true, BINNED><<<grid, kStage, 0, stream>>>(a);
   else if (K == 2)

@@ -251,11 +251,15 @@ P3D_HDM u32x2 mk_pair(unsigned lo, unsigned hi) {
 // z = sum of products of non-negative numbers): the pair is laid out idx | z so that, as one unsigned 64-bit number, it
 // orders like (z, idx) for z >= +0 -- "sorts before" is then ONE 64-bit compare instead of three 32-bit ones.  NaN
 // depths compare above +inf (the empty entry) as bit patterns and are never admitted, as with the float compares.
-template <int KT, bool KEY64 = false>
+// NP: 4 payload words (meshes) or none (long point queues: the entry is the one pair).
+template <int KT, bool KEY64 = false, int NP = 4>
 struct TopKPairs {
+  static_assert(NP == 4 || NP == 0, "payload pairs: two or none");
+  static constexpr int KP = NP == 4 ? KT : 1;
+  static constexpr int NPS = NP > 0 ? NP : 1;
   u32x2 zi[KT];  // z bits, idx (KEY64: idx, z bits)
-  u32x2 pa[KT];  // payload 0, 1
-  u32x2 pb[KT];  // payload 2, 3
+  u32x2 pa[KP];  // payload 0, 1
+  u32x2 pb[KP];  // payload 2, 3
   float kz;
   int ki;
   static constexpr int kZ = KEY64 ? 1 : 0, kI = KEY64 ? 0 : 1;  // which half holds what
@@ -267,8 +271,10 @@ struct TopKPairs {
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
       zi[k] = mk_entry(INFINITY, kEmptyIdx);
-      pa[k] = mk_pair(f32_bits(-1.0f), f32_bits(-1.0f));
-      pb[k] = pa[k];
+      if (NP == 4) {
+        pa[k % KP] = mk_pair(f32_bits(-1.0f), f32_bits(-1.0f));
+        pb[k % KP] = pa[k % KP];
+      }
     }
     kz = INFINITY;
     ki = kEmptyIdx;
@@ -276,7 +282,10 @@ struct TopKPairs {
 
   P3D_HDM float zf(int k) const { return bits_f32(zi[k][kZ]); }
   P3D_HDM int ix(int k) const { return (int)zi[k][kI]; }
-  P3D_HDM float pay(int p, int k) const { return bits_f32(p == 0 ? pa[k][0] : (p == 1 ? pa[k][1] : (p == 2 ? pb[k][0] : pb[k][1]))); }
+  P3D_HDM float pay(int p, int k) const {
+    const int j = k % KP;
+    return bits_f32(p == 0 ? pa[j][0] : (p == 1 ? pa[j][1] : (p == 2 ? pb[j][0] : pb[j][1])));
+  }
   P3D_HDM bool valid(int k) const { return ix(k) != kEmptyIdx; }
   P3D_HDM bool admits(int /*K*/, float cz, int cidx) const {
     if (KEY64) return key_of(mk_entry(cz, cidx)) < key_of(mk_entry(kz, ki));
@@ -298,6 +307,17 @@ struct TopKPairs {
   // entry k <- candidate where m, then entry k <- entry k-1 where m1
   __device__ __forceinline__ void place_and_shift(int k, LaneMask m, LaneMask m1, u32x2 czi, u32x2 cpa, u32x2 cpb) {
     LaneMask saved;
+    if constexpr (NP == 0) {
+      asm volatile(
+          "s_and_saveexec_b64 %[sv], %[m]\n\t"
+          "v_pk_mov_b32 %[z], %[cz], %[cz] op_sel:[0,1]\n\t"
+          "s_and_b64 exec, exec, %[m1]\n\t"
+          "v_pk_mov_b32 %[z], %[pz], %[pz] op_sel:[0,1]\n\t"
+          "s_mov_b64 exec, %[sv]"
+          : [z] "+v"(zi[k]), [sv] "=&s"(saved)
+          : [m] "s"(m), [m1] "s"(m1), [cz] "v"(czi), [pz] "v"(zi[k - 1]));
+      return;
+    }
     asm volatile(
         "s_and_saveexec_b64 %[sv], %[m]\n\t"
         "v_pk_mov_b32 %[z], %[cz], %[cz] op_sel:[0,1]\n\t"
@@ -308,19 +328,28 @@ struct TopKPairs {
         "v_pk_mov_b32 %[a], %[pa_], %[pa_] op_sel:[0,1]\n\t"
         "v_pk_mov_b32 %[b], %[pb_], %[pb_] op_sel:[0,1]\n\t"
         "s_mov_b64 exec, %[sv]"
-        : [z] "+v"(zi[k]), [a] "+v"(pa[k]), [b] "+v"(pb[k]), [sv] "=&s"(saved)
-        : [m] "s"(m), [m1] "s"(m1), [cz] "v"(czi), [ca] "v"(cpa), [cb] "v"(cpb), [pz] "v"(zi[k - 1]), [pa_] "v"(pa[k - 1]),
-          [pb_] "v"(pb[k - 1]));
+        : [z] "+v"(zi[k]), [a] "+v"(pa[k % KP]), [b] "+v"(pb[k % KP]), [sv] "=&s"(saved)
+        : [m] "s"(m), [m1] "s"(m1), [cz] "v"(czi), [ca] "v"(cpa), [cb] "v"(cpb), [pz] "v"(zi[k - 1]), [pa_] "v"(pa[(k - 1) % KP]),
+          [pb_] "v"(pb[(k - 1) % KP]));
   }
   __device__ __forceinline__ void place(int k, LaneMask m, u32x2 czi, u32x2 cpa, u32x2 cpb) {
     LaneMask saved;
+    if constexpr (NP == 0) {
+      asm volatile(
+          "s_and_saveexec_b64 %[sv], %[m]\n\t"
+          "v_pk_mov_b32 %[z], %[cz], %[cz] op_sel:[0,1]\n\t"
+          "s_mov_b64 exec, %[sv]"
+          : [z] "+v"(zi[k]), [sv] "=&s"(saved)
+          : [m] "s"(m), [cz] "v"(czi));
+      return;
+    }
     asm volatile(
         "s_and_saveexec_b64 %[sv], %[m]\n\t"
         "v_pk_mov_b32 %[z], %[cz], %[cz] op_sel:[0,1]\n\t"
         "v_pk_mov_b32 %[a], %[ca], %[ca] op_sel:[0,1]\n\t"
         "v_pk_mov_b32 %[b], %[cb], %[cb] op_sel:[0,1]\n\t"
         "s_mov_b64 exec, %[sv]"
-        : [z] "+v"(zi[k]), [a] "+v"(pa[k]), [b] "+v"(pb[k]), [sv] "=&s"(saved)
+        : [z] "+v"(zi[k]), [a] "+v"(pa[k % KP]), [b] "+v"(pb[k % KP]), [sv] "=&s"(saved)
         : [m] "s"(m), [cz] "v"(czi), [ca] "v"(cpa), [cb] "v"(cpb));
   }
 #else
@@ -332,29 +361,35 @@ struct TopKPairs {
   void place_and_shift(int k, LaneMask m, LaneMask m1, u32x2 czi, u32x2 cpa, u32x2 cpb) {
     if (m) {
       zi[k] = czi;
-      pa[k] = cpa;
-      pb[k] = cpb;
+      if (NP == 4) {
+        pa[k % KP] = cpa;
+        pb[k % KP] = cpb;
+      }
     }
     if (m1) {
       zi[k] = zi[k - 1];
-      pa[k] = pa[k - 1];
-      pb[k] = pb[k - 1];
+      if (NP == 4) {
+        pa[k % KP] = pa[(k - 1) % KP];
+        pb[k % KP] = pb[(k - 1) % KP];
+      }
     }
   }
   void place(int k, LaneMask m, u32x2 czi, u32x2 cpa, u32x2 cpb) {
     if (m) {
       zi[k] = czi;
-      pa[k] = cpa;
-      pb[k] = cpb;
+      if (NP == 4) {
+        pa[k % KP] = cpa;
+        pb[k % KP] = cpb;
+      }
     }
   }
 #endif
 
   // K == KT only (exact-K kernels)
-  P3D_HDM void insert(int /*K*/, float cz, int cidx, const float (&cpl)[4]) {
+  P3D_HDM void insert(int /*K*/, float cz, int cidx, const float (&cpl)[NPS]) {
     const u32x2 czi = mk_entry(cz, cidx);
-    const u32x2 cpa = mk_pair(f32_bits(cpl[0]), f32_bits(cpl[1]));
-    const u32x2 cpb = mk_pair(f32_bits(cpl[2]), f32_bits(cpl[3]));
+    const u32x2 cpa = NP == 4 ? mk_pair(f32_bits(cpl[0]), f32_bits(cpl[1 % NPS])) : czi;
+    const u32x2 cpb = NP == 4 ? mk_pair(f32_bits(cpl[2 % NPS]), f32_bits(cpl[3 % NPS])) : czi;
     LaneMask mk = sorts_before(cz, cidx, KT - 1);
 #pragma unroll
     for (int k = KT - 1; k >= 1; --k) {
@@ -391,8 +426,10 @@ struct TopKPairs {
     for (int k = 0; k < KT - 1; ++k) {
       if (k >= at) {
         zi[k] = zi[k + 1];
-        pa[k] = pa[k + 1];
-        pb[k] = pb[k + 1];
+        if (NP == 4) {
+          pa[k % KP] = pa[(k + 1) % KP];
+          pb[k % KP] = pb[(k + 1) % KP];
+        }
       }
     }
     zi[KT - 1] = mk_entry(INFINITY, kEmptyIdx);
@@ -407,7 +444,7 @@ struct PcQueue {
   typedef Q type;
 };
 template <int KT>
-struct PcQueue<TopKPairs<KT, false>> {
+struct PcQueue<TopKPairs<KT, false, 4>> {
 #if defined(P3D_QUEUE_PAIRS) && P3D_QUEUE_PAIRS == 2
   typedef TopKPairs<KT, true> type;
 #else

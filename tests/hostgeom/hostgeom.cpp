@@ -306,3 +306,44 @@ extern "C" int64_t hg_queue_pairs_check(int64_t sequences, uint64_t seed) {
   }
   return bad;
 }
+
+// The payload-free form (long point queues): TopKPairs<12, *, 0> against TopKReg<12, 0>, inserts gated by admits().
+extern "C" int64_t hg_queue_pairs0_check(int64_t sequences, uint64_t seed) {
+  uint64_t s = seed * 0x9E3779B97F4A7C15ull + 11;
+  auto next = [&]() {
+    s ^= s << 13;
+    s ^= s >> 7;
+    s ^= s << 17;
+    return s;
+  };
+  int64_t bad = 0;
+  for (int64_t t = 0; t < sequences; ++t) {
+    TopKReg<12, 0> a;
+    TopKPairs<12, false, 0> b;
+    TopKPairs<12, true, 0> c;
+    a.init();
+    b.init();
+    c.init();
+    const int ops = 4 + (int)(next() % 60);
+    const int zlevels = 1 + (int)(next() % 9);
+    for (int o = 0; o < ops; ++o) {
+      const uint64_t r = next();
+      const float z = (float)(r % zlevels) * 0.5f + ((r >> 8) % 4 == 0 ? 0.0f : 1e-4f * (float)((r >> 12) % 3));
+      const int idx = (int)((r >> 20) % 97);
+      const float pl[1] = {0.0f};
+      const bool ad = a.admits(12, z, idx);
+      if (ad != b.admits(12, z, idx) || ad != c.admits(12, z, idx)) ++bad;
+      if (ad) {
+        a.insert(12, z, idx, pl);
+        b.insert(12, z, idx, pl);
+        c.insert(12, z, idx, pl);
+      }
+      if ((a.kth_z(12) != b.kth_z(12) || a.kth_z(12) != c.kth_z(12))) ++bad;
+      for (int k = 0; k < 12; ++k) {
+        if (a.valid(k) != b.valid(k) || a.valid(k) != c.valid(k) || a.ix(k) != b.ix(k) || a.ix(k) != c.ix(k)) ++bad;
+        if (a.valid(k) && (a.zf(k) != b.zf(k) || a.zf(k) != c.zf(k))) ++bad;
+      }
+    }
+  }
+  return bad;
+}

@@ -356,6 +356,10 @@ def test_pair_register_queue_scheme_matches_the_register_queue():
     hg.hg_queue_pairs_check.restype = ctypes.c_int64
     hg.hg_queue_pairs_check.argtypes = [ctypes.c_int64, ctypes.c_uint64]
     assert hg.hg_queue_pairs_check(200_000, 99) == 0
+    # the payload-free form of the long point queues (-DP3D_POINT_QUEUE_PAIRS), with and without the 64-bit key compare
+    hg.hg_queue_pairs0_check.restype = ctypes.c_int64
+    hg.hg_queue_pairs0_check.argtypes = [ctypes.c_int64, ctypes.c_uint64]
+    assert hg.hg_queue_pairs0_check(200_000, 7) == 0
 
 
 def test_experiment_flags_of_the_fine_rasterizer_still_compile(tmp_path):
@@ -369,8 +373,9 @@ def test_experiment_flags_of_the_fine_rasterizer_still_compile(tmp_path):
     hipcc = B._hipcc()
     if shutil.which(hipcc) is None and not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
-    src = os.path.join(B.CSRC, "raster_mesh.hip")
-    cmd = [hipcc] + B.FLAGS + ["-DP3D_QUEUE_PAIRS=1", "-DP3D_GEOM_PACKED=1", "-DP3D_CONCURRENT_FILL=1", "-x", "hip",
-                               "--cuda-device-only", "-c", src, "-o", str(tmp_path / "variant.o")]
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    assert res.returncode == 0, res.stderr[-2000:]
+    for src, flags in (("raster_mesh.hip", ["-DP3D_QUEUE_PAIRS=2", "-DP3D_GEOM_PACKED=1", "-DP3D_CONCURRENT_FILL=1"]),
+                       ("raster_points.hip", ["-DP3D_POINT_QUEUE_PAIRS=2"])):
+        cmd = [hipcc] + B.FLAGS + flags + ["-x", "hip", "--cuda-device-only", "-c", os.path.join(B.CSRC, src), "-o",
+                                           str(tmp_path / (src + ".o"))]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr[-2000:]
