@@ -75,7 +75,7 @@ struct MeshArgs {
 // fill in memory order (fill_tile_background), 2 the same by one wave of the workgroup, 3 / 4 = 1 / 0 with non-temporal
 // stores.
 #ifndef P3D_QUEUE_PAIRS
-#define P3D_QUEUE_PAIRS 0  // 1: the exact K = 4 and K = 8 kernels keep their queue in register pairs (topk.h: TopKPairs), an experiment;
+#define P3D_QUEUE_PAIRS 0  // 1: the K = 4, 8, 16 kernels keep their queue in register pairs (topk.h: TopKPairs), an experiment;
                            // 2: ... and the perspective + clip kernels order entries by one 64-bit key compare
 #endif
 #ifndef P3D_BG_FILL_MODE
@@ -867,6 +867,10 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
 #endif
   // 9..12: the queue (6 registers per entry: 72) still fits the register file at 3 waves per SIMD; from 16 entries on
   // the allocator spills hundreds of registers, and the queue in private memory is the better choice
+#if P3D_QUEUE_PAIRS
+  else if (K == 16)  // (12 entries in pairs spill 52 B/lane at three waves per SIMD: not offered)
+    P3D_LAUNCH_FINE_W(16, 2, TopKPairs<16>);
+#endif
   else if (K <= 12)
     P3D_LAUNCH_FINE_W(12, 3, TopKReg<12 P3D_COMMA kMeshPayload>);
   else if (K <= 16)
