@@ -713,7 +713,10 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
 #ifndef P3D_CONCURRENT_FILL
 #define P3D_CONCURRENT_FILL 0
 #endif
-constexpr size_t kFillLimiterLds = 40 * 1024;
+#ifndef P3D_FILL_LIMITER_KB
+#define P3D_FILL_LIMITER_KB 40  // unused LDS a fill workgroup asks for (occupancy limiter); to be swept: 0, 16, 40
+#endif
+constexpr size_t kFillLimiterLds = (size_t)P3D_FILL_LIMITER_KB * 1024;
 
 __global__ __launch_bounds__(kWave) void mesh_fill_background_kernel(MeshArgs a) {
   TileCoord tc;
