@@ -116,9 +116,12 @@ extern "C" int hg_rasterize_meshes_backward(const float* fv, const int64_t* p2f,
           const int64_t f = p2f[i];
           if (f < 0) continue;
           const float* g = fv + f * 9;
-          const FaceGrad r = face_sample_bwd(mk3(g[0], g[1], g[2]), mk3(g[3], g[4], g[5]), mk3(g[6], g[7], g[8]), p,
-                                             gz[i], mk3(gb[i * 3], gb[i * 3 + 1], gb[i * 3 + 2]), gd[i], persp, clip,
-                                             clip_on_corrected);
+          // clip_on_corrected bit 1: the packed-arithmetic form (p3d_geom.h: face_sample_bwd_pk)
+          const f3 w0 = mk3(g[0], g[1], g[2]), w1 = mk3(g[3], g[4], g[5]), w2 = mk3(g[6], g[7], g[8]);
+          const f3 gbv = mk3(gb[i * 3], gb[i * 3 + 1], gb[i * 3 + 2]);
+          const FaceGrad r = (clip_on_corrected & 2)
+                                 ? face_sample_bwd_pk(w0, w1, w2, p, gz[i], gbv, gd[i], persp, clip, (clip_on_corrected & 1) != 0)
+                                 : face_sample_bwd(w0, w1, w2, p, gz[i], gbv, gd[i], persp, clip, (clip_on_corrected & 1) != 0);
           for (int j = 0; j < 9; ++j) acc[f * 9 + j] += (double)r.g[j];
         }
       }
