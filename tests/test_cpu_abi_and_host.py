@@ -374,7 +374,7 @@ def test_experiment_flags_of_the_fine_rasterizer_still_compile(tmp_path):
     if shutil.which(hipcc) is None and not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     for src, flags in (("raster_mesh.hip", ["-DP3D_QUEUE_PAIRS=2", "-DP3D_GEOM_PACKED=1", "-DP3D_CONCURRENT_FILL=1"]),
-                       ("raster_points.hip", ["-DP3D_POINT_QUEUE_PAIRS=2"])):
+                       ("raster_points.hip", ["-DP3D_POINT_QUEUE_PAIRS=2"]), ("raster_mesh_bwd.hip", ["-DP3D_BWD_PACKED=1"])):
         cmd = [hipcc] + B.FLAGS + flags + ["-x", "hip", "--cuda-device-only", "-c", os.path.join(B.CSRC, src), "-o",
                                            str(tmp_path / (src + ".o"))]
         res = subprocess.run(cmd, capture_output=True, text=True)
