@@ -18,7 +18,7 @@ import sys
 
 OURS = {"mesh_raster_kernel": "mesh_fine", "mesh_backward": "mesh_backward", "points_raster": "points_fine",
         "bin_count": "bin_count", "bin_fill": "bin_fill", "bin_scan_offsets": "bin_scan_offsets",
-        "bin_scan_rows": "bin_scan_rows", "bin_plan": "bin_plan", "gather_faces": "gather_face_verts",
+        "bin_scan_rows": "bin_scan_rows", "bin_scan_small": "bin_scan_small", "bin_plan": "bin_plan", "gather_faces": "gather_face_verts",
         "scatter_face": "scatter_face_grads"}
 
 
