@@ -324,7 +324,11 @@ __device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue&
 #endif
         } else {
           fr.wide = __float_as_int(r2.w) != 0;
+#if P3D_GEOM_PACKED
+          hit = face_hit_rec_pk(fr, p, a.blur, persp, clip, &h);
+#else
           hit = face_hit_rec(fr, p, a.blur, persp, clip, &h);
+#endif
         }
       }
       if (hit) {
