@@ -9,6 +9,7 @@ Function, driven by fixed random upstream gradients for zbuf / bary / dists (the
 tests/test_rasterize_meshes.py:563-571).  Inputs are resident in HBM before the timed region.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]                      weak scaling: every rank its own batch of 64
+                                                                             (N > 1 without a launcher: spawns the N ranks itself)
     python bench.py --jobs 512 [--gpus N]                                    BASELINE configs[4]: 512 fixed jobs = 8 sub-batches
                                                                              of 64 (generator seeds 0..7), rank r runs sub-batches
                                                                              r, r+G, ...; one pass = K "steps" (K = 8/G per rank)
@@ -261,9 +262,35 @@ def other_configs(lib, _lib, device):
     return out
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: re-execute this script under torch.distributed.run with one rank per
+    GPU (what the driver does itself for N > 1, and what the reference's only multi-device test does with
+    nn.DataParallel, tests/test_render_multigpu.py:127-184).  The children print the ONE JSON line (rank 0)."""
+    import socket
+    import subprocess
+
+    n = args.gpus
+    have = torch.cuda.device_count()
+    if have < n and not os.environ.get("P3D_BENCH_TEST_BACKEND"):
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size is used", file=sys.stderr)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
