@@ -63,7 +63,7 @@ def stage(force=False):
         if os.path.exists(src):
             _copy(src, os.path.join(STAGE, "tests", m + ".py"))
     ddir = os.path.join(tdir, "data")
-    for f in os.listdir(ddir):
+    for f in (os.listdir(ddir) if os.path.isdir(ddir) else []):
         if f.endswith(".png"):
             _copy(os.path.join(ddir, f), os.path.join(STAGE, "tests", "data", f))
     for sub in ("missing_usemtl", "missing_files_obj", "obj_mtl_no_image"):  # small OBJ fixtures of test_render_meshes
@@ -72,7 +72,7 @@ def stage(force=False):
                 src = os.path.join(d, f)
                 _copy(src, os.path.join(STAGE, "tests", "data", os.path.relpath(src, ddir)))
     cow = os.path.join(REFERENCE, "docs", "tutorials", "data", "cow_mesh")
-    for f in os.listdir(cow):
+    for f in (os.listdir(cow) if os.path.isdir(cow) else []):
         _copy(os.path.join(cow, f), os.path.join(STAGE, "docs", "tutorials", "data", "cow_mesh", f))
     return STAGE
 

@@ -49,6 +49,22 @@ def _same_device(*named):
     return dev
 
 
+def _check_fragments(who, pix_to_face, **floats):
+    """The fragment tensors a fused kernel is about to reinterpret: pix_to_face must be int64 (rasterize_points returns
+    int32 idx -- a mix-up would be misread, not rejected, by a kernel that takes a raw pointer), the float tensors
+    float32, and everything on pix_to_face's GPU."""
+    _need_gpu(pix_to_face, "pix_to_face")
+    if pix_to_face.dtype != torch.int64:
+        raise RuntimeError(f"{who}: pix_to_face must be int64, got {pix_to_face.dtype}")
+    for name, t in floats.items():
+        _need_gpu(t, name)
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"{who}: {name} must be float32, got {t.dtype}")
+        if t.device != pix_to_face.device:
+            raise RuntimeError(f"Expected all tensors to be on the same GPU, but {name} is on {t.device} and pix_to_face is on "
+                               f"{pix_to_face.device}")
+
+
 def _c(t, dtype):
     if t.dtype != dtype:
         raise RuntimeError(f"expected dtype {dtype}, got {t.dtype}")

@@ -123,11 +123,7 @@ class _SoftmaxRGBBlend(torch.autograd.Function):
 def softmax_rgb_blend(colors, fragments, blend_params: BlendParams, znear: Union[float, torch.Tensor] = 1.0,
                       zfar: Union[float, torch.Tensor] = 100) -> torch.Tensor:
     """blending.py:147-244.  colors (N,H,W,K,3), fragments.{pix_to_face, dists, zbuf} (N,H,W,K) -> RGBA (N,H,W,4)."""
-    for name, t in (("colors", colors), ("dists", fragments.dists), ("zbuf", fragments.zbuf),
-                    ("pix_to_face", fragments.pix_to_face)):
-        _C._need_gpu(t, name)
-    if colors.dtype != torch.float32:
-        raise RuntimeError("softmax_rgb_blend: colors must be float32")
+    _C._check_fragments("softmax_rgb_blend", fragments.pix_to_face, colors=colors, dists=fragments.dists, zbuf=fragments.zbuf)
     bg = _background(blend_params, colors.device)
     return _SoftmaxRGBBlend.apply(colors, fragments.dists, fragments.zbuf, fragments.pix_to_face, blend_params.sigma,
                                   blend_params.gamma, bg, znear, zfar)
@@ -166,10 +162,7 @@ class _HardRGBBlend(torch.autograd.Function):
 def hard_rgb_blend(colors, fragments, blend_params: BlendParams) -> torch.Tensor:
     """blending.py:54-88: RGB of the closest face (slot 0), the background colour where no face covers the pixel;
     alpha 1 / 0.  colors (N,H,W,K,3) -> RGBA (N,H,W,4)."""
-    for name, t in (("colors", colors), ("pix_to_face", fragments.pix_to_face)):
-        _C._need_gpu(t, name)
-    if colors.dtype != torch.float32:
-        raise RuntimeError("hard_rgb_blend: colors must be float32")
+    _C._check_fragments("hard_rgb_blend", fragments.pix_to_face, colors=colors)
     if colors.shape != tuple(fragments.pix_to_face.shape) + (3,) or fragments.pix_to_face.shape[3] < 1:
         raise ValueError("colors must have shape (N, H, W, K, 3) with K >= 1 matching pix_to_face")
     return _HardRGBBlend.apply(colors, fragments.pix_to_face, _background(blend_params, colors.device, "hard_rgb_blend"))

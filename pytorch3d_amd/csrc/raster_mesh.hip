@@ -765,7 +765,10 @@ template <typename Q, int KT, bool REGS, bool BINNED, bool EXACT>
 void launch_fine_variant(const MeshArgs& a, unsigned grid, bool split, size_t dyn_lds, hipStream_t stream) {
   if constexpr (REGS && EXACT && BINNED) {
     if (split) {
-      mesh_raster_kernel<Q, KT, REGS, BINNED, EXACT, P3D_FINE_WAVES_PER_SIMD, false, true><<<grid * 4, kStage, 0, stream>>>(a);
+      // the merge slab (3 x 6 x KT x 64 floats beside the staging arrays) bounds the split kernel's occupancy: declare what
+      // the LDS allows (K = 8: 66 KB -> 2 workgroups per CU, K = 4: 47 KB -> 3) instead of an unattainable 4
+      constexpr int kSplitWaves = KT >= 8 ? 2 : (KT >= 4 ? 3 : P3D_FINE_WAVES_PER_SIMD);
+      mesh_raster_kernel<Q, KT, REGS, BINNED, EXACT, kSplitWaves, false, true><<<grid * 4, kStage, 0, stream>>>(a);
       return;
     }
   }

@@ -230,8 +230,7 @@ class _RasterizeMeshVerts(torch.autograd.Function):
         face_verts, faces, pix_to_face = ctx.saved_tensors
         if grad_zbuf is None and grad_barycentric_coords is None and grad_dists is None:
             return (None,) * 13
-        if torch.are_deterministic_algorithms_enabled() and not torch.is_deterministic_algorithms_warn_only_enabled():
-            raise RuntimeError("RasterizeMeshesBackwardCuda does not have a deterministic implementation")
+        _refuse_when_deterministic()
         dev = pix_to_face.device
         N, H, W, K = pix_to_face.shape
         zeros = lambda *tail: torch.zeros(tuple(pix_to_face.shape) + tail, dtype=torch.float32, device=dev)
@@ -303,7 +302,9 @@ def rasterize_meshes_world(meshes_world, world_to_view, view_to_ndc, image_size=
         a = a[None] if a.dim() == 2 else a
         b = b[None] if b.dim() == 2 else b
         ndc = transform_points_reference(verts, meshes_world.verts_packed_to_mesh_idx(), a, b)
-        return rasterize_meshes(meshes_world.update_verts_packed(ndc), image_size, blur_radius, faces_per_pixel, bin_size,
+        # any object with the packed accessors is accepted here (PackedMeshes, the reference's Meshes): do not ask it for
+        # more than rasterize_meshes itself does (update_verts_packed exists on PackedMeshes only)
+        return rasterize_meshes(_PackedVertsView(meshes_world, ndc), image_size, blur_radius, faces_per_pixel, bin_size,
                                 max_faces_per_bin, perspective_correct, clip_barycentric_coords, cull_backfaces)
     mats = _pack_matrices(w2v, v2n, n, verts.device)
     im_size = parse_image_size(image_size)
@@ -322,6 +323,38 @@ def rasterize_meshes_world(meshes_world, world_to_view, view_to_ndc, image_size=
                                      meshes_world.num_faces_per_mesh(), meshes_world.mesh_to_verts_packed_first_idx(), mats, nbr,
                                      (im_size, blur_radius, faces_per_pixel, bin_size, max_faces_per_bin,
                                       bool(perspective_correct), bool(clip_barycentric_coords), bool(cull_backfaces)))
+
+
+class _PackedVertsView:
+    """The packed accessors `rasterize_meshes` reads, with the vertices replaced (topology shared with `meshes`)."""
+
+    def __init__(self, meshes, verts_packed):
+        self._meshes, self._verts = meshes, verts_packed
+
+    def __len__(self):
+        return len(self._meshes)
+
+    def verts_packed(self):
+        return self._verts
+
+    def faces_packed(self):
+        return self._meshes.faces_packed()
+
+    def mesh_to_faces_packed_first_idx(self):
+        return self._meshes.mesh_to_faces_packed_first_idx()
+
+    def num_faces_per_mesh(self):
+        return self._meshes.num_faces_per_mesh()
+
+    @property
+    def _F(self):
+        return self._meshes._F
+
+
+def _refuse_when_deterministic():
+    """The backward scatters with float atomics, like the reference's (rasterize_meshes.cu:587 alertNotDeterministic)."""
+    if torch.are_deterministic_algorithms_enabled() and not torch.is_deterministic_algorithms_warn_only_enabled():
+        raise RuntimeError("RasterizeMeshesBackwardCuda does not have a deterministic implementation")
 
 
 class _RasterizeMeshWorld(torch.autograd.Function):
@@ -357,6 +390,7 @@ class _RasterizeMeshWorld(torch.autograd.Function):
         verts, faces, vert_first, mats, face_verts, pix_to_face = ctx.saved_tensors
         if grad_zbuf is None and grad_bary is None and grad_dists is None:
             return (None,) * 8
+        _refuse_when_deterministic()
         dev = pix_to_face.device
         N, H, W, K = pix_to_face.shape
         zeros = lambda *tail: torch.zeros(tuple(pix_to_face.shape) + tail, dtype=torch.float32, device=dev)

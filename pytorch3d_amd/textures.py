@@ -113,9 +113,8 @@ def sample_textures_uv(fragments, faces_verts_uvs, maps, align_corners: bool = T
         raise NotImplementedError(f"sample_textures_uv: padding_mode {padding_mode!r} (only 'zeros' and 'border')")
     if sampling_mode not in _MODE:
         raise ValueError(f"sample_textures_uv: sampling_mode {sampling_mode!r}")
-    for name, t in (("pix_to_face", fragments.pix_to_face), ("bary_coords", fragments.bary_coords),
-                    ("faces_verts_uvs", faces_verts_uvs), ("maps", maps)):
-        _C._need_gpu(t, name)
+    _C._check_fragments("sample_textures_uv", fragments.pix_to_face, bary_coords=fragments.bary_coords,
+                        faces_verts_uvs=faces_verts_uvs, maps=maps)
     if faces_verts_uvs.dim() != 3 or faces_verts_uvs.shape[1:] != (3, 2):
         raise ValueError("faces_verts_uvs must have shape (F, 3, 2)")
     if maps.dim() != 4 or maps.shape[0] != fragments.pix_to_face.shape[0]:
@@ -131,9 +130,11 @@ def _sample_textures_uv_multi(fragments, faces_verts_uvs, maps, maps_ids, align_
         raise NotImplementedError(f"sample_textures_uv: padding_mode {padding_mode!r} (only 'zeros' and 'border')")
     if sampling_mode not in _MODE:
         raise ValueError(f"sample_textures_uv: sampling_mode {sampling_mode!r}")
-    for name, t in (("pix_to_face", fragments.pix_to_face), ("bary_coords", fragments.bary_coords),
-                    ("faces_verts_uvs", faces_verts_uvs), ("maps", maps), ("maps_ids", maps_ids)):
-        _C._need_gpu(t, name)
+    _C._check_fragments("sample_textures_uv", fragments.pix_to_face, bary_coords=fragments.bary_coords,
+                        faces_verts_uvs=faces_verts_uvs, maps=maps)
+    _C._need_gpu(maps_ids, "maps_ids")
+    if maps_ids.device != fragments.pix_to_face.device:
+        raise RuntimeError(f"Expected all tensors to be on the same GPU, but maps_ids is on {maps_ids.device}")
     if faces_verts_uvs.dim() != 3 or faces_verts_uvs.shape[1:] != (3, 2):
         raise ValueError("faces_verts_uvs must have shape (F, 3, 2)")
     N = fragments.pix_to_face.shape[0]
@@ -188,9 +189,7 @@ def sample_textures_atlas(fragments, atlas_packed) -> torch.Tensor:
     """TexturesAtlas.sample_textures(fragments) for atlas_packed = atlas_packed() (F,R,R,C) -> texels (N,H,W,K,C): the
     cell of the face's R x R grid nearest to the barycentric sample (textures.py:565-612).  Differentiable with respect
     to the atlas, not to the barycentric coordinates."""
-    for name, t in (("pix_to_face", fragments.pix_to_face), ("bary_coords", fragments.bary_coords),
-                    ("atlas_packed", atlas_packed)):
-        _C._need_gpu(t, name)
+    _C._check_fragments("sample_textures_atlas", fragments.pix_to_face, bary_coords=fragments.bary_coords, atlas_packed=atlas_packed)
     if atlas_packed.dim() != 4 or atlas_packed.shape[1] != atlas_packed.shape[2] or atlas_packed.shape[1] < 1:
         raise ValueError("atlas_packed must have shape (F, R, R, C)")
     if atlas_packed.dtype != torch.float32 or fragments.bary_coords.dtype != torch.float32:
