@@ -33,10 +33,10 @@
 
 enum Op {
   FMA_F32, MUL_F32, ADD_F32, MAX_F32, MOV_B32, CNDMASK, CMP_F32, CMP_U64, PK_MUL_F32, PK_FMA_F32, PK_ADD_F32, PK_MOV_B32,
-  MUL_F64, FMA_F64, ADD_F64, CVT_F64_F32, CVT_F32_F64, CVT_ROUNDTRIP, RCP_F32, RCP_F64, MUL_LO_U32, LSHL_B64, BPERMUTE, READLANE, NOPS
+  CNDMASK_SGPR, CNDMASK_E64_VCC, CNDMASK_ALT_ADD, CNDMASK_ALT2, CNDMASK_VCCSET, CNDMASK_CONST, EXEC_MOV, EXEC_PKMOV, CMP_CNDMASK, MIN3_F32, MED3_F32, MUL_F64, FMA_F64, ADD_F64, CVT_F64_F32, CVT_F32_F64, CVT_ROUNDTRIP, RCP_F32, RCP_F64, MUL_LO_U32, LSHL_B64, BPERMUTE, READLANE, NOPS
 };
 static const char* kNames[] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_max_f32", "v_mov_b32", "v_cndmask_b32", "v_cmp_lt_f32", "v_cmp_lt_u64",
-                               "v_pk_mul_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_pk_mov_b32", "v_mul_f64", "v_fma_f64", "v_add_f64",
+                               "v_pk_mul_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_pk_mov_b32", "v_cndmask_b32 (sgpr mask)", "v_cndmask_b32_e64 (vcc)", "cndmask_e32 / v_add alternating", "2 cndmask_e32 / 2 v_add", "v_cndmask_b32 (vcc set)", "v_cndmask_b32 (inline 0)", "saveexec+v_mov+restore", "saveexec+v_pk_mov+restore", "v_cmp+v_cndmask pair", "v_min3_f32", "v_med3_f32", "v_mul_f64", "v_fma_f64", "v_add_f64",
                                "v_cvt_f64_f32", "v_cvt_f32_f64", "cvt f32->f64->f32 (pair)", "v_rcp_f32", "v_rcp_f64", "v_mul_lo_u32",
                                "v_lshlrev_b64", "ds_bpermute_b32", "v_readlane_b32", "(count)"};
 
@@ -60,7 +60,7 @@ static const char* kNames[] = {"v_fma_f32", "v_mul_f32", "v_add_f32", "v_max_f32
                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(d0), "+v"(d1), "+v"(d2), \
                  "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7)                                                        \
                : "v"(s0), "v"(s1), "v"(q0), "v"(q1)                                                                      \
-               : "vcc", "s20", "s21")
+               : "vcc", "scc", "s20", "s21")
 
 template <int OP, bool DEP>
 __global__ __launch_bounds__(1024) void k(int iters, unsigned long long* ticks, float* sink) {
@@ -96,6 +96,41 @@ __global__ __launch_bounds__(1024) void k(int iters, unsigned long long* ticks, 
       if (DEP) RUN_BLOCK("v_pk_mov_b32 %8, %9, %9 op_sel:[0,1]\nv_pk_mov_b32 %9, %8, %8 op_sel:[0,1]\nv_pk_mov_b32 %8, %9, %9 op_sel:[0,1]\nv_pk_mov_b32 %9, %8, %8 op_sel:[0,1]\nv_pk_mov_b32 %8, %9, %9 op_sel:[0,1]\nv_pk_mov_b32 %9, %8, %8 op_sel:[0,1]\nv_pk_mov_b32 %8, %9, %9 op_sel:[0,1]\nv_pk_mov_b32 %9, %8, %8 op_sel:[0,1]\n");
       else RUN_BLOCK("v_pk_mov_b32 %8, %18, %18 op_sel:[0,1]\nv_pk_mov_b32 %9, %18, %18 op_sel:[0,1]\nv_pk_mov_b32 %10, %18, %18 op_sel:[0,1]\nv_pk_mov_b32 %11, %18, %18 op_sel:[0,1]\nv_pk_mov_b32 %12, %19, %19 op_sel:[0,1]\nv_pk_mov_b32 %13, %19, %19 op_sel:[0,1]\nv_pk_mov_b32 %14, %19, %19 op_sel:[0,1]\nv_pk_mov_b32 %15, %19, %19 op_sel:[0,1]\n");
     }
+    if constexpr (OP == CNDMASK_SGPR) {  // VOP3 form: the lane mask in an SGPR pair (what the compiler emits for all but one select)
+      asm volatile("s_mov_b32 s20, 0x55555555\ns_mov_b32 s21, 0x55555555" ::: "s20", "s21");
+      if (DEP) RUN_BLOCK(D8_32("v_cndmask_b32", ", %16, s[20:21]")); else RUN_BLOCK(I8_32("v_cndmask_b32", ", %16, s[20:21]"));
+    }
+    if constexpr (OP == CNDMASK_E64_VCC) {  // the same select in the VOP3 encoding, mask still in vcc
+      if (DEP) RUN_BLOCK(D8_32("v_cndmask_b32_e64", ", %16, vcc")); else RUN_BLOCK(I8_32("v_cndmask_b32_e64", ", %16, vcc"));
+    }
+    if constexpr (OP == CNDMASK_ALT_ADD) {
+      RUN_BLOCK("v_cndmask_b32_e32 %0, %0, %16, vcc\nv_add_f32 %1, %1, %17\nv_cndmask_b32_e32 %2, %2, %16, vcc\nv_add_f32 %3, %3, %17\nv_cndmask_b32_e32 %4, %4, %16, vcc\nv_add_f32 %5, %5, %17\nv_cndmask_b32_e32 %6, %6, %16, vcc\nv_add_f32 %7, %7, %17\n");
+    }
+    if constexpr (OP == CNDMASK_ALT2) {
+      RUN_BLOCK("v_cndmask_b32_e32 %0, %0, %16, vcc\nv_cndmask_b32_e32 %1, %1, %16, vcc\nv_add_f32 %2, %2, %17\nv_add_f32 %3, %3, %17\nv_cndmask_b32_e32 %4, %4, %16, vcc\nv_cndmask_b32_e32 %5, %5, %16, vcc\nv_add_f32 %6, %6, %17\nv_add_f32 %7, %7, %17\n");
+    }
+    if constexpr (OP == CNDMASK_VCCSET) {
+      asm volatile("s_mov_b32 vcc_lo, 0x33333333\ns_mov_b32 vcc_hi, 0x33333333" ::: "vcc");
+      if (DEP) RUN_BLOCK(D8_32("v_cndmask_b32", ", %16, vcc")); else RUN_BLOCK(I8_32("v_cndmask_b32", ", %16, vcc"));
+    }
+    if constexpr (OP == CNDMASK_CONST) {
+      asm volatile("s_mov_b32 vcc_lo, 0x33333333\ns_mov_b32 vcc_hi, 0x33333333" ::: "vcc");
+      if (DEP) RUN_BLOCK(D8_32("v_cndmask_b32", ", 0, vcc")); else RUN_BLOCK(I8_32("v_cndmask_b32", ", 0, vcc"));
+    }
+    if constexpr (OP == EXEC_MOV) {  // 8 x (s_and_saveexec, v_mov, s_mov exec): counted as 8 "instructions" (one masked move each)
+      asm volatile("s_mov_b32 vcc_lo, 0x33333333\ns_mov_b32 vcc_hi, 0x33333333" ::: "vcc");
+      RUN_BLOCK("s_and_saveexec_b64 s[20:21], vcc\nv_mov_b32 %0, %16\ns_mov_b64 exec, s[20:21]\ns_and_saveexec_b64 s[20:21], vcc\nv_mov_b32 %1, %16\ns_mov_b64 exec, s[20:21]\ns_and_saveexec_b64 s[20:21], vcc\nv_mov_b32 %2, %16\ns_mov_b64 exec, s[20:21]\ns_and_saveexec_b64 s[20:21], vcc\nv_mov_b32 %3, %16\ns_mov_b64 exec, s[20:21]\ns_and_saveexec_b64 s[20:21], vcc\nv_mov_b32 %4, %16\ns_mov_b64 exec, s[20:21]\ns_and_saveexec_b64 s[20:21], vcc\nv_mov_b32 %5, %16\ns_mov_b64 exec, s[20:21]\ns_and_saveexec_b64 s[20:21], vcc\nv_mov_b32 %6, %16\ns_mov_b64 exec, s[20:21]\ns_and_saveexec_b64 s[20:21], vcc\nv_mov_b32 %7, %16\ns_mov_b64 exec, s[20:21]\n");
+    }
+    if constexpr (OP == EXEC_PKMOV) {  // one saveexec / restore around 6 v_pk_mov (the TopKPairs entry step): 8 "instructions" = 8 instructions
+      asm volatile("s_mov_b32 vcc_lo, 0x33333333\ns_mov_b32 vcc_hi, 0x33333333" ::: "vcc");
+      RUN_BLOCK("s_and_saveexec_b64 s[20:21], vcc\nv_pk_mov_b32 %8, %18, %18 op_sel:[0,1]\nv_pk_mov_b32 %9, %18, %18 op_sel:[0,1]\nv_pk_mov_b32 %10, %18, %18 op_sel:[0,1]\nv_pk_mov_b32 %11, %19, %19 op_sel:[0,1]\nv_pk_mov_b32 %12, %19, %19 op_sel:[0,1]\nv_pk_mov_b32 %13, %19, %19 op_sel:[0,1]\ns_mov_b64 exec, s[20:21]\n");
+    }
+    if constexpr (OP == CMP_CNDMASK) {  // the compiler's select idiom: compare into an SGPR pair, select on it
+      if (DEP) RUN_BLOCK("v_cmp_lt_f32 s[20:21], %0, %16\nv_cndmask_b32 %0, %0, %17, s[20:21]\nv_cmp_lt_f32 s[20:21], %0, %16\nv_cndmask_b32 %0, %0, %17, s[20:21]\nv_cmp_lt_f32 s[20:21], %0, %16\nv_cndmask_b32 %0, %0, %17, s[20:21]\nv_cmp_lt_f32 s[20:21], %0, %16\nv_cndmask_b32 %0, %0, %17, s[20:21]\n");
+      else RUN_BLOCK("v_cmp_lt_f32 s[20:21], %0, %16\nv_cndmask_b32 %1, %1, %17, s[20:21]\nv_cmp_lt_f32 vcc, %2, %16\nv_cndmask_b32 %3, %3, %17, vcc\nv_cmp_lt_f32 s[20:21], %4, %16\nv_cndmask_b32 %5, %5, %17, s[20:21]\nv_cmp_lt_f32 vcc, %6, %16\nv_cndmask_b32 %7, %7, %17, vcc\n");
+    }
+    if constexpr (OP == MIN3_F32) { if (DEP) RUN_BLOCK(D8_32("v_min3_f32", ", %16, %17")); else RUN_BLOCK(I8_32("v_min3_f32", ", %16, %17")); }
+    if constexpr (OP == MED3_F32) { if (DEP) RUN_BLOCK(D8_32("v_med3_f32", ", %16, %17")); else RUN_BLOCK(I8_32("v_med3_f32", ", %16, %17")); }
     if constexpr (OP == MUL_F64) { if (DEP) RUN_BLOCK(D8_64("v_mul_f64", ", %18")); else RUN_BLOCK(I8_64("v_mul_f64", ", %18")); }
     if constexpr (OP == FMA_F64) { if (DEP) RUN_BLOCK(D8_64("v_fma_f64", ", %18, %19")); else RUN_BLOCK(I8_64("v_fma_f64", ", %18, %19")); }
     if constexpr (OP == ADD_F64) { if (DEP) RUN_BLOCK(D8_64("v_add_f64", ", %19")); else RUN_BLOCK(I8_64("v_add_f64", ", %19")); }
@@ -193,6 +228,11 @@ int main() {
   g_ghz = p.clockRate / 1e6;
   printf("# %s, %d CUs, clockRate %.0f MHz, wave64; one workgroup of 256*W threads per CU (W waves per SIMD), 1.28M instructions per wave\n",
          p.gcnArchName, cus, p.clockRate / 1e3);
+  {
+    Result r = run_one<FMA_F32, false>(1, 20000, d_ticks, d_sink, cus);
+    printf("# s_memtime: %.1f ticks per microsecond of kernel wall time in a one-wave-per-SIMD v_fma_f32 loop (a constant 100 MHz counter would read 100)\n",
+           r.med_ticks / (r.wall_ms * 1e3));
+  }
   printf("# cyc/wave = kernel wall time x clockRate / instructions of one wave; cyc/SIMD = cyc/wave / W (issue cost per instruction\n"
          "# when W waves share the SIMD); tick = s_memtime ticks per instruction of one wave (median over waves)\n");
   report<FMA_F32>(d_ticks, d_sink, cus);
@@ -207,6 +247,17 @@ int main() {
   report<PK_FMA_F32>(d_ticks, d_sink, cus);
   report<PK_ADD_F32>(d_ticks, d_sink, cus);
   report<PK_MOV_B32>(d_ticks, d_sink, cus);
+  report<CNDMASK_SGPR>(d_ticks, d_sink, cus);
+  report<CNDMASK_E64_VCC>(d_ticks, d_sink, cus);
+  report<CNDMASK_ALT_ADD>(d_ticks, d_sink, cus);
+  report<CNDMASK_ALT2>(d_ticks, d_sink, cus);
+  report<CNDMASK_VCCSET>(d_ticks, d_sink, cus);
+  report<CNDMASK_CONST>(d_ticks, d_sink, cus);
+  report<EXEC_MOV>(d_ticks, d_sink, cus);
+  report<EXEC_PKMOV>(d_ticks, d_sink, cus);
+  report<CMP_CNDMASK>(d_ticks, d_sink, cus);
+  report<MIN3_F32>(d_ticks, d_sink, cus);
+  report<MED3_F32>(d_ticks, d_sink, cus);
   report<MUL_F64>(d_ticks, d_sink, cus);
   report<FMA_F64>(d_ticks, d_sink, cus);
   report<ADD_F64>(d_ticks, d_sink, cus);

@@ -97,33 +97,28 @@ def summary(ops):
 
 
 def main():
+    """Product build only (the round-2 build-flag variants this script compared are folded in or deleted: the pair queues
+    are the product since round 3; profiles/r02_static_counts.txt keeps the before / after record)."""
     with tempfile.TemporaryDirectory() as tmp:
         print("# mesh_fine, K = 8, perspective + clip kernel: innermost candidate loop (per wave and candidate face)")
-        for tag, flags in (("product", []), ("-DP3D_QUEUE_PAIRS=1", ["-DP3D_QUEUE_PAIRS=1"]), ("-DP3D_GEOM_PACKED=1", ["-DP3D_GEOM_PACKED=1"]),
-                           ("PAIRS=1 + PACKED", ["-DP3D_QUEUE_PAIRS=1", "-DP3D_GEOM_PACKED=1"]),
-                           ("PAIRS=2 + PACKED", ["-DP3D_QUEUE_PAIRS=2", "-DP3D_GEOM_PACKED=1"])):
-            lines, err = compile_s("raster_mesh.hip", flags, tmp)
-            ks, rs = kernels(lines), resources(err)
-            name = [n for n in ks if re.search(r"mesh_raster_kernel<TopK(Reg<8, 4>|Pairs<8, (false|true), 4>), 8, true, true, true, 4, true, false>", n)][0]
-            print("%-22s %s  VGPR %s scratch %s" % (tag, summary(count(ks[name], "s_ff1_i32_b64")), rs[name][0], rs[name][2]))
+        lines, err = compile_s("raster_mesh.hip", [], tmp)
+        ks, rs = kernels(lines), resources(err)
+        name = [n for n in ks if re.search(r"mesh_raster_kernel<TopKPairs<8, true, 4>, 8, true, true, true, 4, true, false>", n)][0]
+        print("%-22s %s  VGPR %s scratch %s" % ("product", summary(count(ks[name], "s_ff1_i32_b64")), rs[name][0], rs[name][2]))
         print("\n# mesh_backward, K = 8 (whole kernel)")
-        for tag, flags in (("product", []), ("-DP3D_BWD_PACKED=1", ["-DP3D_BWD_PACKED=1"])):
-            lines, err = compile_s("raster_mesh_bwd.hip", flags, tmp)
-            ks, rs = kernels(lines), resources(err)
-            name = [n for n in ks if "mesh_backward_kernel<8, false>" in n][0]
-            print("%-22s %s  VGPR %s scratch %s" % (tag, summary(count(ks[name])), rs[name][0], rs[name][2]))
+        lines, err = compile_s("raster_mesh_bwd.hip", [], tmp)
+        ks, rs = kernels(lines), resources(err)
+        name = [n for n in ks if "mesh_backward_kernel<8, false>" in n][0]
+        print("%-22s %s  VGPR %s scratch %s" % ("product", summary(count(ks[name])), rs[name][0], rs[name][2]))
         print("\n# points_fine (whole kernel) per queue capacity")
-        for tag, flags in (("product", []), ("-DP3D_POINT_QUEUE_PAIRS=1", ["-DP3D_POINT_QUEUE_PAIRS=1"]),
-                           ("-DP3D_POINT_QUEUE_PAIRS=2", ["-DP3D_POINT_QUEUE_PAIRS=2"])):
-            lines, err = compile_s("raster_points.hip", flags, tmp)
-            ks, rs = kernels(lines), resources(err)
-            for K in (10, 32, 50, 100):
-                pat = (r"point_raster_kernel<TopKReg<%d, [01]>, %d, true, true" % (K, K)) if not flags else (r"point_raster_kernel<TopKPairs<%d, (false|true), 0>, %d, true, true" % (K, K))
-                names = [n for n in ks if re.search(pat, n)]
-                if not names:
-                    continue
-                r = rs[names[0]]
-                print("%-26s K=%-3d %s  VGPR %s AGPR %s scratch %s waves/SIMD %s" % (tag, K, summary(count(ks[names[0]])), r[0], r[1], r[2], r[3]))
+        lines, err = compile_s("raster_points.hip", [], tmp)
+        ks, rs = kernels(lines), resources(err)
+        for K in (10, 32, 50, 100):
+            names = [n for n in ks if re.search(r"point_raster_kernel<TopKPairs<%d, true, 0>, %d, true, true" % (K, K), n)]
+            if not names:
+                continue
+            r = rs[names[0]]
+            print("%-26s K=%-3d %s  VGPR %s AGPR %s scratch %s waves/SIMD %s" % ("product", K, summary(count(ks[names[0]])), r[0], r[1], r[2], r[3]))
 
 
 if __name__ == "__main__":

@@ -358,87 +358,6 @@ P3D_HD bool face_hit_rec(const FaceRec& r, f2 p, float blur_radius, bool perspec
 }
 
 // ---------------------------------------------------------------------------
-// face_hit_rec with the (x, y) arithmetic written on two-float vectors (-DP3D_GEOM_PACKED=1, an experiment: the fine
-// rasterizer is bound by VALU issue, and gfx950 executes v_pk_mul / v_pk_add / v_pk_fma on two floats per lane at the
-// rate of one scalar instruction).  Every component goes through the same operations in the same order as in
-// face_hit_rec -- a packed multiply or add is the two scalar ones -- so the results are the same bits; the host build
-// (tests/hostgeom) checks that.  hipcc's own SLP pairing of the scalar code lost 3.5 % to operand shuffles
-// (-fno-slp-vectorize in build.py); here the pairs are the natural ones: (x, y) of a difference vector.
-// ---------------------------------------------------------------------------
-#ifndef P3D_GEOM_PACKED
-#define P3D_GEOM_PACKED 0
-#endif
-#if defined(__clang__)
-typedef float v2f __attribute__((ext_vector_type(2)));
-#else
-typedef float v2f __attribute__((vector_size(8)));
-#endif
-
-P3D_HD v2f mkv(float x, float y) {
-  v2f r;
-  r[0] = x;
-  r[1] = y;
-  return r;
-}
-P3D_HD v2f swap2(v2f a) { return mkv(a[1], a[0]); }
-
-// seg_dist2_rec on vectors: pa = p - a, pb = p - b (shared with the edge functions), ba = b - a
-P3D_HD float seg_dist2_pk(v2f p, v2f a, v2f pa, v2f pb, v2f ba, double rd_l2) {
-  const v2f m = ba * pa;                      // bax * (p.x - a.x), bay * (p.y - a.y)
-  float t = exact_div(m[0] + m[1], rd_l2);
-  const v2f e2 = pb * pb;                     // ex * ex, ey * ey
-  const float d_point = e2[0] + e2[1];
-  t = sat01(t);
-  const v2f tt = mkv(t, t);
-  const v2f d = (a + tt * ba) - p;            // (a.x + t * bax) - p.x, (a.y + t * bay) - p.y
-  const v2f d2 = d * d;
-  const float d_seg = d2[0] + d2[1];
-  return (rd_l2 < 0.0) ? d_point : d_seg;
-}
-
-P3D_HD bool face_hit_rec_pk(const FaceRec& r, f2 pp, float blur_radius, bool perspective_correct, bool clip_bary,
-                            FaceHit* out) {
-  const v2f p = mkv(pp.x, pp.y);
-  const v2f a = mkv(r.v0.x, r.v0.y), b = mkv(r.v1.x, r.v1.y), c = mkv(r.v2.x, r.v2.y);
-  const v2f pa = p - a, pb = p - b, pc = p - c;
-  const v2f ab = b - a, bc = c - b, ca = a - c, ac = c - a;
-  // edge_fn(p, u, v) = (p.x - u.x) * (v.y - u.y) - (p.y - u.y) * (v.x - u.x)
-  const v2f m0 = pb * swap2(bc), m1 = pc * swap2(ca), m2 = pa * swap2(ab);
-  const f3 bw = mk3(exact_div(m0[0] - m0[1], r.rd_area), exact_div(m1[0] - m1[1], r.rd_area),
-                    exact_div(m2[0] - m2[1], r.rd_area));
-  f3 bp = bw;
-  if (perspective_correct) {
-    const float t0 = bw.x * r.v1.z * r.v2.z;
-    const float t1 = r.v0.z * bw.y * r.v2.z;
-    const float t2 = r.v0.z * r.v1.z * bw.z;
-    const float denom = fmaxf(t0 + t1 + t2, (float)P3D_KEPS);
-    const double rd = r.wide ? recip_for_div_wide(denom) : recip_for_div(denom);
-    bp = mk3(exact_div(t0, rd), exact_div(t1, rd), exact_div(t2, rd));
-  }
-  f3 bcl = bp;
-  if (clip_bary) {
-    const float w0 = bp.x > 0.0f ? bp.x : 0.0f;
-    const float w1 = bp.y > 0.0f ? bp.y : 0.0f;
-    const float w2 = bp.z > 0.0f ? bp.z : 0.0f;
-    float s = w0 + w1 + w2;
-    s = fmaxf(s, 1e-5f);
-    const double rd = r.wide ? recip_for_div_wide(s) : recip_for_div(s);
-    bcl = mk3(exact_div(w0, rd), exact_div(w1, rd), exact_div(w2, rd));
-  }
-  const float pz = bcl.x * r.v0.z + bcl.y * r.v1.z + bcl.z * r.v2.z;
-  const float e01 = seg_dist2_pk(p, a, pa, pb, ab, r.rd_l01);
-  const float e02 = seg_dist2_pk(p, a, pa, pc, ac, r.rd_l02);
-  const float e12 = seg_dist2_pk(p, b, pb, pc, bc, r.rd_l12);
-  const float dist = fminf(fminf(e01, e02), e12);
-  const bool inside = (bp.x > 0.0f) & (bp.y > 0.0f) & (bp.z > 0.0f);
-  const bool hit = !(pz < 0.0f) & (inside | !(dist >= blur_radius));
-  out->z = pz;
-  out->dist = inside ? -dist : dist;
-  out->bary = bcl;
-  return hit;
-}
-
-// ---------------------------------------------------------------------------
 // Conservative rectangle-vs-face reject for the fine rasterizers' culling stages: true only if NO pixel centre
 // in [x0, x1] x [y0, y1] can be hit by the face, i.e. every point of the rectangle is outside the triangle AND
 // farther than sqrt(blur) from it.  Two sufficient conditions: (1) the rectangle is farther than r from the
@@ -686,111 +605,6 @@ P3D_HD FaceGrad face_sample_bwd(f3 v0, f3 v1, f3 v2, f2 p, float g_zbuf, f3 g_ba
   r.g[6] = db.d2.x + dd.d2.x;
   r.g[7] = db.d2.y + dd.d2.y;
   r.g[8] = g_zbuf * bc.z + dz2;
-  return r;
-}
-
-// ---------------------------------------------------------------------------
-// face_sample_bwd with the (x, y) arithmetic on two-float vectors (-DP3D_BWD_PACKED=1, an experiment like
-// face_hit_rec_pk: the backward kernel's busy phases are VALU-bound too).  The forward recompute that decides anything
-// (inside test, clip masks, the closest edge) goes through the same operations per component as the scalar code; the
-// gradient arithmetic itself is tolerance-gated (the reference's own tests use rtol 2e-3) and is regrouped where that
-// saves work: the three edge_fn_bwd(v2, v0, v1, s_k) terms of bary_coords_bwd share their vectors, so their scalars
-// are summed first.  tests/hostgeom compares it with face_sample_bwd.
-// ---------------------------------------------------------------------------
-#ifndef P3D_BWD_PACKED
-#define P3D_BWD_PACKED 0
-#endif
-
-P3D_HD v2f rot2(v2f d) { return mkv(d[1], -d[0]); }  // (d.y, -d.x): edge_fn's gradient direction
-P3D_HD v2f splat2(float s) { return mkv(s, s); }
-
-// seg_dist2 (IEEE division) on vectors; pa = p - a, pb = p - b, ba = b - a
-P3D_HD float seg_dist2_v(v2f p, v2f a, v2f pa, v2f pb, v2f ba) {
-  const v2f l = ba * ba;
-  const float l2 = l[0] + l[1];
-  const v2f m = ba * pa;
-  float t = (m[0] + m[1]) / l2;
-  const v2f e2 = pb * pb;
-  const float d_point = e2[0] + e2[1];
-  t = sat01(t);
-  const v2f d = (a + splat2(t) * ba) - p;
-  const v2f d2 = d * d;
-  const float d_seg = d2[0] + d2[1];
-  return ((double)l2 <= P3D_KEPS) ? d_point : d_seg;
-}
-
-P3D_HD FaceGrad face_sample_bwd_pk(f3 v0, f3 v1, f3 v2, f2 pp, float g_zbuf, f3 g_bary, float g_dist,
-                                   bool perspective_correct, bool clip_bary, bool clip_bwd_on_corrected) {
-#if defined(__clang__)
-#pragma clang fp contract(fast)  // gradient-only arithmetic (tolerance-gated): let mul+add fuse into FMA
-#endif
-  const v2f p = mkv(pp.x, pp.y);
-  const v2f a = mkv(v0.x, v0.y), b = mkv(v1.x, v1.y), c = mkv(v2.x, v2.y);
-  const v2f pa = p - a, pb = p - b, pc = p - c;
-  const v2f ab = b - a, bc = c - b, ca = a - c, ac = c - a;
-  // forward recompute (signs decide): bary_coords<true>, bary_perspective<true>, bary_clip<true>
-  const float area = bary_area(mk2(v0.x, v0.y), mk2(v1.x, v1.y), mk2(v2.x, v2.y));
-  const v2f m0 = pb * mkv(bc[1], bc[0]), m1 = pc * mkv(ca[1], ca[0]), m2 = pa * mkv(ab[1], ab[0]);
-  const float e0 = m0[0] - m0[1], e1 = m1[0] - m1[1], e2 = m2[0] - m2[1];
-  const float inv_area = qdiv<true>(1.0f, area);
-  const f3 bw = mk3(qdiv<true>(e0, area), qdiv<true>(e1, area), qdiv<true>(e2, area));
-  const f3 bp = perspective_correct ? bary_perspective<true>(bw, v0.z, v1.z, v2.z) : bw;
-  const f3 bcl = clip_bary ? bary_clip<true>(bp) : bp;
-  const bool inside = (bp.x > 0.0f) & (bp.y > 0.0f) & (bp.z > 0.0f);
-  const float sign = inside ? -1.0f : 1.0f;
-
-  // tri_dist2_bwd: the closest edge (ties e01, e02, e12) gets the gradient
-  const float d01 = seg_dist2_v(p, a, pa, pb, ab);
-  const float d02 = seg_dist2_v(p, a, pa, pc, ac);
-  const float d12 = seg_dist2_v(p, b, pb, pc, bc);
-  const int sel = ((d01 <= d02) & (d01 <= d12)) ? 0 : (((d02 <= d01) & (d02 <= d12)) ? 1 : (((d12 <= d01) & (d12 <= d02)) ? 2 : 3));
-  v2f dd0 = splat2(0.0f), dd1 = dd0, dd2 = dd0;
-  {
-    const v2f ea = sel == 2 ? b : a, eb = sel == 0 ? b : c;
-    const float g = sel == 3 ? 0.0f : sign * g_dist;
-    const v2f ba = eb - ea;
-    const v2f q = ba * ba, t2 = ba * (p - ea);
-    const float bot = q[0] + q[1], top = t2[0] + t2[1];
-    const float tt = sat01(qdiv<true>(top, bot));
-    const v2f d = (splat2(1.0f - tt) * ea + splat2(tt) * eb) - p;
-    const v2f da = splat2(g * (1.0f - tt) * 2.0f) * d, db = splat2(g * tt * 2.0f) * d;
-    const v2f zero = splat2(0.0f);
-    dd0 = sel <= 1 ? da : zero;
-    dd1 = sel == 0 ? db : (sel == 2 ? da : zero);
-    dd2 = (sel == 1 || sel == 2) ? db : zero;
-  }
-
-  f3 gb = mk3(g_bary.x + g_zbuf * v0.z, g_bary.y + g_zbuf * v1.z, g_bary.z + g_zbuf * v2.z);
-  if (clip_bary) gb = bary_clip_bwd(clip_bwd_on_corrected ? bp : bw, gb);
-  float dz0 = 0.0f, dz1 = 0.0f, dz2 = 0.0f;
-  if (perspective_correct) {
-    const PerspGrad pg = bary_perspective_bwd(bw, v0.z, v1.z, v2.z, gb);
-    gb = pg.dbary;
-    dz0 = pg.dz0;
-    dz1 = pg.dz1;
-    dz2 = pg.dz2;
-  }
-  // bary_coords_bwd: w_k = e_k / area.  d w_k = t_k * d e_k + s_k * d area, t_k = g_k / area, s_k = -g_k e_k / area^2;
-  // d e_0 = edge_fn_bwd(p, v1, v2), d e_1 = (p, v2, v0), d e_2 = (p, v0, v1), d area = edge_fn_bwd(v2, v0, v1) for all k
-  const float inv_area2 = qdiv<true>(1.0f, area * area);
-  const float t0 = gb.x * inv_area, t1 = gb.y * inv_area, t2 = gb.z * inv_area;
-  const float A = gb.x * (-e0 * inv_area2) + gb.y * (-e1 * inv_area2) + gb.z * (-e2 * inv_area2);
-  const v2f ra = rot2(pa), rb = rot2(pb), rc = rot2(pc);
-  const v2f db0 = (splat2(t2) * rb - splat2(t1) * rc) + splat2(A) * rot2(c - b);
-  const v2f db1 = (splat2(t0) * rc - splat2(t2) * ra) + splat2(A) * rot2(ca);
-  const v2f db2 = (splat2(t1) * ra - splat2(t0) * rb) + splat2(A) * rot2(ab);
-
-  const v2f r0 = db0 + dd0, r1 = db1 + dd1, r2 = db2 + dd2;
-  FaceGrad r;
-  r.g[0] = r0[0];
-  r.g[1] = r0[1];
-  r.g[2] = g_zbuf * bcl.x + dz0;
-  r.g[3] = r1[0];
-  r.g[4] = r1[1];
-  r.g[5] = g_zbuf * bcl.y + dz1;
-  r.g[6] = r2[0];
-  r.g[7] = r2[1];
-  r.g[8] = g_zbuf * bcl.z + dz2;
   return r;
 }
 

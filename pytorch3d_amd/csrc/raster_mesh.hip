@@ -34,7 +34,6 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-#include <mutex>
 
 namespace p3d {
 
@@ -62,36 +61,16 @@ struct MeshArgs {
   TileMap tm;
   float blur, sqrt_blur;
   int persp, clip, cull;
-  int skip_background;  // background tiles are written by mesh_fill_background_kernel on the side stream (concurrent fill)
-  unsigned long long* timeline;  // -DP3D_FWD_TIMELINE builds only: per workgroup (start, end) of s_memrealtime (100 MHz) + face count
-  int debug;  // P3D_DEBUG_FWD ablation bits (profiles/ablate.py): 1 no per-pixel evaluation, 2 no queue insertion, 4 no stores, 16 no depth cull, 32 no front-to-back order, 64 background tiles stored per lane instead of cooperatively, 128 no bin permutation, 256 no rectangle-vs-face prune, 512 caller's bin geometry instead of tile-sized bins, 2048 background tiles store nothing, 4096 tiles with faces do nothing, 8192 every tile is background, 16384 staging only (no candidate loop), 32768 every chunk takes the general (neighbour rule) loop, 1024 (launcher) never / 131072 always the split kernel
   int64_t* p2f;
   float* zbuf;
   float* bary;
   float* dists;
 };
 
-// P3D_BG_FILL_MODE (ablation builds): how background tiles are stored.  0 every lane its own pixel's rows, 1 cooperative
-// fill in memory order (fill_tile_background), 2 the same by one wave of the workgroup, 3 / 4 = 1 / 0 with non-temporal
-// stores.
-#ifndef P3D_QUEUE_PAIRS
-#define P3D_QUEUE_PAIRS 0  // 1: the K = 4, 8, 16 kernels keep their queue in register pairs (topk.h: TopKPairs), an experiment;
-                           // 2: ... and the perspective + clip kernels order entries by one 64-bit key compare
-#endif
-#ifndef P3D_BG_FILL_MODE
-#define P3D_BG_FILL_MODE 1
-#endif
-#ifndef P3D_ACTIVE_NT
-#define P3D_ACTIVE_NT 0  // 1: the tiles with faces store their rows non-temporally
-#endif
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-template <bool NT>
 __device__ __forceinline__ void store16(void* p, unsigned a, unsigned b, unsigned c, unsigned d) {
   u32x4 v = {a, b, c, d};
-  if (NT)
-    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p));
-  else
-    *reinterpret_cast<u32x4*>(p) = v;
+  *reinterpret_cast<u32x4*>(p) = v;  // (non-temporal stores measured in round 2: equal or slower, profiles/r02_fill_modes.txt)
 }
 
 template <int KT>
@@ -118,7 +97,7 @@ __device__ __forceinline__ void store_row(float* dst, const float (&v)[KT]) {
 }
 
 // One pixel's K = KT rows of the four outputs from the register queue: 16-byte stores.
-template <typename Queue, int KT, bool IN_REGS, bool NT = false>
+template <typename Queue, int KT, bool IN_REGS>
 __device__ __forceinline__ void write_pixel(const MeshArgs& a, const Queue& q, int64_t opix) {
   static_assert(IN_REGS, "vector-row stores need the register queue");
   const int64_t base = opix * KT;
@@ -137,18 +116,18 @@ __device__ __forceinline__ void write_pixel(const MeshArgs& a, const Queue& q, i
   if constexpr (KT % 4 == 0) {
 #pragma unroll
     for (int k = 0; k < KT; k += 4) {
-      store16<NT>(a.zbuf + base + k, __float_as_uint(zv[k]), __float_as_uint(zv[k + 1]), __float_as_uint(zv[k + 2]),
+      store16(a.zbuf + base + k, __float_as_uint(zv[k]), __float_as_uint(zv[k + 1]), __float_as_uint(zv[k + 2]),
                   __float_as_uint(zv[k + 3]));
-      store16<NT>(a.dists + base + k, __float_as_uint(dv[k]), __float_as_uint(dv[k + 1]), __float_as_uint(dv[k + 2]),
+      store16(a.dists + base + k, __float_as_uint(dv[k]), __float_as_uint(dv[k + 1]), __float_as_uint(dv[k + 2]),
                   __float_as_uint(dv[k + 3]));
     }
 #pragma unroll
     for (int k = 0; k < 3 * KT; k += 4)
-      store16<NT>(a.bary + base * 3 + k, __float_as_uint(bv[k]), __float_as_uint(bv[k + 1]), __float_as_uint(bv[k + 2]),
+      store16(a.bary + base * 3 + k, __float_as_uint(bv[k]), __float_as_uint(bv[k + 1]), __float_as_uint(bv[k + 2]),
                   __float_as_uint(bv[k + 3]));
 #pragma unroll
     for (int k = 0; k < KT; k += 2)
-      store16<NT>(a.p2f + base + k, (unsigned)iv[k], (unsigned)(iv[k] >> 32), (unsigned)iv[k + 1], (unsigned)(iv[k + 1] >> 32));
+      store16(a.p2f + base + k, (unsigned)iv[k], (unsigned)(iv[k] >> 32), (unsigned)iv[k + 1], (unsigned)(iv[k + 1] >> 32));
   } else {
     store_row<KT>(a.zbuf + base, zv);
     store_row<KT>(a.dists + base, dv);
@@ -185,7 +164,7 @@ __device__ __forceinline__ void write_subtile_fill_patch(const MeshArgs& a, cons
   const int rows = min(8, y_end - sy0), cols = min(8, x_end - sx0);
   const int seg = cols * K;             // contiguous entries per sub-tile row (outputs are stored flipped: x_out = W-1-x)
   const int64_t col0 = W - sx0 - cols;  // first output column of the sub-tile
-  const bool patch = have && !(P3D_DBG(a) & 1024);
+  const bool patch = have;
   for (int r = 0; r < rows; ++r) {
     // ---- (A) fill row r of the sub-tile: one contiguous piece of each output ----
     const int64_t px = ((int64_t)n * H + (H - 1 - (sy0 + r))) * W + col0;
@@ -255,7 +234,7 @@ __device__ __forceinline__ void write_subtile_fill_patch(const MeshArgs& a, cons
 // 256 threads -- every store instruction of a wave covers one contiguous 1 KiB piece (a lane writing its own pixel's
 // K-row stores 16 bytes at a stride of 4*K..12*K).  Per tile row the outputs hold cols*K floats (zbuf, dists),
 // 3*cols*K floats (bary) and cols*K int64 (pix_to_face) = 7 * cols*K/4 16-byte pieces.
-template <int THREADS, bool NT>
+template <int THREADS>
 __device__ __forceinline__ void fill_tile_background(const MeshArgs& a, int n, int ty0, int tx0, int y_end, int x_end,
                                                      int tid, int side = kTile) {
   const int H = a.H, W = a.W, K = a.K;
@@ -273,7 +252,7 @@ __device__ __forceinline__ void fill_tile_background(const MeshArgs& a, int n, i
                                 : (in_b ? reinterpret_cast<char*>(a.bary + px * K * 3) : reinterpret_cast<char*>(a.p2f + px * K)));
       const int piece = e - (in_z ? 0 : (in_d ? q4 : (in_b ? 2 * q4 : 5 * q4)));
       const unsigned v = in_b ? 0xbf800000u : ~0u;  // four -1.0f, or two int64 -1 (a select of two uint4 constants compiles to a scratch array)
-      store16<NT>(base + (size_t)piece * 16, v, v, v, v);
+      store16(base + (size_t)piece * 16, v, v, v, v);
     }
   }
 }
@@ -299,8 +278,8 @@ __device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue&
     const float zc = s_zc[jj];
     const float4 r0 = s_rec[jj][0], r1 = s_rec[jj][1], r2 = s_rec[jj][2];
     const bool out = p.x > b.y || p.x < b.x || p.y > b.w || p.y < b.z;
-    const bool too_deep = zc > q.kth_z(K) && !(P3D_DBG(a) & 16);
-    if (pix_ok && !out && !too_deep && !(P3D_DBG(a) & 1)) {
+    const bool too_deep = zc > q.kth_z(K);
+    if (pix_ok && !out && !too_deep) {
       const int f = __float_as_int(r2.y);
       FaceHit h;
       bool hit;
@@ -317,18 +296,10 @@ __device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue&
         fr.rd_l12 = d1.y;
         if constexpr (PC && !GENERAL) {
           fr.wide = false;  // wide faces make their chunk general (stage_chunk)
-#if P3D_GEOM_PACKED
-          hit = face_hit_rec_pk(fr, p, a.blur, true, true, &h);
-#else
           hit = face_hit_rec(fr, p, a.blur, true, true, &h);
-#endif
         } else {
           fr.wide = __float_as_int(r2.w) != 0;
-#if P3D_GEOM_PACKED
-          hit = face_hit_rec_pk(fr, p, a.blur, persp, clip, &h);
-#else
           hit = face_hit_rec(fr, p, a.blur, persp, clip, &h);
-#endif
         }
       }
       if (hit) {
@@ -350,7 +321,7 @@ __device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue&
         }
         // a candidate that sorts after the K-th entry of a full queue would fall straight off the end of the insertion
         // network: skip the network for it
-        if (ins && q.admits(K, h.z, f) && !(P3D_DBG(a) & 2)) q.insert(K, h.z, f, pl);
+        if (ins && q.admits(K, h.z, f)) q.insert(K, h.z, f, pl);
       }
     }
   }
@@ -412,7 +383,7 @@ __device__ __forceinline__ int stage_chunk(const MeshArgs& a, const StageLds& l,
   if (keep) {
     FaceRec fr;
     face_rec_make(v0, v1, v2, &fr);
-    gen = nb != -1 || (PC && fr.wide) || (P3D_DBG(a) & 32768);
+    gen = nb != -1 || (PC && fr.wide);
     l.box[pos] = make_float4(fs.xlo, fs.xhi, fs.ylo, fs.yhi);
     l.rec[pos][0] = make_float4(v0.x, v0.y, v1.x, v1.y);
     l.rec[pos][1] = make_float4(v2.x, v2.y, v0.z, v1.z);
@@ -537,9 +508,6 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
   const int ty0 = by * a.tm.bin_size + ty * kTile;
   const int tx0 = bx * a.tm.bin_size + tx * kTile;
   if (ty0 >= y_end || tx0 >= x_end) return;  // tile has no pixel (uniform)
-#ifdef P3D_FWD_TIMELINE
-  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-#endif
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -564,40 +532,24 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
     src_base = a.mesh_first[n];
     count = (int)a.mesh_count[n];
   }
-  if (P3D_DBG(a) & 8192) count = 0;            // ablation: every tile is treated as background (pure fill)
-  if ((P3D_DBG(a) & 4096) && count > 0) return;  // ablation: tiles with faces do nothing at all
   if (count <= 0) {
-    if (a.skip_background) return;  // uniform
     const int Kbg = EXACT ? KT : a.K;  // compile-time where it can be: the row-fill branch is then the only one left
     // background tile (3 of 5 at the bench workload): nothing but the -1 stores; skip the NDC set-up below
-    if (!(P3D_DBG(a) & 4) && !(P3D_DBG(a) & 2048)) {
-      if (SPLIT && (Kbg & 3) == 0) {
-        fill_tile_background<kStage, false>(a, n, sy0, sx0, y_end, x_end, tid, 8);
-      } else if (SPLIT && w != 0) {
-        // the four waves cover the same pixels: wave 0 writes them
-      } else if ((Kbg & 3) == 0 && !(P3D_DBG(a) & 64) && P3D_BG_FILL_MODE != 0 && P3D_BG_FILL_MODE != 4) {
-        if (P3D_BG_FILL_MODE == 2) {
-          if (tid < kWave) fill_tile_background<kWave, false>(a, n, ty0, tx0, y_end, x_end, tid);
-        } else {
-          fill_tile_background<kStage, P3D_BG_FILL_MODE == 3>(a, n, ty0, tx0, y_end, x_end, tid);
-        }
-      } else if constexpr (EXACT) {
-        Queue e;
-        e.init();
-        if (pix_ok) write_pixel<Queue, KT, IN_REGS, P3D_BG_FILL_MODE == 4>(a, e, ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi));
-      } else if (wave_ok) {
-        Queue e;
-        e.init();
-        write_subtile_fill_patch<Queue, KT, IN_REGS>(a, e, false, n, sy0, sx0, y_end, x_end, lane, pix_ok, yi, xi);
-      }
+    if (SPLIT && (Kbg & 3) == 0) {
+      fill_tile_background<kStage>(a, n, sy0, sx0, y_end, x_end, tid, 8);
+    } else if (SPLIT && w != 0) {
+      // the four waves cover the same pixels: wave 0 writes them
+    } else if ((Kbg & 3) == 0) {
+      fill_tile_background<kStage>(a, n, ty0, tx0, y_end, x_end, tid);
+    } else if constexpr (EXACT) {
+      Queue e;
+      e.init();
+      if (pix_ok) write_pixel<Queue, KT, IN_REGS>(a, e, ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi));
+    } else if (wave_ok) {
+      Queue e;
+      e.init();
+      write_subtile_fill_patch<Queue, KT, IN_REGS>(a, e, false, n, sy0, sx0, y_end, x_end, lane, pix_ok, yi, xi);
     }
-#ifdef P3D_FWD_TIMELINE
-    if (a.timeline && tid == 0) {
-      a.timeline[3 * (size_t)blockIdx.x] = t_start;
-      a.timeline[3 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-      a.timeline[3 * (size_t)blockIdx.x + 2] = 0;
-    }
-#endif
     return;
   }
 
@@ -613,7 +565,7 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
   q.init();
   const int K = EXACT ? KT : a.K;
   const bool persp = PC || a.persp != 0, clip = PC || a.clip != 0, cull = a.cull != 0;
-  const bool prune = !(P3D_DBG(a) & 256);
+  const bool prune = true;  // the conservative rectangle-vs-face reject of the tile / sub-tile culls
   StageLds lds;
   lds.box = s_box;
   lds.rec = s_rec;
@@ -632,7 +584,7 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
   st.x1 = sub_x1;
   st.y0 = sub_y0;
   st.y1 = sub_y1;
-  const bool run_waves = wave_ok && !(P3D_DBG(a) & 16384);
+  const bool run_waves = wave_ok;
 
   // Two loop nests, entered one after the other and never re-entered: chunks are processed by the FAST nest (shared-
   // reciprocal evaluation, front-to-back order) until the first chunk that holds a face with a clipped neighbour;
@@ -646,15 +598,10 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
   for (; base < count; base += kStage) {
     staged = stage_chunk<BINNED, PC>(a, lds, tile, src_base, count, base, tid, cull, clip, prune, &general);
     if (general) break;  // uniform
-    if (!(P3D_DBG(a) & 32)) {
-      chunk_bucket_order(s_zc, staged, s_order, s_qlow, s_ord, tid);
-    } else {
-      if (tid < staged) s_order[tid] = tid;
-      __syncthreads();
-    }
+    chunk_bucket_order(s_zc, staged, s_order, s_qlow, s_ord, tid);
     if (run_waves)
-      wave_chunk<false, Queue, PC>(a, K, q, staged, !(P3D_DBG(a) & 32), st, p, pix_ok, lane, persp, clip, prune, s_box, s_rec, s_zc, s_order,
-                               s_qlow, SPLIT ? w : -1);
+      wave_chunk<false, Queue, PC>(a, K, q, staged, true, st, p, pix_ok, lane, persp, clip, prune, s_box, s_rec, s_zc, s_order, s_qlow,
+                                   SPLIT ? w : -1);
     __syncthreads();
   }
   if constexpr (SPLIT) {
@@ -682,7 +629,7 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
     }
   }
 
-  if (!(P3D_DBG(a) & 4)) {
+  {
     if constexpr (EXACT) {
       if (pix_ok && (!SPLIT || w == 0)) {
         // the pixel's coordinates are rebuilt from a fresh lane id: keeping yi / xi alive across the chunk loops costs the
@@ -690,74 +637,12 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
         int l2;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l2));
         const int yo = sy0 + (l2 >> 3), xo = sx0 + (l2 & 7);
-        write_pixel<Queue, KT, IN_REGS, P3D_ACTIVE_NT != 0>(a, q, ((int64_t)n * H + (H - 1 - yo)) * W + (W - 1 - xo));
+        write_pixel<Queue, KT, IN_REGS>(a, q, ((int64_t)n * H + (H - 1 - yo)) * W + (W - 1 - xo));
       }
     } else {
       if (wave_ok) write_subtile_fill_patch<Queue, KT, IN_REGS>(a, q, true, n, sy0, sx0, y_end, x_end, lane, pix_ok, yi, xi);
     }
   }
-#ifdef P3D_FWD_TIMELINE
-  __syncthreads();
-  if (a.timeline && tid == 0) {
-    a.timeline[3 * (size_t)blockIdx.x] = t_start;
-    a.timeline[3 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-    a.timeline[3 * (size_t)blockIdx.x + 2] = (unsigned long long)count;
-  }
-#endif
-}
-
-// ---- concurrent background fill (-DP3D_CONCURRENT_FILL=1) -----------------------------------------------------------
-// The tiles with faces are VALU-bound, the background tiles are pure stores; inside one launch they do not overlap,
-// because a workgroup that only stores still occupies a full slot of the fine kernel (256 threads x 120 registers; the
-// chip holds 1024 of them).  With the fine kernel at <= 120 registers, four of its workgroups per CU leave 32 registers
-// per SIMD lane and ~45 KB of LDS free: a second, tiny kernel on a side stream walks the same tile map, returns at once
-// for tiles with faces and fills the background tiles with one wave each, while the fine kernel (which now returns at
-// once for background tiles) keeps all its slots for tiles with faces.  The fill workgroups ask for 40 KB of LDS they
-// never touch: at most one of them fits beside the fine kernel's workgroups on a CU, so they cannot crowd those out.
-#ifndef P3D_CONCURRENT_FILL
-#define P3D_CONCURRENT_FILL 0
-#endif
-#ifndef P3D_FILL_LIMITER_KB
-#define P3D_FILL_LIMITER_KB 40  // unused LDS a fill workgroup asks for (occupancy limiter); to be swept: 0, 16, 40
-#endif
-constexpr size_t kFillLimiterLds = (size_t)P3D_FILL_LIMITER_KB * 1024;
-
-__global__ __launch_bounds__(kWave) void mesh_fill_background_kernel(MeshArgs a) {
-  TileCoord tc;
-  if (!tile_of_block(a.tm, blockIdx.x, &tc)) return;
-  const int y_end = min(a.H, (tc.by + 1) * a.tm.bin_size);
-  const int x_end = min(a.W, (tc.bx + 1) * a.tm.bin_size);
-  const int ty0 = tc.by * a.tm.bin_size + tc.ty * kTile;
-  const int tx0 = tc.bx * a.tm.bin_size + tc.tx * kTile;
-  if (ty0 >= y_end || tx0 >= x_end) return;
-  const int64_t row = ((int64_t)tc.n * a.tm.BH + tc.by) * a.tm.BW + tc.bx;
-  if (a.csr.total[row] > 0) return;  // the fine kernel's tile
-  fill_tile_background<kWave, false>(a, tc.n, ty0, tx0, y_end, x_end, (int)threadIdx.x);
-}
-
-// One side stream (lowest priority: the fine kernel's workgroups are placed first) and a fork / join event pair per
-// device, created on first use.  The mutex covers a whole fork .. join sequence: the events are shared.
-struct SideStream {
-  hipStream_t stream = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-  bool ok = false, tried = false;
-};
-std::mutex g_side_mutex;
-SideStream g_side[64];
-
-SideStream* side_stream_locked() {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  SideStream& s = g_side[dev];
-  if (!s.tried) {
-    s.tried = true;
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    s.ok = hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, P3D_CONCURRENT_FILL == 2 ? greatest : least) == hipSuccess &&
-           hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess;
-  }
-  return s.ok ? &s : nullptr;
 }
 
 // The instantiations one (Queue, K) pair can run as: split (few tiles), compile-time persp & clip, or plain.
@@ -784,75 +669,14 @@ void launch_fine_variant(const MeshArgs& a, unsigned grid, bool split, size_t dy
 #define P3D_COMMA ,
 template <bool BINNED>
 int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
-  MeshArgs a = a0;
-#ifdef P3D_ABLATION
-  {
-    const char* e = getenv("P3D_DEBUG_FWD");
-    a.debug = e ? atoi(e) : 0;
-    if (P3D_DBG(a) & 128) a.tm.bin_mult = 1;
-  }
-#endif
+  const MeshArgs& a = a0;
   const unsigned grid = tile_grid(a.tm);
   const char* name = BINNED ? "mesh_fine" : "mesh_naive";
-#ifdef P3D_FWD_TIMELINE
-  // ablation only: per-workgroup (start, end, faces) written to the file named by P3D_FWD_TIMELINE_OUT (synchronous)
-  struct Timeline {
-    unsigned long long* dev = nullptr;
-    unsigned n = 0;
-    hipStream_t s;
-    ~Timeline() {
-      const char* out = getenv("P3D_FWD_TIMELINE_OUT");
-      if (!dev) return;
-      (void)hipStreamSynchronize(s);
-      if (out) {
-        unsigned long long* h = (unsigned long long*)malloc((size_t)n * 24);
-        (void)hipMemcpy(h, dev, (size_t)n * 24, hipMemcpyDeviceToHost);
-        FILE* f = fopen(out, "wb");
-        if (f) {
-          fwrite(h, 24, n, f);
-          fclose(f);
-        }
-        free(h);
-      }
-      (void)hipFree(dev);
-    }
-  } tl;
-  tl.s = stream;
-  a.timeline = nullptr;
-  if (getenv("P3D_FWD_TIMELINE_OUT") && BINNED) {
-    tl.n = grid;
-    if (hipMalloc(&tl.dev, (size_t)grid * 24) == hipSuccess) {
-      (void)hipMemsetAsync(tl.dev, 0, (size_t)grid * 24, stream);
-      a.timeline = tl.dev;
-    }
-  }
-#endif
-  size_t dyn_lds = 0;  // extra (unused) LDS per workgroup: an occupancy limiter
-#ifdef P3D_ABLATION
-  if (const char* e = getenv("P3D_DEBUG_FWD_LDS")) dyn_lds = (size_t)atoi(e);
-#endif
   LaunchScope ls(name, stream);
   const int K = a.K;
   // few tiles (one image, a small batch): one workgroup per sub-tile with the candidate list dealt to its four waves
-  bool split = BINNED && grid <= (unsigned)kSplitMaxTiles;
-#ifdef P3D_ABLATION
-  if (P3D_DBG(a) & 1024) split = false;
-  if (P3D_DBG(a) & 131072) split = BINNED;
-#endif
-  // concurrent fill: K % 4 == 0 (fill_tile_background's 16-byte pieces), not the 12-entry queue (168 registers x 3 waves
-  // leave no room beside it), not the split kernel (small launches: nothing to overlap)
-  std::unique_lock<std::mutex> side_lock(g_side_mutex, std::defer_lock);
-  SideStream* side = nullptr;
-  if (P3D_CONCURRENT_FILL && BINNED && !split && (K & 3) == 0 && K != 12) {
-    side_lock.lock();
-    side = side_stream_locked();
-    if (side && hipEventRecord(side->fork, stream) == hipSuccess && hipStreamWaitEvent(side->stream, side->fork, 0) == hipSuccess)
-      a.skip_background = 1;
-    else
-      side = nullptr;
-    // mode 2 (experiment): highest priority and launched before the fine kernel
-    if (side && P3D_CONCURRENT_FILL == 2) mesh_fill_background_kernel<<<grid, kWave, kFillLimiterLds, side->stream>>>(a);
-  }
+  const bool split = BINNED && grid <= (unsigned)kSplitMaxTiles;
+  const size_t dyn_lds = 0;
 #define P3D_LAUNCH_FINE(KT_, REGS_, EXACT_, Q_) launch_fine_variant<Q_, KT_, REGS_, BINNED, EXACT_>(a, grid, split, dyn_lds, stream)
 #define P3D_LAUNCH_FINE_W(KT_, WAVES_, Q_) mesh_raster_kernel<Q_, KT_, true, BINNED, false, WAVES_><<<grid, kStage, 0, stream>>>(a)
   if (K == 1)
@@ -861,26 +685,16 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
     P3D_LAUNCH_FINE(2, true, true, TopKReg<2 P3D_COMMA kMeshPayload>);
   else if (K == 3)
     P3D_LAUNCH_FINE(4, true, false, TopKReg<4 P3D_COMMA kMeshPayload>);
-  else if (K == 4)
-#if P3D_QUEUE_PAIRS
-    P3D_LAUNCH_FINE(4, true, true, TopKPairs<4>);
-#else
-    P3D_LAUNCH_FINE(4, true, true, TopKReg<4 P3D_COMMA kMeshPayload>);
-#endif
+  else if (K == 4)  // K = 4, 8, 16: the queue in register pairs (topk.h: TopKPairs; one 64-bit key compare per entry in the
+    P3D_LAUNCH_FINE(4, true, true, TopKPairs<4>);  // perspective + clip kernels): measured -3 % / -11 % / -10 % (profiles/r03)
   else if (K < 8)
     P3D_LAUNCH_FINE(8, true, false, TopKReg<8 P3D_COMMA kMeshPayload>);
   else if (K == 8)
-#if P3D_QUEUE_PAIRS
     P3D_LAUNCH_FINE(8, true, true, TopKPairs<8>);
-#else
-    P3D_LAUNCH_FINE(8, true, true, TopKReg<8 P3D_COMMA kMeshPayload>);
-#endif
   // 9..12: the queue (6 registers per entry: 72) still fits the register file at 3 waves per SIMD; from 16 entries on
   // the allocator spills hundreds of registers, and the queue in private memory is the better choice
-#if P3D_QUEUE_PAIRS
   else if (K == 16)  // (12 entries in pairs spill 52 B/lane at three waves per SIMD: not offered)
     P3D_LAUNCH_FINE_W(16, 2, TopKPairs<16>);
-#endif
   else if (K <= 12)
     P3D_LAUNCH_FINE_W(12, 3, TopKReg<12 P3D_COMMA kMeshPayload>);
   else if (K <= 16)
@@ -889,12 +703,6 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
     P3D_LAUNCH_FINE(P3D_MAX_K, false, false, TopKMem<P3D_MAX_K P3D_COMMA kMeshPayload>);
 #undef P3D_LAUNCH_FINE
 #undef P3D_LAUNCH_FINE_W
-  if (side) {
-    // after the fine kernel, so that its workgroups take their slots first; the caller's stream continues after both
-    if (P3D_CONCURRENT_FILL != 2) mesh_fill_background_kernel<<<grid, kWave, kFillLimiterLds, side->stream>>>(a);
-    if (hipEventRecord(side->join, side->stream) != hipSuccess || hipStreamWaitEvent(stream, side->join, 0) != hipSuccess)
-      return P3D_ERR_LAUNCH;
-  }
   return launch_status();
 }
 
@@ -999,13 +807,7 @@ P3D_API int p3d_rasterize_meshes(const float* face_verts, const int64_t* mesh_fi
   if (!mesh_first || !mesh_count || !p2f || !zbuf || !bary || !dists) return P3D_ERR_INVALID_ARG;
   const BinGeom gu = make_geom(H, W, bin_size);
   if (gu.BH > P3D_MAX_BINS_PER_SIDE || gu.BW > P3D_MAX_BINS_PER_SIDE) return P3D_ERR_TOO_MANY_BINS;
-#ifdef P3D_ABLATION
-  const char* dbg_env = getenv("P3D_DEBUG_FWD");
-  const bool user_bins = dbg_env && (atoi(dbg_env) & 512);  // ablation: bin with the caller's geometry
-#else
-  const bool user_bins = false;
-#endif
-  const BinGeom g = user_bins ? gu : make_internal_geom(H, W, bin_size);  // tile-sized bins: results do not depend on the binning
+  const BinGeom g = make_internal_geom(H, W, bin_size);  // tile-sized bins: results do not depend on the binning
   Arena arena(workspace, workspace_bytes);
   BinWorkspace ws;
   if (!workspace || !bin_carve(arena, F, N, g, max_faces_per_bin, &ws)) return P3D_ERR_WORKSPACE;

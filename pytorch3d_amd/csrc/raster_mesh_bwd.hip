@@ -209,13 +209,8 @@ __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
 #pragma unroll
             for (int j = 0; j < 9; ++j) r.g[j] = v0.x + gz[k] + gd[k] + gb[3 * k];
           } else {
-#if P3D_BWD_PACKED
-            r = face_sample_bwd_pk(v0, v1, v2, p, gz[k], mk3(gb[3 * k], gb[3 * k + 1], gb[3 * k + 2]), gd[k], persp, clip,
-                                   false);
-#else
             r = face_sample_bwd(v0, v1, v2, p, gz[k], mk3(gb[3 * k], gb[3 * k + 1], gb[3 * k + 2]), gd[k], persp, clip,
                                 false);
-#endif
           }
         }
         if (P3D_DBG(a) & 2) {

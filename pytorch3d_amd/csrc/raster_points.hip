@@ -36,14 +36,6 @@ struct PointArgs {
   float* dists;
 };
 
-// P3D_POINT_QUEUE_PAIRS (experiment, see topk.h: TopKPairs): K = 8, 10, 16, 32, 40, 50, 64, 100 (exactly) as payload-free
-// queues of one 64-bit register pair per entry, insertion by masked v_pk_mov_b32; 2: entries ordered by one unsigned 64-bit
-// compare of (z bits, idx) -- then a staged depth of -0.0 is stored as +0.0 (the sign of a zero depth is the one thing
-// that differs from the reference with that setting).
-#ifndef P3D_POINT_QUEUE_PAIRS
-#define P3D_POINT_QUEUE_PAIRS 0
-#endif
-
 // PAYLOAD: the queue carries dist2 next to (z, idx).  Without it (long queues: 2 registers per entry instead of 3) the
 // distance is recomputed from the point's coordinates when the pixel is written -- the same two subtractions, two
 // products and one sum as in the test (rasterize_points.cu:55-60), so the same bits.
@@ -131,7 +123,9 @@ __global__ __launch_bounds__(kStage, WAVES) void point_raster_kernel(PointArgs a
     }
     if (keep) {
       s_box[pos] = make_float4(px - r, px + r, py - r, py + r);
-      s_pt[pos] = make_float4(px, py, P3D_POINT_QUEUE_PAIRS == 2 ? pz + 0.0f : pz, r * r);
+      // a queue ordered by the 64-bit key (z bits, idx) needs +0.0 for a zero depth: -0.0 would sort last.  The sign of an
+      // exactly zero depth is then the one bit that differs from the reference (K in {8, 10, 16, 32, 40, 50, 64, 100}).
+      s_pt[pos] = make_float4(px, py, Queue::kKeyOrder ? pz + 0.0f : pz, r * r);
       s_idx[pos] = pid;
       s_key[pos] = pz;
     }
@@ -212,10 +206,12 @@ int launch_point_raster(const PointArgs& a, hipStream_t stream) {
   const unsigned grid = tile_grid(a.tm);
   LaunchScope ls(BINNED ? "points_fine" : "points_naive", stream);
   const int K = a.K;
-#if P3D_POINT_QUEUE_PAIRS
-  // experiment: exact capacities as payload-free pair queues (the distance is recomputed at the store)
+  // The common capacities as payload-free pair queues with one 64-bit key compare per entry (topk.h: TopKPairs<KT, true, 0>;
+  // the distance is recomputed at the store; staged depths are >= +0).  Measured in round 3 against the cndmask queues
+  // below (1M points, 512^2): K = 10 0.27 -> 0.18 ms, K = 32 1.55 -> 0.73, K = 50 2.34 -> 1.54, K = 100 9.1 -> 3.0 ms
+  // (two waves per SIMD instead of one with 241 AGPRs).  Other K take the queue of the next capacity below.
 #define P3D_PQ(KT_, WAVES_) \
-  point_raster_kernel<TopKPairs<KT_ P3D_COMMA P3D_POINT_QUEUE_PAIRS == 2 P3D_COMMA 0>, KT_, true, BINNED, false, WAVES_><<<grid, kStage, 0, stream>>>(a)
+  point_raster_kernel<TopKPairs<KT_ P3D_COMMA true P3D_COMMA 0>, KT_, true, BINNED, false, WAVES_><<<grid, kStage, 0, stream>>>(a)
   switch (K) {
     case 8: P3D_PQ(8, 2); return launch_status();
     case 10: P3D_PQ(10, 2); return launch_status();
@@ -228,7 +224,6 @@ int launch_point_raster(const PointArgs& a, hipStream_t stream) {
     default: break;
   }
 #undef P3D_PQ
-#endif
   if (K == 1)
     point_raster_kernel<TopKReg<1, 1>, 1, true, BINNED><<<grid, kStage, 0, stream>>>(a);
   else if (K == 2)

@@ -25,6 +25,7 @@ constexpr int kEmptyIdx = 0x7fffffff;
 
 template <int KT, int NP>
 struct TopKReg {
+  static constexpr bool kKeyOrder = false;  // entries are ordered by float compares: -0.0 == +0.0
   static constexpr int NPS = NP > 0 ? NP : 1;  // storage rows; NP = 0: no payload (the one row is never touched and costs no register)
   float z[KT];
   int idx[KT];
@@ -153,6 +154,7 @@ struct TopKReg {
 
 template <int KMAX, int NP>
 struct TopKMem {
+  static constexpr bool kKeyOrder = false;
   float z[KMAX];
   int idx[KMAX];
   float pl[NP][KMAX];
@@ -209,9 +211,12 @@ struct TopKMem {
 
 // ---------------------------------------------------------------------------------------------------------------
 // TopKPairs -- TopKReg<KT, 4> with every entry held as three 64-bit register PAIRS (z | idx, payload 0 | 1, payload
-// 2 | 3) and the sorted insertion done with v_pk_mov_b32 under the lane mask instead of v_cndmask_b32 (an experiment,
-// -DP3D_QUEUE_PAIRS=1: the fine rasterizer is bound by VALU issue and the 8-entry insertion network is 97 of the 278
-// VALU instructions of its inner loop).  lt[k] = "the candidate sorts before entry k" is monotone in k, so top-down
+// 2 | 3) and the sorted insertion done with v_pk_mov_b32 under the lane mask instead of v_cndmask_b32.  The fine
+// rasterizers are bound by VALU issue (profiles/microbench/valu_issue.hip: v_cndmask / v_cmp / v_pk_mov all cost ~3.1
+// cycles of a SIMD with four waves resident) and the 8-entry insertion network is 97 v_cndmask + 24 v_cmp of the 278 VALU
+// instructions of the K = 8 inner loop; in pairs it is 45 v_pk_mov + 22 compares (measured, round 3: mesh_fine 1.49 ->
+// 1.31 ms at K = 8 with the 64-bit key, points K = 100 9.1 -> 3.0 ms).  lt[k] = "the candidate sorts before entry k" is
+// monotone in k, so top-down
 //     lanes with lt[k]:    entry k <- candidate            (3 pair moves)
 //     lanes with lt[k-1]:  entry k <- entry k-1            (3 pair moves; lt[k-1] implies lt[k])
 // leaves entry k = lt[k-1] ? old k-1 : (lt[k] ? candidate : itself) -- TopKReg::insert's result -- in 6 instructions
@@ -247,14 +252,15 @@ P3D_HDM u32x2 mk_pair(unsigned lo, unsigned hi) {
   return r;
 }
 
-// KEY64 (-DP3D_QUEUE_PAIRS=2, kernels whose depths are never -0.0: perspective-correct + clipped barycentrics give
-// z = sum of products of non-negative numbers): the pair is laid out idx | z so that, as one unsigned 64-bit number, it
+// KEY64 (kernels whose depths are never -0.0: perspective-correct + clipped barycentrics give z = sum of products of
+// non-negative numbers; point depths are staged with -0.0 canonicalised): the pair is laid out idx | z so that, as one unsigned 64-bit number, it
 // orders like (z, idx) for z >= +0 -- "sorts before" is then ONE 64-bit compare instead of three 32-bit ones.  NaN
 // depths compare above +inf (the empty entry) as bit patterns and are never admitted, as with the float compares.
 // NP: 4 payload words (meshes) or none (long point queues: the entry is the one pair).
 template <int KT, bool KEY64 = false, int NP = 4>
 struct TopKPairs {
   static_assert(NP == 4 || NP == 0, "payload pairs: two or none");
+  static constexpr bool kKeyOrder = KEY64;  // ordered by the bit pattern of z: the caller supplies depths >= +0
   static constexpr int KP = NP == 4 ? KT : 1;
   static constexpr int NPS = NP > 0 ? NP : 1;
   u32x2 zi[KT];  // z bits, idx (KEY64: idx, z bits)
@@ -445,11 +451,7 @@ struct PcQueue {
 };
 template <int KT>
 struct PcQueue<TopKPairs<KT, false, 4>> {
-#if defined(P3D_QUEUE_PAIRS) && P3D_QUEUE_PAIRS == 2
   typedef TopKPairs<KT, true> type;
-#else
-  typedef TopKPairs<KT, false> type;
-#endif
 };
 
 }  // namespace p3d

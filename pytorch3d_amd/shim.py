@@ -10,6 +10,23 @@ interpolate_face_attributes, ...) runs on the MI355X kernels.
 `pytorch3d/__init__.py` does not import `_C`; the sub-packages do (`from pytorch3d import _C`),
 so the module must be in sys.modules before they are imported.  Operators outside the hot path
 (knn, point_mesh, pulsar, ...) raise NotImplementedError when called.
+
+    shim.install(patch_python=True)
+
+additionally replaces the reference's pure-torch callers and callees of the operator surface with the
+fused HIP versions of this package, so that `MeshRenderer(MeshRasterizer, SoftPhongShader)` built from the UNMODIFIED
+reference classes runs on them end to end:
+
+    renderer.mesh.rasterize_meshes.rasterize_meshes           -> fused gather + rasterizer (+ HIP clipping), one autograd node
+    renderer.mesh.clip.clip_faces / convert_clipped_...       -> csrc/clip.hip
+    renderer.blending.softmax_rgb_blend / hard_rgb_blend      -> csrc/blend.hip
+    renderer.mesh.shading.phong_shading / flat_shading / gouraud_shading -> csrc/shade.hip (+ interp.hip)
+    renderer.mesh.textures.TexturesUV / TexturesAtlas .sample_textures   -> csrc/texture*.hip, atlas.hip
+
+Every replacement falls back to the reference's own function for inputs the fused kernels do not cover (CPU tensors,
+colour widths other than 3, light classes other than Point / Directional / Ambient, padding modes grid_sample has and
+the kernels do not).  The names are replaced in every loaded `pytorch3d.*` module that imported them (`from .x import
+f` copies), `uninstall_python_patches()` restores them.
 """
 import sys
 import types
@@ -39,17 +56,201 @@ def make_module():
     return mod
 
 
-def install(reference_root=None):
-    """Register the shim (idempotent).  Returns the module object."""
+def install(reference_root=None, patch_python=False):
+    """Register the shim (idempotent).  Returns the module object.  patch_python: see the module docstring."""
     if reference_root is not None and reference_root not in sys.path:
         sys.path.insert(0, reference_root)
     existing = sys.modules.get("pytorch3d._C")
     if existing is not None and getattr(existing, "__p3d_amd__", False):
-        return existing
-    mod = make_module()
-    mod.__p3d_amd__ = True
-    sys.modules["pytorch3d._C"] = mod
-    pkg = sys.modules.get("pytorch3d")
-    if pkg is not None:
-        setattr(pkg, "_C", mod)
+        mod = existing
+    else:
+        mod = make_module()
+        mod.__p3d_amd__ = True
+        sys.modules["pytorch3d._C"] = mod
+        pkg = sys.modules.get("pytorch3d")
+        if pkg is not None:
+            setattr(pkg, "_C", mod)
+    if patch_python:
+        patch_reference_python()
     return mod
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# patch_python: the reference's torch formulations around the operator surface -> the fused kernels (SURVEY 8(f))
+# ---------------------------------------------------------------------------------------------------------------------
+_PATCHED = []  # (owner object, attribute name, original, replacement)
+PATCH_CALLS = {}  # name -> [fused calls, fallback calls]: what actually ran (read by tests/run_reference_suite.py)
+
+
+def _count(name, fused):
+    c = PATCH_CALLS.setdefault(name, [0, 0])
+    c[0 if fused else 1] += 1
+
+
+def _replace_everywhere(orig, new):
+    """Rebind every `pytorch3d.*` module attribute that IS `orig` (the defining module and all `from x import f` copies)."""
+    for mname, mod in list(sys.modules.items()):
+        if mod is None or not (mname == "pytorch3d" or mname.startswith("pytorch3d.")):
+            continue
+        for attr, val in list(vars(mod).items()):
+            if val is orig:
+                setattr(mod, attr, new)
+                _PATCHED.append((mod, attr, orig, new))
+
+
+def _is_hip_f32(t):
+    import torch
+
+    return torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32
+
+
+def _fragments_ok(fragments):
+    import torch
+
+    p2f = getattr(fragments, "pix_to_face", None)
+    return (torch.is_tensor(p2f) and p2f.is_cuda and p2f.dtype == torch.int64 and p2f.dim() == 4
+            and _is_hip_f32(getattr(fragments, "bary_coords", None)))
+
+
+_FUSED_LIGHTS = ("PointLights", "DirectionalLights", "AmbientLights")
+
+
+def _shading_ok(meshes, fragments, lights, cameras, materials, colors=None):
+    if not _fragments_ok(fragments) or type(lights).__name__ not in _FUSED_LIGHTS:
+        return False
+    if colors is not None and not (_is_hip_f32(colors) and colors.shape[-1] == 3 and colors.dim() == 5):
+        return False
+    if not all(hasattr(materials, a) for a in ("ambient_color", "diffuse_color", "specular_color", "shininess")):
+        return False
+    if not hasattr(cameras, "get_camera_center"):
+        return False
+    v = meshes.verts_packed()
+    return _is_hip_f32(v) and v.device == fragments.pix_to_face.device
+
+
+def patch_reference_python():
+    """Idempotent.  The reference package must be importable (install(reference_root) or an installed pytorch3d)."""
+    if _PATCHED:
+        return
+    import importlib
+
+    from . import blending as our_blend
+    from . import clip as our_clip
+    from . import rasterize_meshes as our_rm
+    from . import shading as our_shade
+    from . import textures as our_tex
+
+    rm = importlib.import_module("pytorch3d.renderer.mesh.rasterize_meshes")
+    clip = importlib.import_module("pytorch3d.renderer.mesh.clip")
+    blend = importlib.import_module("pytorch3d.renderer.blending")
+    shading = importlib.import_module("pytorch3d.renderer.mesh.shading")
+    textures = importlib.import_module("pytorch3d.renderer.mesh.textures")
+    importlib.import_module("pytorch3d.renderer")  # every module that copied the names must be loaded before rebinding
+
+    def wrap(name, orig, ours, usable):
+        def patched(*args, **kwargs):
+            ok = False
+            try:
+                ok = bool(usable(*args, **kwargs))
+            except Exception:  # an argument form the probe does not understand: the reference's own code decides
+                ok = False
+            _count(name, ok)
+            return ours(*args, **kwargs) if ok else orig(*args, **kwargs)
+
+        patched.__name__ = getattr(orig, "__name__", name)
+        patched.__doc__ = getattr(orig, "__doc__", None)
+        patched.__wrapped__ = orig
+        patched.__p3d_amd__ = True
+        return patched
+
+    # rasterize_meshes(meshes, image_size, blur_radius, faces_per_pixel, bin_size, max_faces_per_bin, perspective_correct,
+    #                  clip_barycentric_coords, cull_backfaces, z_clip_value, cull_to_frustum): rasterize_meshes.py:32-250
+    def rm_ok(meshes, *a, **k):
+        return _is_hip_f32(meshes.verts_packed()) and meshes.faces_packed().is_cuda
+
+    _replace_everywhere(rm.rasterize_meshes, wrap("rasterize_meshes", rm.rasterize_meshes, our_rm.rasterize_meshes, rm_ok))
+
+    # clip.py:324-734
+    def clip_ok(face_verts_unclipped, *a, **k):
+        return _is_hip_f32(face_verts_unclipped)
+
+    _replace_everywhere(clip.clip_faces, wrap("clip_faces", clip.clip_faces, our_clip.clip_faces, clip_ok))
+
+    def conv_ok(pix_to_face_clipped, bary_coords_clipped, clipped_faces):
+        return pix_to_face_clipped.is_cuda and _is_hip_f32(bary_coords_clipped)
+
+    _replace_everywhere(clip.convert_clipped_rasterization_to_original_faces,
+                        wrap("convert_clipped_rasterization_to_original_faces", clip.convert_clipped_rasterization_to_original_faces,
+                             our_clip.convert_clipped_rasterization_to_original_faces, conv_ok))
+
+    # blending.py:54-88, 147-244
+    def blend_ok(colors, fragments, blend_params, **k):
+        import torch
+
+        p2f = fragments.pix_to_face
+        return (_is_hip_f32(colors) and colors.dim() == 5 and colors.shape[-1] == 3 and p2f.is_cuda
+                and p2f.dtype == torch.int64 and tuple(colors.shape[:4]) == tuple(p2f.shape) and p2f.shape[3] >= 1)
+
+    def soft_ok(colors, fragments, blend_params, znear=1.0, zfar=100):
+        return blend_ok(colors, fragments, blend_params) and _is_hip_f32(fragments.dists) and _is_hip_f32(fragments.zbuf)
+
+    _replace_everywhere(blend.softmax_rgb_blend, wrap("softmax_rgb_blend", blend.softmax_rgb_blend, our_blend.softmax_rgb_blend, soft_ok))
+    _replace_everywhere(blend.hard_rgb_blend, wrap("hard_rgb_blend", blend.hard_rgb_blend, our_blend.hard_rgb_blend, blend_ok))
+
+    # shading.py:100-225
+    def phong_ok(meshes, fragments, lights, cameras, materials, texels):
+        return _shading_ok(meshes, fragments, lights, cameras, materials, texels)
+
+    def gouraud_ok(meshes, fragments, lights, cameras, materials):
+        tex = getattr(meshes, "textures", None)
+        return (type(tex).__name__ == "TexturesVertex" and _shading_ok(meshes, fragments, lights, cameras, materials)
+                and tex.verts_features_packed().shape[-1] == 3)
+
+    _replace_everywhere(shading.phong_shading, wrap("phong_shading", shading.phong_shading, our_shade.phong_shading, phong_ok))
+    _replace_everywhere(shading.flat_shading, wrap("flat_shading", shading.flat_shading, our_shade.flat_shading, phong_ok))
+    _replace_everywhere(shading.gouraud_shading, wrap("gouraud_shading", shading.gouraud_shading, our_shade.gouraud_shading, gouraud_ok))
+
+    # TexturesUV.sample_textures (textures.py:1190-1313), TexturesAtlas.sample_textures (textures.py:565-612): methods
+    import torch
+
+    uv_orig = textures.TexturesUV.sample_textures
+
+    def uv_sample(self, fragments, **kwargs):
+        ok = (_fragments_ok(fragments) and not self.isempty() and self.padding_mode in our_tex._PAD
+              and self.sampling_mode in our_tex._MODE and _is_hip_f32(self.maps_padded())
+              and self.maps_padded().device == fragments.pix_to_face.device)
+        ids = self.maps_ids_padded() if ok and hasattr(self, "maps_ids_padded") else None
+        if ok and ids is not None and self.maps_padded().shape[1] < 2:
+            ok = False
+        _count("TexturesUV.sample_textures", ok)
+        if not ok:
+            return uv_orig(self, fragments, **kwargs)
+        faces_verts_uvs = torch.cat([i[j] for i, j in zip(self.verts_uvs_list(), self.faces_uvs_list())])  # textures.py:1218-1221
+        return our_tex.sample_textures_uv(fragments, faces_verts_uvs.to(torch.float32), self.maps_padded(), align_corners=self.align_corners,
+                                          padding_mode=self.padding_mode, sampling_mode=self.sampling_mode, maps_ids=ids)
+
+    uv_sample.__wrapped__ = uv_orig
+    textures.TexturesUV.sample_textures = uv_sample
+    _PATCHED.append((textures.TexturesUV, "sample_textures", uv_orig, uv_sample))
+
+    atlas_orig = textures.TexturesAtlas.sample_textures
+
+    def atlas_sample(self, fragments, **kwargs):
+        ok = _fragments_ok(fragments) and not self.isempty()
+        at = self.atlas_packed() if ok else None
+        ok = ok and _is_hip_f32(at) and at.device == fragments.pix_to_face.device and at.shape[1] >= 1 and at.shape[3] >= 1
+        _count("TexturesAtlas.sample_textures", ok)
+        if not ok:
+            return atlas_orig(self, fragments, **kwargs)
+        return our_tex.sample_textures_atlas(fragments, at)
+
+    atlas_sample.__wrapped__ = atlas_orig
+    textures.TexturesAtlas.sample_textures = atlas_sample
+    _PATCHED.append((textures.TexturesAtlas, "sample_textures", atlas_orig, atlas_sample))
+
+
+def uninstall_python_patches():
+    """Put the reference's own functions back (the `_C` module stays installed)."""
+    while _PATCHED:
+        owner, attr, orig, _new = _PATCHED.pop()
+        setattr(owner, attr, orig)

@@ -32,8 +32,7 @@ static void raster_pixel(const float* fv, const int64_t* nbr, int64_t f0, int64_
         continue;
       FaceRec fr;
       face_rec_make(v0, v1, v2, &fr);
-      // rect[4] != 0: the packed-arithmetic form of the same test (p3d_geom.h: face_hit_rec_pk)
-      if (!(rect[4] != 0.0f ? face_hit_rec_pk(fr, p, blur, persp, clip, &h) : face_hit_rec(fr, p, blur, persp, clip, &h))) continue;
+      if (!face_hit_rec(fr, p, blur, persp, clip, &h)) continue;
     } else if (!face_hit(v0, v1, v2, p, blur, persp, clip, &h)) {
       continue;
     }
@@ -78,7 +77,7 @@ extern "C" int hg_rasterize_meshes(const float* fv, const int64_t* first, const 
         const int64_t o = (((int64_t)n * H + yo) * W + xo) * K;
         const int64_t f0 = first[n], f1 = first[n] + count[n];
         // use_mem bit 1: the fast path, with the 8x8 pixel block around the pixel as the culling rectangle
-        float rect_v[5];  // x0, x1, y0, y1, packed-arithmetic flag (use_mem bit 2)
+        float rect_v[4];  // x0, x1, y0, y1
         const float* rect = nullptr;
         if (use_mem & 2) {
           const int bx0 = xi & ~7, by0 = yi & ~7;
@@ -87,7 +86,6 @@ extern "C" int hg_rasterize_meshes(const float* fv, const int64_t* first, const 
           rect_v[1] = pix_to_ndc(bx1, W, H);
           rect_v[2] = pix_to_ndc(by0, H, W);
           rect_v[3] = pix_to_ndc(by1, H, W);
-          rect_v[4] = (use_mem & 4) ? 1.0f : 0.0f;
           rect = rect_v;
         }
         if (!(use_mem & 1) && K <= 8) {
@@ -116,12 +114,9 @@ extern "C" int hg_rasterize_meshes_backward(const float* fv, const int64_t* p2f,
           const int64_t f = p2f[i];
           if (f < 0) continue;
           const float* g = fv + f * 9;
-          // clip_on_corrected bit 1: the packed-arithmetic form (p3d_geom.h: face_sample_bwd_pk)
           const f3 w0 = mk3(g[0], g[1], g[2]), w1 = mk3(g[3], g[4], g[5]), w2 = mk3(g[6], g[7], g[8]);
           const f3 gbv = mk3(gb[i * 3], gb[i * 3 + 1], gb[i * 3 + 2]);
-          const FaceGrad r = (clip_on_corrected & 2)
-                                 ? face_sample_bwd_pk(w0, w1, w2, p, gz[i], gbv, gd[i], persp, clip, (clip_on_corrected & 1) != 0)
-                                 : face_sample_bwd(w0, w1, w2, p, gz[i], gbv, gd[i], persp, clip, (clip_on_corrected & 1) != 0);
+          const FaceGrad r = face_sample_bwd(w0, w1, w2, p, gz[i], gbv, gd[i], persp, clip, (clip_on_corrected & 1) != 0);
           for (int j = 0; j < 9; ++j) acc[f * 9 + j] += (double)r.g[j];
         }
       }
