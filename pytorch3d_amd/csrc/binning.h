@@ -55,11 +55,24 @@ inline BinGeom make_internal_geom(int H, int W, int user_bin_size) {
   return make_geom(H, W, b);
 }
 
+// Which bins hold primitives ("active") and which are background, written by the offsets scan at no extra launch:
+//   arank[row]  number of active rows before `row`          (valid for every row)
+//   bg_list[j]  the j-th background row, ascending           (j < hdr[1])
+//   hdr         {A = active rows, B = background rows}
+// The fine rasterizers use it to let the workgroups of active tiles write the -1 fill of the background tiles
+// (raster_mesh.hip: "piggyback fill"): active row number r fills background rows [r * q, (r + 1) * q), q = ceil(B / A).
+struct TilePlan {
+  const int* arank;
+  const int* bg_list;
+  const int* hdr;
+};
+
 // Device-side CSR view consumed by the fine kernels.
 struct BinCSR {
   const int64_t* offset;  // (N*nbins) start of each bin's list inside `list`
   const int* total;       // (N*nbins) entries in each bin's list
   const int* list;        // primitive ids (packed, global), ascending per bin
+  TilePlan plan;          // null pointers when the lists did not come from bin_build (user-supplied bins)
 };
 
 struct BinWorkspace {
@@ -69,6 +82,9 @@ struct BinWorkspace {
   int64_t* offset;   // (N*nbins + 1)
   long long* blocksum;  // (ceil(N*nbins / 1024) + 1) scratch of the offsets scan
   int* list;         // (capacity)
+  int* arank;        // (N*nbins)  TilePlan
+  int* bg_list;      // (N*nbins)
+  int* plan_hdr;     // (2)
   int64_t max_chunks;
   int64_t capacity;
 };

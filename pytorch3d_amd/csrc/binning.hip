@@ -266,7 +266,21 @@ __global__ __launch_bounds__(256) void bin_scan_rows_kernel(int* __restrict__ co
 //   A  one workgroup per 1024 rows: block sum -> blocksum[b]
 //   B  the same grid: base = sum of the preceding block sums (<= rows/1024 coalesced adds per
 //      thread), then a local exclusive scan of the block's 1024 rows.
+// The scans carry the tile plan (binning.h: TilePlan) along for free: every row contributes total + (active << 40), so
+// the low 40 bits of the running sum are the list offset (list capacities are far below 2^40 entries) and the bits
+// above count the active rows before it.
 // ---------------------------------------------------------------------------------------
+constexpr int kPlanShift = 40;
+constexpr long long kPlanMask = (1ll << kPlanShift) - 1;
+__device__ __forceinline__ long long plan_pack(int total) { return (long long)total + (total > 0 ? (1ll << kPlanShift) : 0ll); }
+// row `i` with running exclusive sum `ex` (packed) and own count `v`: offset, active rank, background list entry
+__device__ __forceinline__ void plan_emit(int64_t i, long long ex, int v, int64_t* offset, int* arank, int* bg_list) {
+  offset[i] = ex & kPlanMask;
+  const int r = (int)(ex >> kPlanShift);
+  arank[i] = r;
+  if (v <= 0) bg_list[i - r] = (int)i;
+}
+
 __device__ __forceinline__ long long block_exclusive_scan_1024(long long v, long long* wsum, long long* block_total) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   long long x = v;
@@ -291,13 +305,14 @@ __global__ __launch_bounds__(1024) void bin_block_sums_kernel(const int* __restr
   __shared__ long long wsum[16];
   const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
   long long all;
-  block_exclusive_scan_1024(i < rows ? total[i] : 0, wsum, &all);
+  block_exclusive_scan_1024(i < rows ? plan_pack(total[i]) : 0, wsum, &all);
   if (threadIdx.x == 0) blocksum[blockIdx.x] = all;
 }
 
 __global__ __launch_bounds__(1024) void bin_scan_offsets_kernel(const int* __restrict__ total, int64_t rows,
                                                                 const long long* __restrict__ blocksum,
-                                                                int64_t* __restrict__ offset) {
+                                                                int64_t* __restrict__ offset, int* __restrict__ arank,
+                                                                int* __restrict__ bg_list, int* __restrict__ plan_hdr) {
   __shared__ long long wsum[16];
   __shared__ long long part[16];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -312,9 +327,21 @@ __global__ __launch_bounds__(1024) void bin_scan_offsets_kernel(const int* __res
   const int64_t i = (int64_t)blockIdx.x * 1024 + tid;
   const int v = i < rows ? total[i] : 0;
   long long all;
-  const long long ex = block_exclusive_scan_1024(v, wsum, &all);
-  if (i < rows) offset[i] = base + ex;
-  if (i == rows - 1) offset[rows] = base + ex + v;
+  const long long ex = block_exclusive_scan_1024(i < rows ? plan_pack(v) : 0, wsum, &all);
+  if (i < rows) {
+    if (arank)
+      plan_emit(i, base + ex, v, offset, arank, bg_list);
+    else
+      offset[i] = (base + ex) & kPlanMask;
+  }
+  if (i == rows - 1) {
+    const long long end = base + ex + plan_pack(v);
+    offset[rows] = end & kPlanMask;
+    if (plan_hdr) {
+      plan_hdr[0] = (int)(end >> kPlanShift);
+      plan_hdr[1] = (int)(rows - (end >> kPlanShift));
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -324,7 +351,8 @@ __global__ __launch_bounds__(1024) void bin_scan_offsets_kernel(const int* __res
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void bin_scan_small_kernel(int* __restrict__ counts, const int64_t* __restrict__ count,
                                                               int N, int nbins, int M, int* __restrict__ total,
-                                                              int64_t* __restrict__ offset) {
+                                                              int64_t* __restrict__ offset, int* __restrict__ arank,
+                                                              int* __restrict__ bg_list, int* __restrict__ plan_hdr) {
   __shared__ int cs[kSelfPlanMax + 1];
   __shared__ long long wsum[16];
   plan_in_lds(count, N, cs);
@@ -348,12 +376,16 @@ __global__ __launch_bounds__(1024) void bin_scan_small_kernel(int* __restrict__ 
       total[row] = t;
     }
     long long all;
-    const long long ex = block_exclusive_scan_1024(t, wsum, &all);
-    if (row < rows) offset[row] = carry + ex;
+    const long long ex = block_exclusive_scan_1024(row < rows ? plan_pack(t) : 0, wsum, &all);
+    if (row < rows) plan_emit(row, carry + ex, t, offset, arank, bg_list);
     carry += all;
     __syncthreads();  // wsum is rewritten by the next step
   }
-  if (tid == 0) offset[rows] = carry;
+  if (tid == 0) {
+    offset[rows] = carry & kPlanMask;
+    plan_hdr[0] = (int)(carry >> kPlanShift);
+    plan_hdr[1] = (int)(rows - (carry >> kPlanShift));
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -487,6 +519,9 @@ bool bin_carve(Arena& arena, int64_t E, int N, const BinGeom& g, int M, BinWorks
   ws->offset = arena.take<int64_t>((size_t)N * g.nbins + 1);
   ws->blocksum = arena.take<long long>((size_t)ceil_div((int64_t)N * g.nbins, 1024) + 1);
   ws->list = arena.take<int>((size_t)ws->capacity);
+  ws->arank = arena.take<int>((size_t)N * g.nbins);
+  ws->bg_list = arena.take<int>((size_t)N * g.nbins);
+  ws->plan_hdr = arena.take<int>(2);
   return arena.ok();
 }
 
@@ -523,7 +558,8 @@ int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t*
   }
   if (small) {
     LaunchScope ls("bin_scan_small", stream);
-    bin_scan_small_kernel<<<1, 1024, 0, stream>>>(ws.counts, count, N, g.nbins, M, ws.total, ws.offset);
+    bin_scan_small_kernel<<<1, 1024, 0, stream>>>(ws.counts, count, N, g.nbins, M, ws.total, ws.offset, ws.arank, ws.bg_list,
+                                                  ws.plan_hdr);
   } else {
     {
       LaunchScope ls("bin_scan_rows", stream);
@@ -533,7 +569,7 @@ int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t*
     LaunchScope ls("bin_scan_offsets", stream);
     const unsigned nb = (unsigned)ceil_div(rows, 1024);
     bin_block_sums_kernel<<<nb, 1024, 0, stream>>>(ws.total, rows, ws.blocksum);
-    bin_scan_offsets_kernel<<<nb, 1024, 0, stream>>>(ws.total, rows, ws.blocksum, ws.offset);
+    bin_scan_offsets_kernel<<<nb, 1024, 0, stream>>>(ws.total, rows, ws.blocksum, ws.offset, ws.arank, ws.bg_list, ws.plan_hdr);
   }
   {
     LaunchScope ls("bin_fill", stream);
@@ -557,7 +593,7 @@ int exclusive_scan_i32(const int* in, int64_t n, long long* blocksum, int64_t* o
   if (n <= 0) return P3D_OK;
   const unsigned nb = (unsigned)ceil_div(n, 1024);
   bin_block_sums_kernel<<<nb, 1024, 0, stream>>>(in, n, blocksum);
-  bin_scan_offsets_kernel<<<nb, 1024, 0, stream>>>(in, n, blocksum, out);
+  bin_scan_offsets_kernel<<<nb, 1024, 0, stream>>>(in, n, blocksum, out, nullptr, nullptr, nullptr);
   return launch_status();
 }
 

@@ -501,12 +501,21 @@ P3D_HD f3 bary_clip_bwd(f3 b, f3 g) {
   const float m1 = b.y < 0.0f ? 0.0f : 1.0f;
   const float m2 = b.z < 0.0f ? 0.0f : 1.0f;
   const float inv = qdiv<true>(1.0f, s);
-  const float inv_s2 = inv * inv;
-  const float q0 = -w0 * inv_s2 * live;
-  const float q1 = -w1 * inv_s2 * live;
-  const float q2 = -w2 * inv_s2 * live;
-  return mk3(m0 * (g.x * (inv + q0) + g.y * q1 + g.z * q2), m1 * (g.y * (inv + q1) + g.x * q0 + g.z * q2),
-             m2 * (g.z * (inv + q2) + g.x * q0 + g.y * q1));
+  const float inv_s2 = inv * inv * live;
+  const float q0 = -w0 * inv_s2;
+  const float q1 = -w1 * inv_s2;
+  const float q2 = -w2 * inv_s2;
+  // d clip_k / d w_k = 1 / s - w_k / s^2.  The reference forms it as that DIFFERENCE of two correctly rounded quotients
+  // (geometry_utils.cuh:313-327), which is exactly 0 when w_k is the only coordinate left after clipping (the clipped
+  // barycentrics are then the constant (0, 0, 1)): 1 / s and w_k / s^2 round to the same float.  With a reciprocal
+  // estimate the two terms no longer cancel, and what is left (1e-7 / s) meets the 1e16 of a perspective denominator
+  // clamped at 1e-8 in the blur band of faces seen nearly edge-on: gradients of 1e15 where the reference has 0 (found in
+  // round 3 on 0.4 % of the faces of the bench batch, once the comparison was made per face).  Written as the sum of the
+  // OTHER two coordinates over s^2 the term is exact in that case and carries no cancellation in any other.
+  const float c0 = live != 0.0f ? (w1 + w2) * inv_s2 : inv;
+  const float c1 = live != 0.0f ? (w0 + w2) * inv_s2 : inv;
+  const float c2 = live != 0.0f ? (w0 + w1) * inv_s2 : inv;
+  return mk3(m0 * (g.x * c0 + g.y * q1 + g.z * q2), m1 * (g.y * c1 + g.x * q0 + g.z * q2), m2 * (g.z * c2 + g.x * q0 + g.y * q1));
 }
 
 struct SegGrad {

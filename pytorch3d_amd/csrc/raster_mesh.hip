@@ -257,6 +257,34 @@ __device__ __forceinline__ void fill_tile_background(const MeshArgs& a, int n, i
   }
 }
 
+// A full 16x16 background tile with K = KT, KT % 4 == 0: thread (row = tid / 16, c = tid % 16) owns the 16-byte pieces
+// c, c + 16, ... of its row of each output -- four base pointers, then KT/4 + KT/4 + 3 KT/4 + KT/2 stores at constant
+// offsets (K = 8: 14 stores and ~25 VALU per thread; the generic loop above spends ~15 VALU per store on choosing the
+// output).  A wave's store covers four rows x 256 contiguous bytes.  This is what an ACTIVE workgroup runs for the
+// background tiles it has been dealt (piggyback fill, see the kernel).
+template <int KT>
+__device__ __forceinline__ void fill_tile_full(const MeshArgs& a, int n, int ty0, int tx0, int tid) {
+  static_assert(KT % 4 == 0, "16-byte pieces");
+  const int H = a.H, W = a.W;
+  const int r = tid >> 4, c = tid & 15;
+  const int64_t px = ((int64_t)n * H + (H - 1 - (ty0 + r))) * W + (W - tx0 - kTile);  // outputs are stored flipped
+  constexpr int Q = KT / 4;  // pieces per 16 pixels of zbuf, in units of 16 lanes
+  char* zb = reinterpret_cast<char*>(a.zbuf + px * KT) + c * 16;
+  char* db = reinterpret_cast<char*>(a.dists + px * KT) + c * 16;
+  char* bb = reinterpret_cast<char*>(a.bary + px * KT * 3) + c * 16;
+  char* ib = reinterpret_cast<char*>(a.p2f + px * KT) + c * 16;
+  const unsigned m1 = 0xbf800000u, i1 = ~0u;
+#pragma unroll
+  for (int i = 0; i < Q; ++i) {
+    store16(zb + i * 256, m1, m1, m1, m1);
+    store16(db + i * 256, m1, m1, m1, m1);
+  }
+#pragma unroll
+  for (int i = 0; i < 3 * Q; ++i) store16(bb + i * 256, m1, m1, m1, m1);
+#pragma unroll
+  for (int i = 0; i < 2 * Q; ++i) store16(ib + i * 256, i1, i1, i1, i1);
+}
+
 // Staged face in LDS: five 16-byte words, each read by a wave as one broadcast (all lanes, same address).
 //   [0] v0x v0y v1x v1y   [1] v2x v2y z0 z1   [2] z2 fid nb wide   [3] rd_area, rd_l01 (doubles)   [4] rd_l02, rd_l12
 constexpr int kRecWords = 5;
@@ -532,9 +560,22 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
     src_base = a.mesh_first[n];
     count = (int)a.mesh_count[n];
   }
+  // Piggyback fill.  Tiles without faces ("background", 3 of 5 at the bench workload) are pure -1 stores, but a workgroup
+  // that only stores still occupies a full slot of this kernel (256 threads x 128 registers; the chip holds 1024) for
+  // ~5.6 us -- 0.2 ms of a 1.5 ms launch were slots held by background tiles (profiles/r02_ablate_fwd.txt: tiles with
+  // faces alone 1.3 ms).  With the tile plan of the offsets scan (binning.h: TilePlan) the ACTIVE workgroups issue those
+  // stores instead, at the end of their own work (fire and forget: ~40 instructions per tile, fill_tile_full), and a
+  // background workgroup returns at once.  Active row number r takes background rows [r q, (r + 1) q), q = ceil(B / A).
+  const bool piggy = BINNED && !SPLIT && EXACT && (KT & 3) == 0 && a.csr.plan.hdr != nullptr;
+  int plan_a = 0, plan_b = 0;
+  if (piggy) {
+    plan_a = a.csr.plan.hdr[0];
+    plan_b = a.csr.plan.hdr[1];
+  }
   if (count <= 0) {
+    if (piggy && plan_a > 0) return;  // an active workgroup writes this tile (uniform)
     const int Kbg = EXACT ? KT : a.K;  // compile-time where it can be: the row-fill branch is then the only one left
-    // background tile (3 of 5 at the bench workload): nothing but the -1 stores; skip the NDC set-up below
+    // background tile: nothing but the -1 stores; skip the NDC set-up below
     if (SPLIT && (Kbg & 3) == 0) {
       fill_tile_background<kStage>(a, n, sy0, sx0, y_end, x_end, tid, 8);
     } else if (SPLIT && w != 0) {
@@ -641,6 +682,27 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
       }
     } else {
       if (wave_ok) write_subtile_fill_patch<Queue, KT, IN_REGS>(a, q, true, n, sy0, sx0, y_end, x_end, lane, pix_ok, yi, xi);
+    }
+  }
+  if constexpr (BINNED && !SPLIT && EXACT && (KT & 3) == 0) {
+    if (piggy && plan_b > 0) {
+      const int64_t row = ((int64_t)n * a.tm.BH + by) * a.tm.BW + bx;
+      const int q_bg = (plan_b + plan_a - 1) / plan_a;
+      const long long j0 = (long long)a.csr.plan.arank[row] * q_bg;
+      const long long j1 = j0 + q_bg < (long long)plan_b ? j0 + q_bg : (long long)plan_b;
+      const int per_image = a.tm.BH * a.tm.BW;
+      for (long long j = j0; j < j1; ++j) {  // uniform: scalar loads and arithmetic
+        const int brow = a.csr.plan.bg_list[j];
+        const int bn = brow / per_image, brem = brow - bn * per_image;
+        const int bby = brem / a.tm.BW, bbx = brem - bby * a.tm.BW;
+        const int by_end = min(H, (bby + 1) * a.tm.bin_size), bx_end = min(W, (bbx + 1) * a.tm.bin_size);
+        const int bty0 = bby * a.tm.bin_size + ty * kTile, btx0 = bbx * a.tm.bin_size + tx * kTile;  // the same tile of that bin
+        if (bty0 >= by_end || btx0 >= bx_end) continue;
+        if (bty0 + kTile <= by_end && btx0 + kTile <= bx_end)
+          fill_tile_full<KT>(a, bn, bty0, btx0, tid);
+        else
+          fill_tile_background<kStage>(a, bn, bty0, btx0, by_end, bx_end, tid);
+      }
     }
   }
 }
@@ -815,7 +877,7 @@ P3D_API int p3d_rasterize_meshes(const float* face_verts, const int64_t* mesh_fi
   int st = bin_build(kTriangles, face_verts, nullptr, mesh_first, mesh_count, F, N, g, max_faces_per_bin,
                      sqrtf(blur_radius), ws, s);
   if (st != P3D_OK) return st;
-  BinCSR csr{ws.offset, ws.total, ws.list};
+  BinCSR csr{ws.offset, ws.total, ws.list, TilePlan{ws.arank, ws.bg_list, ws.plan_hdr}};
   return mesh_fine_from_csr(face_verts, neighbor, csr, N, H, W, g, blur_radius, K, persp, clip, cull, p2f, zbuf, bary,
                             dists, s);
 }
@@ -869,7 +931,7 @@ P3D_API int p3d_rasterize_meshes_fine(const float* face_verts, const int32_t* bi
   g.BH = BH;
   g.BW = BW;
   g.nbins = BH * BW;
-  BinCSR csr{offset, total, list};
+  BinCSR csr{offset, total, list, TilePlan{nullptr, nullptr, nullptr}};
   return mesh_fine_from_csr(face_verts, neighbor, csr, N, H, W, g, blur_radius, K, persp, clip, cull, p2f, zbuf, bary,
                             dists, s);
 }

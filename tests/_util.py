@@ -255,3 +255,123 @@ def scatter_face_grads(gfa, faces, V, lo, hi):
     out = torch.zeros(V, hi - lo, dtype=torch.float64)
     out.index_add_(0, faces.reshape(-1), gfa[:, :, lo:hi].reshape(-1, hi - lo).double())
     return out.float()
+
+
+# ---------------------------------------------------------------------------------------------
+# gradient comparison (mesh rasterizer backward)
+# ---------------------------------------------------------------------------------------------
+def per_item_rel_dev(got, want):
+    """Per item (dim 0: a face's (3,3) partials, a vertex's xyz): max |got - want| relative to the item's largest |want|
+    component (+ a floor at 1e-6 of the median item magnitude).  A tolerance scaled by the GLOBAL maximum is vacuous on
+    batches that hold faces seen nearly edge-on, whose gradients reach 1e24 (1 / area^2).  -> (deviation (items,),
+    item magnitude (items,))."""
+    g = got.reshape(got.shape[0], -1)
+    w = want.reshape(want.shape[0], -1)
+    per = w.abs().amax(1)
+    nz = per[per > 0]
+    floor = 1e-6 * float(nz.median()) if nz.numel() else 1e-30
+    return (g - w).abs().amax(1) / (per + floor), per
+
+
+def faces_with_singular_perspective(face_verts, pix_to_face, rel=1e-4):
+    """Faces that own at least one (pixel, k) sample whose perspective-correction denominator
+    t0 + t1 + t2 = bw.x z1 z2 + z0 bw.y z2 + z0 z1 bw.z (geometry_utils.cuh:172-185) is clamped at 1e-8 or nearly cancels
+    (below `rel` of |t0| + |t1| + |t2|): pixels in the blur band far outside a face seen nearly edge-on.  There the backward
+    divides by denom^2 (up to 1e16) what is mathematically a ZERO gradient of constant clipped barycentrics; the
+    reference's own result is the rounding residue of `1 / s - w / s^2` (geometry_utils.cuh:313-327) times that factor:
+    0 or 1e15 depending on how two float quotients happen to round (its CPU and device builds disagree with each other
+    on such samples).  Gradients of these faces are reported, not compared.  -> bool (F,)."""
+    N, H, W, K = pix_to_face.shape
+    idx = (pix_to_face >= 0).nonzero()
+    f = pix_to_face[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]]
+    fv = face_verts[f]
+
+    def ndc(i, S1, S2):  # rasterization_utils.cuh:16-42
+        rng = 2.0 * S1 / S2 if S1 > S2 else 2.0
+        return -rng / 2.0 + (rng * i.to(torch.float32) + rng / 2.0) / S1
+
+    px = ndc(W - 1 - idx[:, 2], W, H)
+    py = ndc(H - 1 - idx[:, 1], H, W)
+    a, b, c = fv[:, 0], fv[:, 1], fv[:, 2]
+
+    def edge(ux, uy, vx, vy):
+        return (px - ux) * (vy - uy) - (py - uy) * (vx - ux)
+
+    area = (c[:, 0] - a[:, 0]) * (b[:, 1] - a[:, 1]) - (c[:, 1] - a[:, 1]) * (b[:, 0] - a[:, 0]) + 1e-8
+    w0 = edge(b[:, 0], b[:, 1], c[:, 0], c[:, 1]) / area
+    w1 = edge(c[:, 0], c[:, 1], a[:, 0], a[:, 1]) / area
+    w2 = edge(a[:, 0], a[:, 1], b[:, 0], b[:, 1]) / area
+    t0, t1, t2 = w0 * b[:, 2] * c[:, 2], a[:, 2] * w1 * c[:, 2], a[:, 2] * b[:, 2] * w2
+    den = t0 + t1 + t2
+    sing = (den <= 1e-7) | (den < rel * (t0.abs() + t1.abs() + t2.abs()))
+    out = torch.zeros(face_verts.shape[0], dtype=torch.bool, device=face_verts.device)
+    out[f[sing]] = True
+    return out
+
+
+def face_grad_truth(face_verts, pix_to_face, grad_zbuf, grad_bary, grad_dists, persp, clip, faces=None, num_verts=None):
+    """-> (float64 gradient, per-entry scale, items flagged singular) as assert_face_grads_vs_truth uses them."""
+    from oracle.backward_f64 import backward_f64
+
+    truth, abs_sum = backward_f64(face_verts, pix_to_face, grad_zbuf, grad_bary, grad_dists, persp, clip)
+    sing = faces_with_singular_perspective(face_verts, pix_to_face)
+    if faces is not None:
+        V = int(num_verts)
+        tv = torch.zeros((V, 3), dtype=torch.float64, device=truth.device)
+        sv = torch.zeros((V, 3), dtype=torch.float64, device=truth.device)
+        tv.index_add_(0, faces.reshape(-1), truth.reshape(-1, 3))
+        sv.index_add_(0, faces.reshape(-1), abs_sum.reshape(-1, 3))
+        sg = torch.zeros((V,), dtype=torch.float64, device=truth.device)
+        sg.index_add_(0, faces.reshape(-1), sing.double().repeat_interleave(3))
+        truth, abs_sum, sing = tv, sv, sg > 0
+    items = truth.shape[0]
+    flat = abs_sum.reshape(items, -1)
+    nz = flat[flat > 0]
+    med = float(nz.median()) if nz.numel() else 0.0
+    scale = (flat + 1e-5 * flat.amax(1, keepdim=True)).reshape(abs_sum.shape) + 2e-4 * med + 1e-30
+    return truth, scale, sing
+
+
+def assert_face_grads_vs_truth(tag, got, face_verts, pix_to_face, grad_zbuf, grad_bary, grad_dists, persp, clip, rtol=5e-3,
+                               reference=None, faces=None, num_verts=None, truth=None):
+    """The gate of the full-size gradient checks.  `got` (F,3,3) -- or (V,3) with `faces` (F,3) / num_verts, the fused
+    vertex scatter -- against oracle/backward_f64.py: the reference's backward formulas evaluated per sample in float64.
+
+    Scale of an entry: S = (sum of the ABSOLUTE per-sample terms of that entry) + 1e-5 x (the largest such sum among the
+    item's entries) + 2e-4 x (the median entry sum of the whole tensor) -- the error scale of a float32 sum of those terms
+    in any order; the second part because a sample's partials share their intermediates, the third is an absolute floor
+    (with rtol 5e-3: one millionth of the typical entry).  rtol = 5e-3 is the reference's own gradient tolerance
+    (tests/test_rasterize_meshes.py:317-319).  An entry passes when it is within rtol x S of the float64 value, or --
+    `reference` given: another float32 implementation of the same formulas (the reference's device backward, the C oracle)
+    -- within rtol x S of that: float32 and float64 evaluations of the reference's formulas part where intermediates
+    cancel (1 / denom^2 of a small perspective denominator), identically in both float32 implementations.  Items that own
+    a sample with a (nearly) clamped perspective denominator (faces_with_singular_perspective) are reported, not gated:
+    there the reference's own value is the rounding residue of `1 / s - w / s^2` times up to 1e16
+    (oracle/backward_f64.py).  Everything is printed: achieved maxima, how many entries needed the second criterion, how
+    the reference itself fares against the float64 value."""
+    truth, scale, sing = truth if truth is not None else face_grad_truth(face_verts, pix_to_face, grad_zbuf, grad_bary, grad_dists,
+                                                                         persp, clip, faces, num_verts)
+    items = got.shape[0]
+    shape1 = (items,) + (1,) * (got.dim() - 1)
+    gated = ~sing.reshape(shape1).expand_as(scale)
+    dev = (got.double() - truth).abs() / scale
+    ok = dev <= rtol
+    msg = (f"[{tag}] {tuple(got.shape)} entries vs the float64 restatement: max |error| / scale = {float(dev[gated].max()):.2e} "
+           f"over the gated items (gate {rtol:g}), {int((~ok & gated).sum())} entries beyond it; {int(sing.sum())} of {items} items own "
+           f"a sample with a (nearly) clamped perspective denominator (reported, not gated; {int((~ok & ~gated).sum())} of their "
+           f"entries beyond the gate); largest |gradient| {float(truth.abs().max()):.2e}")
+    if reference is not None:
+        rdev = (reference.double() - truth).abs() / scale
+        both = (got.double() - reference.double()).abs() / scale
+        ok2 = both <= rtol
+        msg += (f"; the reference implementation against the same float64 values: max {float(rdev.max()):.2e}, "
+                f"{int((rdev > rtol).reshape(items, -1).any(1).sum())} items beyond the gate ({int(((rdev > rtol) & gated).reshape(items, -1).any(1).sum())} "
+                f"gated ones); entries of ours that pass only by agreeing with the reference's float32 value: {int((~ok & ok2 & gated).sum())}")
+        ok = ok | ok2
+    n_bad = int((~ok & gated).sum())
+    msg += f"; FAILING entries: {n_bad}"
+    print(msg)
+    assert n_bad == 0, msg
+    assert bool(torch.isfinite(got).all())
+    assert int(sing.sum()) <= 0.05 * items, msg
+    return float(dev[gated].max())

@@ -309,3 +309,31 @@ def test_oracle_reproduces_reference_on_the_cow_config2():
     got = orc.rasterize_meshes_backward(fv, ref[0], gz, gb, gd, True, True, cuda_semantics=False)
     assert torch.allclose(got, want, rtol=2e-3, atol=2e-4 * float(want.abs().max()))
 
+
+
+@pytest.mark.parametrize("persp,clip", [(False, False), (True, False), (False, True), (True, True)])
+def test_float64_backward_restatement_vs_c_oracle(persp, clip):
+    """oracle/backward_f64.py (the reference's backward formulas, CUDA semantics, per sample in float64 -- the yardstick
+    of the full-size GPU gradient checks) against oracle/p3d_oracle.c (float32, the reference's operation order, pinned
+    to the reference's CPU kernels above) on soups with a blur band: every face entry within 1e-4 of the sum of the
+    absolute per-sample terms.  Samples where ONE barycentric survives the clipping are where the two differ by design
+    (the C oracle keeps the reference's `1 / s - w / s^2`, whose rounding residue a clamped perspective denominator
+    multiplies by up to 1e16 -- 1e13 on one face of this soup; the float64 form is cancellation-free): the faces owning
+    such a sample (tests/_util.py: faces_with_singular_perspective) are excluded, and must be few."""
+    from oracle.backward_f64 import backward_f64
+
+    gen = torch.Generator().manual_seed(23)
+    F = 120
+    fv = U.smooth_soup(F, gen)
+    first, count = U.split_counts(F, 2)
+    nbr = torch.full((F,), -1, dtype=torch.int64)
+    fwd = orc.rasterize_meshes_naive(fv, first, count, nbr, (24, 20), 0.004, 5, persp, clip, False)
+    gz, gb, gd = (torch.randn(t.shape, generator=gen) for t in fwd[1:])
+    want = orc.rasterize_meshes_backward(fv, fwd[0], gz, gb, gd, persp, clip)
+    got, abs_sum = backward_f64(fv, fwd[0], gz, gb, gd, persp, clip)
+    assert int((fwd[0] >= 0).sum()) > 500
+    err = (got - want.double()).abs()
+    tol = 1e-4 * abs_sum + 1e-9
+    sing = U.faces_with_singular_perspective(fv, fwd[0])
+    assert int(sing.sum()) <= 3
+    assert bool((err <= tol)[~sing].all()), float((err / (abs_sum + 1e-12))[~sing].max())

@@ -11,8 +11,13 @@ hipified and compiled with -ffp-contract=off, oracle/build_ref_hip.py; ~2 s per 
   * pix_to_face differences only in slots whose depth ties exactly with a neighbouring slot of the pixel (or the last
     slot, whose tie partner was evicted): the reference's CUDA queue orders by z alone, ours by (z, index) like the
     reference's CPU / Python implementations (SURVEY appendix A "Top-K"); the count is printed;
-  * the backward of the same fragments within 5e-3 of the reference's device backward (its own test tolerance,
-    tests/test_rasterize_meshes.py:317-319), measured per face against the face's largest partial, 0 outliers.
+  * the backward of the same fragments: every entry within 5e-3 (the reference's own gradient tolerance,
+    tests/test_rasterize_meshes.py:317-319) x the sum of the absolute per-sample terms of the float64 restatement of the
+    reference's formulas (oracle/backward_f64.py), and within twice that of the reference's device backward wherever
+    the latter passes the same gate.  (A tolerance scaled by the largest gradient of the batch -- 1e24, faces seen edge-on
+    -- was vacuous; the per-face comparison that replaced it in round 3 found gradients of 1e15 where the reference has
+    0, a reciprocal estimate breaking the reference's exact cancellation `1 / s - w / s^2`: fixed in csrc/p3d_geom.h
+    bary_clip_bwd, and the cases where the reference's own value is that residue times 1e16 are now counted.)
 
 The same inputs through the L2 mirror (`pytorch3d_amd.rasterize_meshes`, what bench.py calls) must give the same bits
 as the `_C` operator (the mirror bins at its own heuristic bin_size; results do not depend on the binning).
@@ -95,15 +100,6 @@ def test_full_bench_batch_forward_and_backward_vs_reference_device_kernels():
     a = _C.rasterize_meshes_backward(fv, ours[0], gz, gb, gd, True, True)
     b = mod.rasterize_meshes_backward(fv, ours[0], gz, gb, gd, True, True)
     torch.cuda.synchronize()
-    # Tolerance per FACE: the batch holds faces seen edge-on whose gradients reach 1e24 (1 / area^2), so a tolerance scaled
-    # by the global maximum would be vacuous for all the others.  |a - b| <= 5e-3 * (largest of the face's nine partials
-    # in the reference's result) + a floor at 1e-6 of the median face magnitude.
-    per_face = b.abs().amax(dim=(1, 2), keepdim=True)
-    med = float(per_face[per_face > 0].median())
-    tol = 5e-3 * per_face + 1e-6 * med
-    bad = int(((a - b).abs() > tol).sum())
-    rel = ((a - b).abs() / (per_face + 1e-6 * med)).amax()
-    print(f"[bench launch backward] {a.shape[0]} faces, median per-face gradient magnitude {med:.3e}, largest {float(per_face.max()):.3e}; "
-          f"max per-face relative deviation from the reference's device backward {float(rel):.2e}; beyond 5e-3: {bad} of {a.numel()}")
-    assert torch.isfinite(a).all() == torch.isfinite(b).all()
-    assert bad == 0
+    # gate: the float64 restatement of the reference's backward (oracle/backward_f64.py), error measured against the sum
+    # of the absolute per-sample terms; the reference's device result is judged by the same gate and printed
+    U.assert_face_grads_vs_truth("bench launch backward", a, fv, ours[0], gz, gb, gd, True, True, reference=b)

@@ -213,10 +213,10 @@ def test_backward_vs_oracle(persp, clip):
     gd = torch.randn(fwd[3].shape, generator=gen)
     ref = orc.rasterize_meshes_backward(fv, fwd[0], gz, gb, gd, persp, clip, cuda_semantics=True, acc64=True)
     ours = _C.rasterize_meshes_backward(fv.to(d), fwd[0].to(d), gz.to(d), gb.to(d), gd.to(d), persp, clip).cpu()
-    scale = ref.abs().max().item()
-    err = (ours - ref).abs().max().item()
-    assert err <= 2e-3 * scale + 1e-6, f"grad_face_verts err {err} vs scale {scale}"
-    assert torch.allclose(ours, ref, rtol=5e-3, atol=2e-4 * scale)
+    # gate: the float64 restatement of the reference's formulas, per entry against the sum of the absolute per-sample terms
+    # (tests/_util.py); the C oracle's float32 result is judged by the same gate and must agree where it passes
+    U.assert_face_grads_vs_truth(f"backward persp={persp} clip={clip}", ours, fv, fwd[0], gz, gb, gd, persp, clip, rtol=2e-3,
+                                 reference=ref)
 
 
 def test_autograd_mirror_and_reference_cpu_build():
@@ -257,13 +257,14 @@ def test_autograd_mirror_and_reference_cpu_build():
     o = orc.rasterize_meshes_naive(fv, mc.mesh_to_faces_packed_first_idx(), mc.num_faces_per_mesh(), nbr, (64, 64),
                                    1e-4, 4, True, False, False)
     assert all(torch.equal(a, b) for a, b in zip(ours, o))
+    ours_fwd_idx = ours[0]
     rg = ref.rasterize_meshes_backward(fv, ours[0], g[0].cpu(), g[1].cpu(), g[2].cpu(), True, False)
     # scatter reference face grads to verts the way autograd does
     gv = torch.zeros_like(mc.verts_packed())
     gv.index_add_(0, mc.faces_packed().reshape(-1), rg.reshape(-1, 3))
     ours = torch.cat([v.grad.cpu() for v in vg], 0)
-    scale = gv.abs().max().item()
-    assert torch.allclose(ours, gv, rtol=5e-3, atol=5e-4 * scale)
+    U.assert_face_grads_vs_truth("autograd mirror, gradient to the vertices", ours, fv, ours_fwd_idx, g[0].cpu(), g[1].cpu(), g[2].cpu(),
+                                 True, False, reference=gv, faces=mc.faces_packed(), num_verts=gv.shape[0])
 
 
 def test_large_image_property_checks():
@@ -338,7 +339,8 @@ def test_backward_with_unused_outputs():
                                         True)
     gv = torch.zeros_like(verts[0])
     gv.index_add_(0, faces[0].reshape(-1), ref.reshape(-1, 3))
-    assert torch.allclose(vg[0].grad.cpu(), gv, rtol=5e-3, atol=5e-4 * max(1.0, gv.abs().max().item()))
+    U.assert_face_grads_vs_truth("only zbuf feeds the loss", vg[0].grad.cpu(), fv, out[0].cpu(), gz, torch.zeros(out[2].shape),
+                                 torch.zeros(out[3].shape), True, True, reference=gv, faces=faces[0], num_verts=gv.shape[0])
 
 
 def test_rasterize_meshes_is_hip_graph_capturable():
