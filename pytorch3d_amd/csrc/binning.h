@@ -56,15 +56,19 @@ inline BinGeom make_internal_geom(int H, int W, int user_bin_size) {
 }
 
 // Which bins hold primitives ("active") and which are background, written by the offsets scan at no extra launch:
-//   arank[row]  number of active rows before `row`          (valid for every row)
+//   arank[row]  number of active rows before `row`          (valid for every row); bit 31: the row is in heavy_list
 //   bg_list[j]  the j-th background row, ascending           (j < hdr[1])
-//   hdr         {A = active rows, B = background rows}
+//   heavy_list  rows with at least kHeavyRow primitives, in arrival order, at most kHeavyCap of them
+//   hdr         {A = active rows, B = background rows, rows appended to heavy_list (may exceed kHeavyCap: use min)}
 // The fine rasterizers use it to let the workgroups of active tiles write the -1 fill of the background tiles
 // (raster_mesh.hip: "piggyback fill"): active row number r fills background rows [r * q, (r + 1) * q), q = ceil(B / A).
+constexpr int kHeavyRow = 384;   // primitives in a bin's list from which its tile is dispatched ahead of all others
+constexpr int kHeavyCap = 1024;  // workgroups reserved at the front of the fine grid for them
 struct TilePlan {
   const int* arank;
   const int* bg_list;
   const int* hdr;
+  const int* heavy_list;
 };
 
 // Device-side CSR view consumed by the fine kernels.
@@ -84,7 +88,8 @@ struct BinWorkspace {
   int* list;         // (capacity)
   int* arank;        // (N*nbins)  TilePlan
   int* bg_list;      // (N*nbins)
-  int* plan_hdr;     // (2)
+  int* plan_hdr;     // (4)
+  int* heavy_list;   // (kHeavyCap)
   int64_t max_chunks;
   int64_t capacity;
 };

@@ -274,11 +274,19 @@ constexpr int kPlanShift = 40;
 constexpr long long kPlanMask = (1ll << kPlanShift) - 1;
 __device__ __forceinline__ long long plan_pack(int total) { return (long long)total + (total > 0 ? (1ll << kPlanShift) : 0ll); }
 // row `i` with running exclusive sum `ex` (packed) and own count `v`: offset, active rank, background list entry
-__device__ __forceinline__ void plan_emit(int64_t i, long long ex, int v, int64_t* offset, int* arank, int* bg_list) {
+__device__ __forceinline__ void plan_emit(int64_t i, long long ex, int v, int64_t* offset, int* arank, int* bg_list,
+                                          int* plan_hdr, int* heavy_list) {
   offset[i] = ex & kPlanMask;
-  const int r = (int)(ex >> kPlanShift);
-  arank[i] = r;
+  int r = (int)(ex >> kPlanShift);
   if (v <= 0) bg_list[i - r] = (int)i;
+  if (v >= kHeavyRow) {  // plan_hdr[2] was zeroed by an earlier kernel / phase of this launch
+    const int pos = atomicAdd(&plan_hdr[2], 1);
+    if (pos < kHeavyCap) {
+      heavy_list[pos] = (int)i;
+      r |= (int)0x80000000;
+    }
+  }
+  arank[i] = r;
 }
 
 __device__ __forceinline__ long long block_exclusive_scan_1024(long long v, long long* wsum, long long* block_total) {
@@ -301,18 +309,20 @@ __device__ __forceinline__ long long block_exclusive_scan_1024(long long v, long
 }
 
 __global__ __launch_bounds__(1024) void bin_block_sums_kernel(const int* __restrict__ total, int64_t rows,
-                                                              long long* __restrict__ blocksum) {
+                                                              long long* __restrict__ blocksum, int* __restrict__ plan_hdr) {
   __shared__ long long wsum[16];
   const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
   long long all;
   block_exclusive_scan_1024(i < rows ? plan_pack(total[i]) : 0, wsum, &all);
   if (threadIdx.x == 0) blocksum[blockIdx.x] = all;
+  if (plan_hdr && blockIdx.x == 0 && threadIdx.x == 0) plan_hdr[2] = 0;  // the heavy-row counter of the scan that follows
 }
 
 __global__ __launch_bounds__(1024) void bin_scan_offsets_kernel(const int* __restrict__ total, int64_t rows,
                                                                 const long long* __restrict__ blocksum,
                                                                 int64_t* __restrict__ offset, int* __restrict__ arank,
-                                                                int* __restrict__ bg_list, int* __restrict__ plan_hdr) {
+                                                                int* __restrict__ bg_list, int* __restrict__ plan_hdr,
+                                                                int* __restrict__ heavy_list) {
   __shared__ long long wsum[16];
   __shared__ long long part[16];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -330,7 +340,7 @@ __global__ __launch_bounds__(1024) void bin_scan_offsets_kernel(const int* __res
   const long long ex = block_exclusive_scan_1024(i < rows ? plan_pack(v) : 0, wsum, &all);
   if (i < rows) {
     if (arank)
-      plan_emit(i, base + ex, v, offset, arank, bg_list);
+      plan_emit(i, base + ex, v, offset, arank, bg_list, plan_hdr, heavy_list);
     else
       offset[i] = (base + ex) & kPlanMask;
   }
@@ -352,8 +362,10 @@ __global__ __launch_bounds__(1024) void bin_scan_offsets_kernel(const int* __res
 __global__ __launch_bounds__(1024) void bin_scan_small_kernel(int* __restrict__ counts, const int64_t* __restrict__ count,
                                                               int N, int nbins, int M, int* __restrict__ total,
                                                               int64_t* __restrict__ offset, int* __restrict__ arank,
-                                                              int* __restrict__ bg_list, int* __restrict__ plan_hdr) {
+                                                              int* __restrict__ bg_list, int* __restrict__ plan_hdr,
+                                                              int* __restrict__ heavy_list) {
   __shared__ int cs[kSelfPlanMax + 1];
+  if (threadIdx.x == 0) plan_hdr[2] = 0;  // visible to the atomics below after plan_in_lds's barrier
   __shared__ long long wsum[16];
   plan_in_lds(count, N, cs);
   const int tid = threadIdx.x;
@@ -377,7 +389,7 @@ __global__ __launch_bounds__(1024) void bin_scan_small_kernel(int* __restrict__ 
     }
     long long all;
     const long long ex = block_exclusive_scan_1024(row < rows ? plan_pack(t) : 0, wsum, &all);
-    if (row < rows) plan_emit(row, carry + ex, t, offset, arank, bg_list);
+    if (row < rows) plan_emit(row, carry + ex, t, offset, arank, bg_list, plan_hdr, heavy_list);
     carry += all;
     __syncthreads();  // wsum is rewritten by the next step
   }
@@ -521,7 +533,8 @@ bool bin_carve(Arena& arena, int64_t E, int N, const BinGeom& g, int M, BinWorks
   ws->list = arena.take<int>((size_t)ws->capacity);
   ws->arank = arena.take<int>((size_t)N * g.nbins);
   ws->bg_list = arena.take<int>((size_t)N * g.nbins);
-  ws->plan_hdr = arena.take<int>(2);
+  ws->plan_hdr = arena.take<int>(4);
+  ws->heavy_list = arena.take<int>(kHeavyCap);
   return arena.ok();
 }
 
@@ -559,7 +572,7 @@ int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t*
   if (small) {
     LaunchScope ls("bin_scan_small", stream);
     bin_scan_small_kernel<<<1, 1024, 0, stream>>>(ws.counts, count, N, g.nbins, M, ws.total, ws.offset, ws.arank, ws.bg_list,
-                                                  ws.plan_hdr);
+                                                  ws.plan_hdr, ws.heavy_list);
   } else {
     {
       LaunchScope ls("bin_scan_rows", stream);
@@ -568,8 +581,9 @@ int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t*
     }
     LaunchScope ls("bin_scan_offsets", stream);
     const unsigned nb = (unsigned)ceil_div(rows, 1024);
-    bin_block_sums_kernel<<<nb, 1024, 0, stream>>>(ws.total, rows, ws.blocksum);
-    bin_scan_offsets_kernel<<<nb, 1024, 0, stream>>>(ws.total, rows, ws.blocksum, ws.offset, ws.arank, ws.bg_list, ws.plan_hdr);
+    bin_block_sums_kernel<<<nb, 1024, 0, stream>>>(ws.total, rows, ws.blocksum, ws.plan_hdr);
+    bin_scan_offsets_kernel<<<nb, 1024, 0, stream>>>(ws.total, rows, ws.blocksum, ws.offset, ws.arank, ws.bg_list, ws.plan_hdr,
+                                                     ws.heavy_list);
   }
   {
     LaunchScope ls("bin_fill", stream);
@@ -592,8 +606,8 @@ int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t*
 int exclusive_scan_i32(const int* in, int64_t n, long long* blocksum, int64_t* out, hipStream_t stream) {
   if (n <= 0) return P3D_OK;
   const unsigned nb = (unsigned)ceil_div(n, 1024);
-  bin_block_sums_kernel<<<nb, 1024, 0, stream>>>(in, n, blocksum);
-  bin_scan_offsets_kernel<<<nb, 1024, 0, stream>>>(in, n, blocksum, out, nullptr, nullptr, nullptr);
+  bin_block_sums_kernel<<<nb, 1024, 0, stream>>>(in, n, blocksum, nullptr);
+  bin_scan_offsets_kernel<<<nb, 1024, 0, stream>>>(in, n, blocksum, out, nullptr, nullptr, nullptr, nullptr);
   return launch_status();
 }
 

@@ -61,6 +61,7 @@ struct MeshArgs {
   TileMap tm;
   float blur, sqrt_blur;
   int persp, clip, cull;
+  int heavy_front;  // the first kHeavyCap workgroups of the grid take the tiles of csr.plan.heavy_list (launcher decides)
   int64_t* p2f;
   float* zbuf;
   float* bary;
@@ -526,8 +527,30 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
   __shared__ ChunkOrderScratch s_ord;
   __shared__ int s_wcnt[kStage / kWave];
 
+  // Heavy tiles first.  The launch ends with a tail: the few tiles whose lists hold many hundred faces run 250-330 us
+  // each (profiles/r02_fine_timeline.txt: the last 150 us of a 1.5 ms launch), and in the tile map's order they start at
+  // arbitrary times.  The offsets scan lists the rows with >= kHeavyRow faces (binning.h: TilePlan::heavy_list); the
+  // first kHeavyCap workgroups of the grid take those tiles, everybody else skips them (bit 31 of arank).
   TileCoord tc;
-  if (!tile_of_block(a.tm, SPLIT ? blockIdx.x >> 2 : blockIdx.x, &tc)) return;
+  unsigned blk = SPLIT ? blockIdx.x >> 2 : blockIdx.x;
+  bool front = false;
+  if (BINNED && !SPLIT && a.heavy_front) {
+    if (blk < (unsigned)kHeavyCap) {
+      const int nh = a.csr.plan.hdr[2];
+      if ((int)blk >= (nh < kHeavyCap ? nh : kHeavyCap)) return;  // uniform
+      const int hrow = a.csr.plan.heavy_list[blk];
+      const int per_image = a.tm.BH * a.tm.BW;
+      tc.n = hrow / per_image;
+      const int rem = hrow - tc.n * per_image;
+      tc.by = rem / a.tm.BW;
+      tc.bx = rem - tc.by * a.tm.BW;
+      tc.ty = tc.tx = 0;
+      front = true;
+    } else {
+      blk -= (unsigned)kHeavyCap;
+    }
+  }
+  if (!front && !tile_of_block(a.tm, blk, &tc)) return;
   const int n = tc.n, by = tc.by, bx = tc.bx, ty = tc.ty, tx = tc.tx;
 
   const int H = a.H, W = a.W;
@@ -571,6 +594,10 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
   if (piggy) {
     plan_a = a.csr.plan.hdr[0];
     plan_b = a.csr.plan.hdr[1];
+  }
+  if (BINNED && !SPLIT && a.heavy_front && !front && count >= kHeavyRow) {
+    const int64_t row = ((int64_t)n * a.tm.BH + by) * a.tm.BW + bx;
+    if (a.csr.plan.arank[row] < 0) return;  // one of the front workgroups has this tile (uniform)
   }
   if (count <= 0) {
     if (piggy && plan_a > 0) return;  // an active workgroup writes this tile (uniform)
@@ -688,7 +715,7 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
     if (piggy && plan_b > 0) {
       const int64_t row = ((int64_t)n * a.tm.BH + by) * a.tm.BW + bx;
       const int q_bg = (plan_b + plan_a - 1) / plan_a;
-      const long long j0 = (long long)a.csr.plan.arank[row] * q_bg;
+      const long long j0 = (long long)(a.csr.plan.arank[row] & 0x7fffffff) * q_bg;
       const long long j1 = j0 + q_bg < (long long)plan_b ? j0 + q_bg : (long long)plan_b;
       const int per_image = a.tm.BH * a.tm.BW;
       for (long long j = j0; j < j1; ++j) {  // uniform: scalar loads and arithmetic
@@ -731,13 +758,16 @@ void launch_fine_variant(const MeshArgs& a, unsigned grid, bool split, size_t dy
 #define P3D_COMMA ,
 template <bool BINNED>
 int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
-  const MeshArgs& a = a0;
-  const unsigned grid = tile_grid(a.tm);
+  MeshArgs a = a0;
+  unsigned grid = tile_grid(a.tm);
   const char* name = BINNED ? "mesh_fine" : "mesh_naive";
   LaunchScope ls(name, stream);
   const int K = a.K;
   // few tiles (one image, a small batch): one workgroup per sub-tile with the candidate list dealt to its four waves
   const bool split = BINNED && grid <= (unsigned)kSplitMaxTiles;
+  // heavy tiles at the front of the grid: when the lists carry a tile plan and a tile is a bin
+  a.heavy_front = BINNED && !split && a.csr.plan.hdr != nullptr && a.tm.Ty == 1 && a.tm.Tx == 1 && grid > 4u * kHeavyCap;
+  if (a.heavy_front) grid += (unsigned)kHeavyCap;
   const size_t dyn_lds = 0;
 #define P3D_LAUNCH_FINE(KT_, REGS_, EXACT_, Q_) launch_fine_variant<Q_, KT_, REGS_, BINNED, EXACT_>(a, grid, split, dyn_lds, stream)
 #define P3D_LAUNCH_FINE_W(KT_, WAVES_, Q_) mesh_raster_kernel<Q_, KT_, true, BINNED, false, WAVES_><<<grid, kStage, 0, stream>>>(a)
@@ -877,7 +907,7 @@ P3D_API int p3d_rasterize_meshes(const float* face_verts, const int64_t* mesh_fi
   int st = bin_build(kTriangles, face_verts, nullptr, mesh_first, mesh_count, F, N, g, max_faces_per_bin,
                      sqrtf(blur_radius), ws, s);
   if (st != P3D_OK) return st;
-  BinCSR csr{ws.offset, ws.total, ws.list, TilePlan{ws.arank, ws.bg_list, ws.plan_hdr}};
+  BinCSR csr{ws.offset, ws.total, ws.list, TilePlan{ws.arank, ws.bg_list, ws.plan_hdr, ws.heavy_list}};
   return mesh_fine_from_csr(face_verts, neighbor, csr, N, H, W, g, blur_radius, K, persp, clip, cull, p2f, zbuf, bary,
                             dists, s);
 }
@@ -931,7 +961,7 @@ P3D_API int p3d_rasterize_meshes_fine(const float* face_verts, const int32_t* bi
   g.BH = BH;
   g.BW = BW;
   g.nbins = BH * BW;
-  BinCSR csr{offset, total, list, TilePlan{nullptr, nullptr, nullptr}};
+  BinCSR csr{offset, total, list, TilePlan{nullptr, nullptr, nullptr, nullptr}};
   return mesh_fine_from_csr(face_verts, neighbor, csr, N, H, W, g, blur_radius, K, persp, clip, cull, p2f, zbuf, bary,
                             dists, s);
 }
