@@ -267,6 +267,94 @@ __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
   if (tab.used > 0) tab.flush(a.grad_fv, lane);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Sample-major form for K = 4, 8, 16 (round 3).  The kernel above gives a lane a PIXEL and walks its K slots: 56 row
+// registers per lane (127 VGPRs, four waves per SIMD) and, per slot, a face-vertex gather whose latency nothing hides --
+// the wave sits in s_waitcnt 47 % of its time (profiles/r02_fine_v2_rocprof.md) while VALU and LDS are each under half
+// busy.  Here a lane owns one SAMPLE per step: a 16-pixel row segment of the four operands is 16 K contiguous samples,
+// walked 64 at a time (K = 8: two steps per row; lane L of step t -> sample 64 t + L = pixel (64 t + L) / K, slot
+// (64 t + L) % K).
+//   * every load is one fully contiguous piece per wave (512 B of pix_to_face, 256 B of grad_zbuf / grad_dists, 768 B of
+//     grad_bary per step) and a lane holds six operand registers instead of 7 K: the kernel fits 80 VGPRs, and with a
+//     118-slot table (26 KB per workgroup, spill mode of wave_table.h) SIX waves per SIMD are resident instead of four --
+//     occupancy is what hides the gather and the LDS round trips of the table (measured, K = 8: 1.26 -> 1.19 ms; a
+//     software-pipelined variant of the same layout at four waves: 1.33; gathers issued a row ahead: no gain);
+//   * a lane's pixel column takes K / 4 values over the steps of a row (their NDC x are computed once), the row's y is
+//     uniform; pix_to_face of the next step is requested before the current one is computed.
+// Table machinery (wave_table.h) unchanged: per step every lane contributes one sample.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KT>
+struct RowsCfg {
+  static constexpr int kWaves = KT >= 16 ? 5 : 6;     // waves per SIMD the kernel is built for (512 / kWaves registers)
+  static constexpr int kSlots = KT >= 16 ? 136 : 118;  // 4 waves x kSlots x 56 B of LDS per workgroup
+};
+
+template <int KT, bool TO_VERTS>
+__global__ __launch_bounds__(256, RowsCfg<KT>::kWaves) void mesh_backward_rows_kernel(BwdArgs a) {
+  constexpr int SPR = KT / 4;  // steps per 16-pixel row segment
+  static_assert(KT == 4 || KT == 8 || KT == 16, "16 K samples per row segment, 64 per step");
+  using Table = WaveTable<9, RowsCfg<KT>::kSlots, TO_VERTS ? kCorners : kRows, true>;
+  __shared__ __align__(16) int s_table[4][Table::kLdsInts];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = tid >> 6;
+  long long t = blockIdx.x;
+  const int rx = (int)(t % a.RX);
+  t /= a.RX;
+  const int ry = (int)(t % a.RY);
+  const int n = (int)(t / a.RY);
+  const int ay = ry * kRegion + (w >> 1) * 16;
+  const int ax = rx * kRegion + (w & 1) * 16;
+  const int H = a.H, W = a.W;
+  if (ay >= H || ax >= W) return;  // wave-uniform; no workgroup barriers in this kernel
+
+  Table tab;
+  tab.init(s_table[w], lane);
+  tab.index = a.faces;
+  tab.index_limit = a.V;
+  const bool persp = a.persp != 0, clip = a.clip != 0;
+
+  const int rows = min(16, H - ay);
+  const int seg = min(16, W - ax) * KT;  // samples of a row segment inside the image
+  float px[SPR];                           // NDC x of this lane's pixel in step s of a row (rasterize_meshes.cu:458-462)
+#pragma unroll
+  for (int s = 0; s < SPR; ++s) px[s] = pix_to_ndc(W - 1 - (ax + (64 * s + lane) / KT), W, H);
+  const int64_t area_base = (((int64_t)n * H + ay) * W + ax) * KT;
+  const int64_t row_pitch = (int64_t)W * KT;
+  const int steps = rows * SPR;
+
+  // pix_to_face one step ahead: the only load every step needs (background costs nothing else)
+  int f_nxt = lane < seg ? (int)a.p2f[area_base + lane] : -1;
+#pragma unroll 1
+  for (int u = 0; u < steps; ++u) {
+    const int r = u / SPR, s = u % SPR;  // SPR is a power of two
+    const int f = f_nxt;
+    {
+      const int un = u + 1, rn = un / SPR, sn = un % SPR;
+      const int e = 64 * sn + lane;
+      f_nxt = (un < steps && e < seg) ? (int)a.p2f[area_base + (int64_t)rn * row_pitch + e] : -1;
+    }
+    if (__ballot(f >= 0) == 0) continue;  // wave-uniform: nothing rendered in these 64 samples
+    FaceGrad g;
+    if (f >= 0) {
+      const int64_t rb = area_base + (int64_t)r * row_pitch + 64 * s;  // uniform
+      const float gz = a.grad_zbuf[rb + lane], gd = a.grad_dists[rb + lane];
+      const float* gbp = a.grad_bary + 3 * rb;
+      const f3 gb = mk3(gbp[3 * lane], gbp[3 * lane + 1], gbp[3 * lane + 2]);
+      const float* q = a.face_verts + (int64_t)f * 9;
+      float pxs = px[0];
+#pragma unroll
+      for (int c = 1; c < SPR; ++c) pxs = s == c ? px[c] : pxs;
+      const f2 p = mk2(pxs, pix_to_ndc(H - 1 - (ay + r), H, W));
+      g = face_sample_bwd(mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), mk3(q[6], q[7], q[8]), p, gz, gb, gd, persp, clip, false);
+    }
+    tab.add(a.grad_fv, lane, f, g.g);
+  }
+  if (tab.used > 0) tab.flush(a.grad_fv, lane);
+}
+
 }  // namespace
 
 }  // namespace p3d
@@ -308,8 +396,9 @@ int launch_mesh_backward(const float* face_verts, const int64_t* faces, int64_t 
   switch (K) {                                                                   \
     case 1: mesh_backward_kernel<1, TV><<<grid, 256, 0, s>>>(a); break;          \
     case 2: mesh_backward_kernel<2, TV><<<grid, 256, 0, s>>>(a); break;          \
-    case 4: mesh_backward_kernel<4, TV><<<grid, 256, 0, s>>>(a); break;          \
-    case 8: mesh_backward_kernel<8, TV><<<grid, 256, 0, s>>>(a); break;          \
+    case 4: mesh_backward_rows_kernel<4, TV><<<grid, 256, 0, s>>>(a); break;     \
+    case 8: mesh_backward_rows_kernel<8, TV><<<grid, 256, 0, s>>>(a); break;     \
+    case 16: mesh_backward_rows_kernel<16, TV><<<grid, 256, 0, s>>>(a); break;   \
     default: mesh_backward_kernel<0, TV><<<grid, 256, 0, s>>>(a); break;         \
   }
   if (faces) {
