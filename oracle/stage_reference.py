@@ -5,7 +5,7 @@ survey planned for the drop-in boundary, so `stage()` copies
 
     /root/reference/pytorch3d/**/*.py      (pure Python; no csrc, no implicitron)
     /root/reference/tests/{common_testing,test_*}.py  for the hot-path test modules listed below
-    /root/reference/tests/data/*.png       (image fixtures of test_render_points / test_render_meshes / ...)
+    /root/reference/tests/data/*.png, *.jpg (image fixtures of test_render_points / test_render_meshes / ...)
     /root/reference/docs/tutorials/data/cow_mesh/*   (BASELINE configs[1]: the cow)
 
 into oracle/_ref/reference_py/ -- git-ignored like the rest of oracle/_ref/ (nothing of the reference enters the
@@ -64,7 +64,7 @@ def stage(force=False):
             _copy(src, os.path.join(STAGE, "tests", m + ".py"))
     ddir = os.path.join(tdir, "data")
     for f in (os.listdir(ddir) if os.path.isdir(ddir) else []):
-        if f.endswith(".png"):
+        if f.endswith((".png", ".jpg")):
             _copy(os.path.join(ddir, f), os.path.join(STAGE, "tests", "data", f))
     for sub in ("missing_usemtl", "missing_files_obj", "obj_mtl_no_image"):  # small OBJ fixtures of test_render_meshes
         for d, _dirs, files in os.walk(os.path.join(ddir, sub)):

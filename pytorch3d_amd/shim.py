@@ -41,6 +41,12 @@ def make_module():
         setattr(mod, name, getattr(_ours, name))
     for name in ("EPS", "MAX_FLOAT", "MAX_INT", "MAX_UINT", "MAX_USHORT", "PULSAR_MAX_GRAD_SPHERES"):
         setattr(mod, name, getattr(_ours, name))
+    # four small operators the reference's mesh classes call on the way to the renderer (face normals / areas, packed <->
+    # padded): torch formulations, not part of the hot path (pytorch3d_amd/_aux_ops.py)
+    from . import _aux_ops
+
+    for name in ("face_areas_normals_forward", "face_areas_normals_backward", "packed_to_padded", "padded_to_packed"):
+        setattr(mod, name, getattr(_aux_ops, name))
 
     def __getattr__(name):  # PEP 562: anything else is outside the hot path
         if name.startswith("__"):
@@ -134,11 +140,12 @@ def patch_reference_python():
         return
     import importlib
 
-    from . import blending as our_blend
-    from . import clip as our_clip
-    from . import rasterize_meshes as our_rm
-    from . import shading as our_shade
-    from . import textures as our_tex
+    # (importlib: the package re-exports FUNCTIONS named rasterize_meshes etc. over the sub-modules of the same name)
+    our_blend = importlib.import_module(__package__ + ".blending")
+    our_clip = importlib.import_module(__package__ + ".clip")
+    our_rm = importlib.import_module(__package__ + ".rasterize_meshes")
+    our_shade = importlib.import_module(__package__ + ".shading")
+    our_tex = importlib.import_module(__package__ + ".textures")
 
     rm = importlib.import_module("pytorch3d.renderer.mesh.rasterize_meshes")
     clip = importlib.import_module("pytorch3d.renderer.mesh.clip")

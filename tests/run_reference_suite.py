@@ -32,7 +32,8 @@ REF_SO = os.path.join(ROOT, "oracle", "_ref", "p3d_ref_cpu.so")
 
 DEFAULT_MODULES = ["test_rasterize_meshes", "test_rasterize_points", "test_compositing",
                    "test_interpolate_face_attributes", "test_blending", "test_render_points", "test_render_meshes",
-                   "test_rasterize_rectangle_images", "test_texturing", "test_shader"]
+                   "test_rasterize_rectangle_images", "test_texturing", "test_shader", "test_render_meshes_clipped",
+                   "test_rasterizer"]
 
 
 def _stub_missing_packages():
@@ -73,6 +74,42 @@ def _stub_missing_packages():
         im.imwrite = lambda *a, **k: None
         im.imread = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("imageio stub"))
         sys.modules["imageio"] = im
+    # tests/test_rasterizer.py imports pure-Python helpers (_check_cameras, _parse_and_verify_image_size, ...) from
+    # pytorch3d.renderer.opengl.rasterizer_opengl, whose module body imports pyopengl / pycuda.  The EGL rasterizer itself is
+    # outside the path and its tests are skipped (PYTORCH3D_NO_TEST_OPENGL=1): any attribute of the stubs is an inert class.
+    try:
+        import OpenGL.EGL  # noqa: F401
+    except Exception:
+        class _InertMeta(type):
+            def __getattr__(cls, name):
+                if name.startswith("__"):
+                    raise AttributeError(name)
+                return cls
+
+        class _Inert(Exception, metaclass=_InertMeta):
+            def __init__(self, *a, **k):
+                pass
+
+            def __call__(self, *a, **k):
+                return _Inert()
+
+            def __getattr__(self, name):
+                return _Inert
+
+        class _InertModule(types.ModuleType):
+            def __getattr__(self, name):
+                if name.startswith("__"):
+                    raise AttributeError(name)
+                return _Inert
+
+        for name in ("OpenGL", "OpenGL.GL", "OpenGL.EGL", "OpenGL._opaque", "OpenGL.raw", "OpenGL.raw.EGL", "OpenGL.raw.EGL._errors",
+                     "pycuda", "pycuda.gl", "pycuda.driver"):
+            m = _InertModule(name)
+            m.__path__ = []
+            sys.modules[name] = m
+            if "." in name:  # `import a.b as c` binds getattr(a, "b")
+                parent, child = name.rsplit(".", 1)
+                setattr(sys.modules[parent], child, m)
 
 
 def _device_routed_C():
@@ -111,25 +148,12 @@ def _device_routed_C():
     for name in ours_C.HOT_PATH_EXPORTS:
         setattr(mod, name, route(name, getattr(ours_C, name)))
 
-    # Operators OUTSIDE the hot path that the reference's renderer tests touch on the way (vertex normals, padding):
-    # computed by the reference's CPU code on host copies.  Counted separately; they never reach pytorch3d_amd.
-    def via_cpu(name, theirs):
-        def call(*args, **kwargs):
-            dev = next((a.device for a in args if isinstance(a, torch.Tensor)), torch.device("cpu"))
-            cargs = [a.cpu() if isinstance(a, torch.Tensor) else a for a in args]
-            out = theirs(*cargs, **kwargs)
-            counts.setdefault("outside_path_ref_cpu", {})[name] = counts.get("outside_path_ref_cpu", {}).get(name, 0) + 1
-            if isinstance(out, tuple):
-                return tuple(o.to(dev) if isinstance(o, torch.Tensor) else o for o in out)
-            return out.to(dev) if isinstance(out, torch.Tensor) else out
+    # The four small operators above the boundary (face areas / normals, packed <-> padded; pytorch3d_amd/_aux_ops.py):
+    # HIP tensors -> our torch formulations, CPU tensors -> the reference's CPU kernels, like everything else.
+    from pytorch3d_amd import _aux_ops
 
-        call.__name__ = name
-        return call
-
-    if ref is not None:
-        for name in ("face_areas_normals_forward", "face_areas_normals_backward", "packed_to_padded", "padded_to_packed"):
-            if hasattr(ref, name):
-                setattr(mod, name, via_cpu(name, getattr(ref, name)))
+    for name in ("face_areas_normals_forward", "face_areas_normals_backward", "packed_to_padded", "padded_to_packed"):
+        setattr(mod, name, route(name, getattr(_aux_ops, name)))
     return mod, counts
 
 
@@ -177,6 +201,10 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "ref_suite.json"))
     ap.add_argument("--stage", default=STAGE)
     ap.add_argument("-k", dest="pattern", default=None, help="only tests whose id contains this substring")
+    ap.add_argument("--patch-python", action="store_true",
+                    help="also replace the reference's torch formulations around the operators (clip_faces, softmax_rgb_blend, "
+                         "phong_shading, TexturesUV.sample_textures, the face gather ...) with the fused HIP versions "
+                         "(pytorch3d_amd.shim.patch_reference_python)")
     args = ap.parse_args()
     if not os.path.isdir(os.path.join(args.stage, "pytorch3d")):
         raise SystemExit(f"{args.stage}: the reference is not staged (run oracle/stage_reference.py in the build container)")
@@ -191,6 +219,10 @@ def main():
     import pytorch3d
 
     pytorch3d._C = mod
+    if args.patch_python:
+        import pytorch3d_amd.shim as shim
+
+        shim.patch_reference_python()
     try:  # the EGL rasterizer is outside the path; the tests only need the name to exist at import time
         import pytorch3d.renderer.opengl as ogl
 
@@ -235,6 +267,11 @@ def main():
                 last = r["msg"].strip().splitlines()[-1] if r["msg"].strip() else ""
                 print(f"    {r['outcome'].upper():5s} {tid.split('.', 2)[-1]}: {last[:200]}", flush=True)
     report["__calls__"] = counts
+    if args.patch_python:
+        import pytorch3d_amd.shim as shim
+
+        report["__patched_calls__"] = {k: {"fused": v[0], "reference_fallback": v[1]} for k, v in sorted(shim.PATCH_CALLS.items())}
+        print("patched python calls (fused / fallback):", report["__patched_calls__"], flush=True)
     report["__totals__"] = totals
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     with open(args.out, "w") as f:
