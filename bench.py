@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--jobs", type=int, default=0, help="BASELINE configs[4]: a fixed number of jobs (multiple of --batch), strong scaling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the timing of the unmodified reference MeshRasterizer through the shim")
     ap.add_argument("--cpu-budget-s", type=float, default=150.0, help="wall-clock bound for the CPU baseline legs")
     return ap.parse_args()
 
@@ -68,11 +69,11 @@ def sub_batches_of_rank(jobs, batch, rank, world):
     return list(range(rank, n_sub, world))
 
 
-def build_batch(n_meshes, seed, device):
+def build_batch(n_meshes, seed, device, torus_div=1.5):
     import _util as U
     import pytorch3d_amd as p3d
 
-    verts, faces = U.hetero_batch(n_meshes, seed=seed)
+    verts, faces = U.hetero_batch(n_meshes, seed=seed, torus_div=torus_div)
     nfaces = [int(f.shape[0]) for f in faces]
     meshes = p3d.PackedMeshes([v.to(device) for v in verts], [f.to(device) for f in faces])
     return meshes, verts, faces, nfaces
@@ -284,6 +285,54 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def dropin_timing(batch, image_size):
+    """The UNMODIFIED reference `MeshRasterizer.forward` + backward through the shim on the same batch, `_C` only and with
+    shim.install(patch_python=True) (profiles/dropin_timing.py, one subprocess each: the shim must not leak into this
+    process).  -> {"c_only": {...}, "patched": {...}} or a reason."""
+    import subprocess
+
+    out = {}
+    for mode in ("c_only", "patched"):
+        try:
+            res = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "dropin_timing.py"), "--mode", mode, "--batch", str(batch),
+                                  "--image-size", str(image_size)], capture_output=True, text=True, timeout=600, cwd=ROOT)
+            lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+            out[mode] = json.loads(lines[-1]) if lines else {"value": None, "reason": (res.stderr or res.stdout)[-400:]}
+        except Exception as e:  # never sink the measurement
+            out[mode] = {"value": None, "reason": repr(e)}
+    return out
+
+
+def scale_one_sensitivity(device, B, H, W, K, blur, steps=20):
+    """The same step on the generator's UNSCALED tori (ring radius 1: the batch fills the frame instead of covering a
+    third of it; SURVEY.md 8d config 3 does not fix the scale): how much the headline depends on that choice."""
+    import pytorch3d_amd as p3d
+
+    meshes, _, _, nfaces = build_batch(B, seed=0, device=device, torus_div=1.0)
+    vp = meshes.verts_packed().clone().requires_grad_(True)
+    gen = torch.Generator().manual_seed(231)
+    g = [torch.randn(s, generator=gen).to(device) for s in ((B, H, W, K), (B, H, W, K, 3), (B, H, W, K))]
+
+    def step():
+        vp.grad = None
+        p2f, zbuf, bary, dists = p3d.rasterize_meshes(meshes.update_verts_packed(vp), image_size=(H, W), blur_radius=blur, faces_per_pixel=K,
+                                                      perspective_correct=True, clip_barycentric_coords=True)
+        torch.autograd.backward([zbuf, bary, dists], g)
+        return p2f
+
+    for _ in range(3):
+        p2f = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        p2f = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"ms_per_step": ms, "Mpix_s": B * H * W / (ms * 1e-3) / 1e6, "covered_pixel_fraction": float((p2f[..., 0] >= 0).float().mean()),
+            "pixel_slot_fill": float((p2f >= 0).float().mean()), "total_faces": sum(nfaces), "steps": steps,
+            "note": "hetero_batch(torus_div=1.0): tori unscaled; not the headline workload"}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -478,6 +527,14 @@ def main():
                 out["other_configs"] = other_configs(lib, _lib, device)
             except Exception as e:
                 out["other_configs"] = {"error": repr(e)}
+        if world == 1 and not jobs_mode and not args.no_other_configs:
+            try:
+                out["workload_scale_1.0"] = scale_one_sensitivity(device, B, H, W, K, blur)
+            except Exception as e:
+                out["workload_scale_1.0"] = {"error": repr(e)}
+        if world == 1 and not jobs_mode and not args.no_dropin:
+            out["dropin"] = dropin_timing(B, H)
+            out["dropin"]["mirror_ms_per_step"] = elapsed / steps * 1e3
         if world == 1 and not args.no_cpu_baseline:
             try:
                 _, _, _, verts_cpu, faces_cpu = batches[0]

@@ -325,6 +325,52 @@ def rasterize_meshes_world(meshes_world, world_to_view, view_to_ndc, image_size=
                                       bool(perspective_correct), bool(clip_barycentric_coords), bool(cull_backfaces)))
 
 
+class _TransformVerts(torch.autograd.Function):
+    """world vertices (V,3) -> NDC x, y + view depth (V,3): MeshRasterizer.transform (rasterizer.py:171-216) on the PACKED
+    vertices in one launch (p3d_transform_verts_forward), backward = p3d_transform_verts_backward."""
+
+    @staticmethod
+    def forward(ctx, verts, vert_first, mats):
+        from . import _lib
+
+        lib = _lib.load()
+        v = verts.contiguous()
+        dev = v.device
+        with torch.cuda.device(dev):
+            out = torch.empty_like(v)
+            if v.shape[0]:
+                rc = lib.p3d_transform_verts_forward(_C._ptr(v), _C._ptr(vert_first), _C._ptr(mats), v.shape[0], vert_first.shape[0],
+                                                     mats.shape[0], _C._ptr(out), _C._stream(dev))
+                _lib.check(rc, "transform_verts_forward")
+        ctx.save_for_backward(v, vert_first, mats)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+
+        v, vert_first, mats = ctx.saved_tensors
+        lib = _lib.load()
+        dev = v.device
+        g = g.contiguous()
+        with torch.cuda.device(dev):
+            out = torch.empty_like(v)
+            if v.shape[0]:
+                rc = lib.p3d_transform_verts_backward(_C._ptr(v), _C._ptr(vert_first), _C._ptr(mats), _C._ptr(g), v.shape[0],
+                                                      vert_first.shape[0], mats.shape[0], _C._ptr(out), _C._stream(dev))
+                _lib.check(rc, "transform_verts_backward")
+        return out, None, None
+
+
+def transform_verts_to_ndc(meshes_world, world_to_view, view_to_ndc):
+    """Packed world vertices of `meshes_world` -> packed NDC vertices (x, y in NDC, z = view depth), differentiable with
+    respect to the vertices.  Matrices as in rasterize_meshes_world; they must not require grad (callers take the torch
+    formulation then)."""
+    verts = meshes_world.verts_packed()
+    mats = _pack_matrices(torch.as_tensor(world_to_view), torch.as_tensor(view_to_ndc), len(meshes_world), verts.device)
+    return _TransformVerts.apply(verts, meshes_world.mesh_to_verts_packed_first_idx().contiguous(), mats)
+
+
 class _PackedVertsView:
     """The packed accessors `rasterize_meshes` reads, with the vertices replaced (topology shared with `meshes`)."""
 

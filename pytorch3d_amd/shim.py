@@ -17,6 +17,8 @@ additionally replaces the reference's pure-torch callers and callees of the oper
 fused HIP versions of this package, so that `MeshRenderer(MeshRasterizer, SoftPhongShader)` built from the UNMODIFIED
 reference classes runs on them end to end:
 
+    renderer.mesh.rasterizer.MeshRasterizer.forward           -> camera transform on the PACKED vertices in one launch
+                                                                 (csrc/transform.hip) + the fused rasterize_meshes below
     renderer.mesh.rasterize_meshes.rasterize_meshes           -> fused gather + rasterizer (+ HIP clipping), one autograd node
     renderer.mesh.clip.clip_faces / convert_clipped_...       -> csrc/clip.hip
     renderer.blending.softmax_rgb_blend / hard_rgb_blend      -> csrc/blend.hip
@@ -254,6 +256,67 @@ def patch_reference_python():
     atlas_sample.__wrapped__ = atlas_orig
     textures.TexturesAtlas.sample_textures = atlas_sample
     _PATCHED.append((textures.TexturesAtlas, "sample_textures", atlas_orig, atlas_sample))
+
+    _patch_mesh_rasterizer(our_rm)
+
+
+def _patch_mesh_rasterizer(our_rm):
+    """MeshRasterizer.forward (rasterizer.py:219-276).  The reference transforms the PADDED vertices with two batched
+    4x4 `transform_points` (homogeneous divides, `cat`, `update_padded` -> a new Meshes): ~4 ms of small launches and
+    Python per call on the bench batch, more than the rasterization itself.  Here: both matrices from the cameras, one
+    kernel on the packed vertices, then the fused rasterize_meshes (its own z-clipping / culling) on a view of the mesh's
+    topology.  Falls back to the reference's forward when the cameras have no matrix form, need an `eps`, or their
+    matrices require grad (camera optimisation: torch autograd through transform_points)."""
+    import importlib
+
+    import torch
+
+    rz = importlib.import_module("pytorch3d.renderer.mesh.rasterizer")
+    cam_utils = importlib.import_module("pytorch3d.renderer.cameras")
+    orig = rz.MeshRasterizer.forward
+
+    def forward(self, meshes_world, **kwargs):
+        cameras = kwargs.get("cameras", self.cameras)
+        ok = cameras is not None and kwargs.get("eps", None) is None
+        if ok:
+            try:
+                verts = meshes_world.verts_packed()
+                ok = _is_hip_f32(verts) and meshes_world.faces_packed().is_cuda and len(cameras) in (1, len(meshes_world))
+                if ok:
+                    w2v = cameras.get_world_to_view_transform(**kwargs).get_matrix()
+                    proj = cam_utils.try_get_projection_transform(cameras, kwargs)
+                    ok = proj is not None
+                    if ok:
+                        v2n = proj.compose(cameras.get_ndc_camera_transform(**kwargs)).get_matrix()
+                        ok = not (w2v.requires_grad or v2n.requires_grad) and w2v.device == verts.device
+            except Exception:
+                ok = False
+        _count("MeshRasterizer.forward", ok)
+        if not ok:
+            return orig(self, meshes_world, **kwargs)
+        rs = kwargs.get("raster_settings", self.raster_settings)
+        clip_bary = rs.clip_barycentric_coords
+        if clip_bary is None:
+            clip_bary = rs.blur_radius > 0.0
+        persp = rs.perspective_correct if rs.perspective_correct is not None else cameras.is_perspective()
+        if rs.z_clip_value is not None:
+            z_clip = rs.z_clip_value
+        else:
+            znear = cameras.get_znear()
+            if isinstance(znear, torch.Tensor):
+                znear = znear.min().item()
+            z_clip = None if not persp or znear is None else znear / 2
+        ndc = our_rm.transform_verts_to_ndc(meshes_world, w2v, v2n)
+        p2f, zbuf, bary, dists = our_rm.rasterize_meshes(
+            our_rm._PackedVertsView(meshes_world, ndc), image_size=rs.image_size, blur_radius=rs.blur_radius,
+            faces_per_pixel=rs.faces_per_pixel, bin_size=rs.bin_size, max_faces_per_bin=rs.max_faces_per_bin,
+            clip_barycentric_coords=clip_bary, perspective_correct=persp, cull_backfaces=rs.cull_backfaces, z_clip_value=z_clip,
+            cull_to_frustum=rs.cull_to_frustum)
+        return rz.Fragments(pix_to_face=p2f, zbuf=zbuf, bary_coords=bary, dists=dists)
+
+    forward.__wrapped__ = orig
+    rz.MeshRasterizer.forward = forward
+    _PATCHED.append((rz.MeshRasterizer, "forward", orig, forward))
 
 
 def uninstall_python_patches():

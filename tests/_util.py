@@ -114,9 +114,10 @@ def split_counts(F, N):
     return first, count
 
 
-def hetero_batch(n_meshes, seed=0, fmin=1000, fmax=20000):
+def hetero_batch(n_meshes, seed=0, fmin=1000, fmax=20000, torus_div=1.5):
     """BASELINE config 3 generator: tori / icospheres with log-uniform face counts, random rotation,
-    seen from distance 2.7.  Returns (list of NDC verts, list of faces)."""
+    seen from distance 2.7.  Returns (list of NDC verts, list of faces).  torus_div: the tori (ring radius 1) are scaled
+    by 1 / torus_div -- 1.5 is the bench workload (the batch covers ~31 % of the pixels), 1.0 fills the frame."""
     gen = torch.Generator().manual_seed(seed)
     verts, faces = [], []
     for _ in range(n_meshes):
@@ -129,7 +130,7 @@ def hetero_batch(n_meshes, seed=0, fmin=1000, fmax=20000):
             sides = max(8, int(round(math.sqrt(target / 2.0 / 2.5))))
             rings = max(8, int(round(target / 2.0 / sides)))
             v, f = torus(0.4 + 0.2 * u[2], 1.0, sides, rings)
-            v = v / 1.5
+            v = v / torus_div
         R = random_rotation(gen)
         verts.append(to_ndc(v @ R.T))
         faces.append(f)

@@ -41,6 +41,13 @@ def test_single_rank_line_small():
     oc = j["other_configs"]
     assert "wall_ms" in oc["config2_cow_256_k8_fwd"], oc
     assert "wall_ms" in oc["config4_points_1m_512_k10_fwd_bwd"], oc
+    # the unmodified reference MeshRasterizer through the shim, both modes (or a reason where the reference is not staged)
+    dr = j["dropin"]
+    for mode in ("c_only", "patched"):
+        assert mode in dr and ("ms_per_step" in dr[mode] or dr[mode].get("reason")), dr
+    if "ms_per_step" in dr["patched"]:
+        assert dr["patched"]["grad_finite"] and dr["patched"]["patched_calls"]["MeshRasterizer.forward"][0] > 0, dr
+    assert j["workload_scale_1.0"]["covered_pixel_fraction"] > j["config"]["covered_pixel_fraction"]
 
 
 @pytest.mark.parametrize("mode", ["weak", "jobs"])

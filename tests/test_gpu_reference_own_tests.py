@@ -89,7 +89,7 @@ def test_reference_hot_path_test_modules_pass_on_the_hip_kernels(report):
         assert sum(calls["hip"].values()) > 300, "the HIP operators were hardly called -- are the tests running on the GPU?"
     else:
         # the fused replacements call the C ABI directly, not `_C`: what ran is in the patch record
-        for name in ("rasterize_meshes", "clip_faces", "convert_clipped_rasterization_to_original_faces", "softmax_rgb_blend",
+        for name in ("MeshRasterizer.forward", "rasterize_meshes", "clip_faces", "convert_clipped_rasterization_to_original_faces", "softmax_rgb_blend",
                      "hard_rgb_blend", "phong_shading", "flat_shading", "gouraud_shading", "TexturesUV.sample_textures",
                      "TexturesAtlas.sample_textures"):
             assert patched.get(name, {}).get("fused", 0) > 0, f"{name}: the fused replacement never ran ({patched.get(name)})"
