@@ -293,6 +293,30 @@ int p3d_phong_shade_backward(const float* grad_colors, const int64_t* pix_to_fac
                              int N, int H, int W, int K, int64_t F, float* grad_bary_coords, float* grad_face_attrs,
                              float* grad_texels, float* grad_params, p3d_stream_t stream);
 
+/* ---- SoftPhongShader in one kernel each way: Phong shading fused with softmax_rgb_blend --------------------------------
+ *
+ * replaces SoftPhongShader.forward (pytorch3d/renderer/mesh/shader.py:113-147): phong_shading (renderer/mesh/shading.py:
+ * 100-125) followed by softmax_rgb_blend (renderer/blending.py:147-244).  Same inputs as p3d_phong_shade_* plus the
+ * fragments' dists / zbuf and the blend parameters of p3d_softmax_rgb_blend_*; the per-sample colours (N,H,W,K,3) and
+ * their gradient never reach memory.  K must be 1, 2, 4, 8 or 16 (p3d_soft_phong_supported_k; other K: run the two
+ * operators one after the other), otherwise P3D_ERR_INVALID_ARG.
+ *   forward: out (N,H,W,4) RGBA fully written.
+ *   backward: grad_out (N,H,W,4) -> grad_bary (N,H,W,K,3), grad_dists, grad_zbuf (N,H,W,K) [and grad_texels (N,H,W,K,3)
+ *   with D = 6] fully written; grad_face_attrs (F,3,D) zeroed and accumulated; grad_params (N, 25) zeroed and
+ *   accumulated when non-null. */
+int p3d_soft_phong_supported_k(int K);
+int p3d_soft_phong_forward(const int64_t* pix_to_face, const float* bary_coords, const float* dists, const float* zbuf,
+                           const float* face_attrs, int D, const float* texels, const float* params, int light_kind,
+                           float sigma, float gamma, const float background[3], float znear, float zfar,
+                           const float* znear_per_image, const float* zfar_per_image, int N, int H, int W, int K, int64_t F,
+                           float* out, p3d_stream_t stream);
+int p3d_soft_phong_backward(const float* grad_out, const int64_t* pix_to_face, const float* bary_coords, const float* dists,
+                            const float* zbuf, const float* face_attrs, int D, const float* texels, const float* params,
+                            int light_kind, float sigma, float gamma, const float background[3], float znear, float zfar,
+                            const float* znear_per_image, const float* zfar_per_image, int N, int H, int W, int K, int64_t F,
+                            float* grad_bary, float* grad_dists, float* grad_zbuf, float* grad_face_attrs, float* grad_texels,
+                            float* grad_params, p3d_stream_t stream);
+
 /* replaces TexturesUV.sample_textures (pytorch3d/renderer/mesh/textures.py:1190-1268, one map per mesh):
  * interpolate_face_attributes of the per-face uvs + torch.lerp to grid coordinates + F.grid_sample on K expanded
  * NCHW copies of the maps + permutes, and their autograd graph, with one kernel each way reading the maps in their

@@ -3,6 +3,9 @@
 
     rasterize_meshes -> phong_shading (vertex colours) -> softmax_rgb_blend -> loss -> backward to the vertices
 
+once with the shading and the blend as two operators (round 2) and once with csrc/soft_phong.hip (round 3: one kernel
+each way, the per-sample colours never in HBM),
+
 i.e. what MeshRenderer(MeshRasterizer, SoftPhongShader) runs per training step (renderer/mesh/renderer.py:41-63,
 shader.py: SoftPhongShader.forward), every stage through this package's fused kernels.  Prints one JSON line with the
 wall time per step and the per-kernel HIP-event times.  Run on the GPU box:  python profiles/bench_pipeline.py
@@ -53,31 +56,38 @@ def main():
     bp = p3d.BlendParams(1e-4, 1e-4, (1.0, 1.0, 1.0))
     lib = _lib.load()
 
-    def step():
+    def step(fused):
         vp.grad = vcol.grad = None
         m = meshes.update_verts_packed(vp)
         frag = Frag(*p3d.rasterize_meshes(m, image_size=H, blur_radius=blur, faces_per_pixel=K, perspective_correct=True,
                                           clip_barycentric_coords=True))
-        colors = p3d.phong_shading_vertex_colors(m, frag, L, cam, M, vcol)
-        img = p3d.softmax_rgb_blend(colors, frag, bp)
+        if fused:
+            img = sh.soft_phong_shading(m, frag, L, cam, M, None, bp, verts_colors_packed=vcol)
+        else:
+            colors = p3d.phong_shading_vertex_colors(m, frag, L, cam, M, vcol)
+            img = p3d.softmax_rgb_blend(colors, frag, bp)
         img.backward(g_img)
 
-    for _ in range(3):
-        step()
-    torch.cuda.synchronize()
-    lib.p3d_profile_reset()
-    lib.p3d_profile_enable(1)
-    iters = 10
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        step()
-    torch.cuda.synchronize()
-    wall = (time.perf_counter() - t0) / iters * 1e3
-    lib.p3d_profile_enable(0)
-    k = {n: ms / c for n, (c, ms) in sorted(_lib.profile_snapshot().items())}
-    print(json.dumps({"config": f"soft Phong render step fwd+bwd: rasterize -> phong (vertex colours) -> softmax blend, "
-                                f"N={B} 512x512 K=8", "wall_ms": wall, "Mpix_per_s": B * H * H / wall / 1e3,
-                      "kernel_sum_ms": sum(k.values()), "kernels_ms": {n: round(v, 4) for n, v in k.items()}}), flush=True)
+    out = {}
+    for fused in (False, True):
+        for _ in range(3):
+            step(fused)
+        torch.cuda.synchronize()
+        lib.p3d_profile_reset()
+        lib.p3d_profile_enable(1)
+        iters = 10
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            step(fused)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / iters * 1e3
+        lib.p3d_profile_enable(0)
+        k = {n: ms / c for n, (c, ms) in sorted(_lib.profile_snapshot().items())}
+        out["fused_soft_phong" if fused else "phong_then_blend"] = {
+            "wall_ms": wall, "Mpix_per_s": B * H * H / wall / 1e3, "kernel_sum_ms": sum(k.values()),
+            "kernels_ms": {n: round(v, 4) for n, v in k.items()}}
+    out["config"] = f"soft Phong render step fwd+bwd: rasterize -> Phong (vertex colours) -> softmax blend, N={B} 512x512 K=8"
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -81,6 +81,13 @@ _SIGNATURES = {
                                         c_ptr, c_ptr]),
     "p3d_phong_shade_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_int, c_int, c_int,
                                          c_int, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "p3d_soft_phong_supported_k": (c_int, [c_int]),
+    "p3d_soft_phong_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_f32, c_f32,
+                                       ctypes.POINTER(c_f32), c_f32, c_f32, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_i64,
+                                       c_ptr, c_ptr]),
+    "p3d_soft_phong_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_int, c_f32, c_f32,
+                                        ctypes.POINTER(c_f32), c_f32, c_f32, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_i64,
+                                        c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "p3d_sample_uv_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_i64, c_int, c_int, c_int,
                                       c_int, c_int, c_int, c_ptr, c_ptr]),
     "p3d_sample_uv_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_i64, c_int, c_int,

@@ -213,3 +213,96 @@ def gouraud_shading(meshes, fragments, lights, cameras, materials, verts_colors_
     ambient, diffuse, specular = _light_points(verts, meshes.verts_normals_packed(), rows, kind)
     shaded = verts_colors_packed * (ambient + diffuse) + specular
     return interpolate_face_attributes(fragments.pix_to_face, fragments.bary_coords, gather_face_verts(shaded, faces))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SoftPhongShader in one kernel each way (csrc/soft_phong.hip): phong_shading + softmax_rgb_blend, the colours never in HBM
+# ---------------------------------------------------------------------------------------------------------------------
+class _SoftPhong(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pix_to_face, bary, dists, zbuf, face_attrs, texels, params, kind, sigma, gamma, bg, znear, zfar):
+        from .blending import _plane
+
+        N, H, W, K = pix_to_face.shape
+        dev = bary.device
+        p2f, b, d, z = pix_to_face.contiguous(), bary.contiguous(), dists.contiguous(), zbuf.contiguous()
+        fa = face_attrs.contiguous()
+        tx = texels.contiguous() if texels is not None else None
+        params = params.contiguous()
+        F, _, D = fa.shape
+        zn, zn_t = _plane(znear, N, dev)
+        zf, zf_t = _plane(zfar, N, dev)
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            out = torch.empty((N, H, W, 4), dtype=torch.float32, device=dev)
+            if out.numel():
+                rc = lib.p3d_soft_phong_forward(_C._ptr(p2f), _C._ptr(b), _C._ptr(d), _C._ptr(z), _C._ptr(fa), D, _C._ptr(tx),
+                                                _C._ptr(params), kind, float(sigma), float(gamma), bg, zn, zf, _C._ptr(zn_t),
+                                                _C._ptr(zf_t), N, H, W, K, F, _C._ptr(out), _C._stream(dev))
+                _lib.check(rc, "soft_phong_shading")
+        empty = torch.empty(0, device=dev)
+        ctx.save_for_backward(p2f, b, d, z, fa, tx if tx is not None else empty, params, zn_t if zn_t is not None else empty,
+                              zf_t if zf_t is not None else empty)
+        ctx.meta = (kind, float(sigma), float(gamma), bg, zn, zf, tx is not None, zn_t is not None, zf_t is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        p2f, b, d, z, fa, tx, params, zn_t, zf_t = ctx.saved_tensors
+        kind, sigma, gamma, bg, zn, zf, has_tx, has_zn, has_zf = ctx.meta
+        N, H, W, K = p2f.shape
+        F, _, D = fa.shape
+        dev = b.device
+        g = grad_out.contiguous()
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            gb = torch.empty((N, H, W, K, 3), dtype=torch.float32, device=dev)
+            gd = torch.empty((N, H, W, K), dtype=torch.float32, device=dev)
+            gz = torch.empty((N, H, W, K), dtype=torch.float32, device=dev)
+            gfa = torch.empty((F, 3, D), dtype=torch.float32, device=dev)
+            gt = torch.empty((N, H, W, K, 3), dtype=torch.float32, device=dev) if has_tx else None
+            gp = torch.empty((N, PARAM_FLOATS), dtype=torch.float32, device=dev) if ctx.needs_input_grad[6] else None
+            rc = lib.p3d_soft_phong_backward(_C._ptr(g), _C._ptr(p2f), _C._ptr(b), _C._ptr(d), _C._ptr(z), _C._ptr(fa), D,
+                                             _C._ptr(tx if has_tx else None), _C._ptr(params), kind, sigma, gamma, bg, zn, zf,
+                                             _C._ptr(zn_t if has_zn else None), _C._ptr(zf_t if has_zf else None), N, H, W, K, F,
+                                             _C._ptr(gb), _C._ptr(gd), _C._ptr(gz), _C._ptr(gfa), _C._ptr(gt), _C._ptr(gp),
+                                             _C._stream(dev))
+            _lib.check(rc, "soft_phong_shading_backward")
+        return None, gb, gd, gz, gfa, gt, gp, None, None, None, None, None, None
+
+
+def soft_phong_supported(fragments) -> bool:
+    """The fused kernels take K in {1, 2, 4, 8, 16} (a pixel's slots are adjacent lanes of one DPP row)."""
+    return int(fragments.pix_to_face.shape[-1]) in (1, 2, 4, 8, 16)
+
+
+def soft_phong_shading(meshes, fragments, lights, cameras, materials, texels, blend_params, znear=1.0, zfar=100.0,
+                       verts_colors_packed=None) -> torch.Tensor:
+    """SoftPhongShader.forward (renderer/mesh/shader.py:113-147) without its intermediate:
+    `softmax_rgb_blend(phong_shading(meshes, fragments, lights, cameras, materials, texels), fragments, blend_params,
+    znear, zfar)` -> RGBA (N,H,W,4), one kernel forward and one backward.  texels (N,H,W,K,3), or None with
+    verts_colors_packed (V,3): the TexturesVertex interpolation is fused in as well.  K outside {1, 2, 4, 8, 16}: the two
+    operators run one after the other."""
+    from .blending import _background, softmax_rgb_blend
+
+    if not soft_phong_supported(fragments):
+        colors = (phong_shading(meshes, fragments, lights, cameras, materials, texels) if texels is not None else
+                  phong_shading_vertex_colors(meshes, fragments, lights, cameras, materials, verts_colors_packed))
+        return softmax_rgb_blend(colors, fragments, blend_params, znear=znear, zfar=zfar)
+    if (texels is None) == (verts_colors_packed is None):
+        raise ValueError("soft_phong_shading: give either texels or verts_colors_packed")
+    named = [("dists", fragments.dists), ("zbuf", fragments.zbuf)]
+    named.append(("texels", texels) if texels is not None else ("verts_colors_packed", verts_colors_packed))
+    _check(fragments, *named)
+    if fragments.pix_to_face.dtype != torch.int64:
+        raise RuntimeError("soft_phong_shading: pix_to_face must be int64")
+    N = fragments.pix_to_face.shape[0]
+    dev = fragments.bary_coords.device
+    params, kind = pack_shade_params(lights, cameras, materials, N, dev)
+    if texels is not None:
+        rec = _face_records(meshes)
+    else:
+        rec = _face_records(meshes, gather_face_verts(verts_colors_packed, meshes.faces_packed()))
+    bg = _background(blend_params, dev, "soft_phong_shading")
+    return _SoftPhong.apply(fragments.pix_to_face, fragments.bary_coords, fragments.dists, fragments.zbuf, rec, texels, params, kind,
+                            blend_params.sigma, blend_params.gamma, bg, znear, zfar)

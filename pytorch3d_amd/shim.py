@@ -21,6 +21,8 @@ reference classes runs on them end to end:
                                                                  (csrc/transform.hip) + the fused rasterize_meshes below
     renderer.mesh.rasterize_meshes.rasterize_meshes           -> fused gather + rasterizer (+ HIP clipping), one autograd node
     renderer.mesh.clip.clip_faces / convert_clipped_...       -> csrc/clip.hip
+    renderer.mesh.shader.SoftPhongShader.forward              -> csrc/soft_phong.hip: shading + softmax blend in one kernel
+                                                                 each way (K in 1, 2, 4, 8, 16), TexturesVertex fused in
     renderer.blending.softmax_rgb_blend / hard_rgb_blend      -> csrc/blend.hip
     renderer.mesh.shading.phong_shading / flat_shading / gouraud_shading -> csrc/shade.hip (+ interp.hip)
     renderer.mesh.textures.TexturesUV / TexturesAtlas .sample_textures   -> csrc/texture*.hip, atlas.hip
@@ -258,6 +260,7 @@ def patch_reference_python():
     _PATCHED.append((textures.TexturesAtlas, "sample_textures", atlas_orig, atlas_sample))
 
     _patch_mesh_rasterizer(our_rm)
+    _patch_soft_phong_shader(our_shade)
 
 
 def _patch_mesh_rasterizer(our_rm):
@@ -317,6 +320,49 @@ def _patch_mesh_rasterizer(our_rm):
     forward.__wrapped__ = orig
     rz.MeshRasterizer.forward = forward
     _PATCHED.append((rz.MeshRasterizer, "forward", orig, forward))
+
+
+def _patch_soft_phong_shader(our_shade):
+    """SoftPhongShader.forward (shader.py:113-147): texels = meshes.sample_textures(fragments); phong_shading;
+    softmax_rgb_blend -> pytorch3d_amd.shading.soft_phong_shading (the colours never reach memory).  With TexturesVertex of
+    three channels the texel interpolation is fused in as well.  Falls back to the reference's forward (whose pieces are
+    themselves patched) whenever the fused kernels do not cover the call."""
+    import importlib
+
+    shader = importlib.import_module("pytorch3d.renderer.mesh.shader")
+    orig = shader.SoftPhongShader.forward
+
+    def forward(self, fragments, meshes, **kwargs):
+        try:
+            cameras = kwargs.get("cameras", self.cameras)
+            lights = kwargs.get("lights", self.lights)
+            materials = kwargs.get("materials", self.materials)
+            blend_params = kwargs.get("blend_params", self.blend_params)
+            ok = (cameras is not None and _shading_ok(meshes, fragments, lights, cameras, materials)
+                  and our_shade.soft_phong_supported(fragments) and _is_hip_f32(fragments.dists) and _is_hip_f32(fragments.zbuf)
+                  and not getattr(blend_params.background_color, "requires_grad", False))
+        except Exception:
+            ok = False
+        if ok:
+            tex = getattr(meshes, "textures", None)
+            vcol = texels = None
+            if type(tex).__name__ == "TexturesVertex" and tex.verts_features_packed().shape[-1] == 3:
+                vcol = tex.verts_features_packed()
+                ok = _is_hip_f32(vcol)
+            else:
+                texels = meshes.sample_textures(fragments)
+                ok = _is_hip_f32(texels) and texels.dim() == 5 and texels.shape[-1] == 3
+        _count("SoftPhongShader.forward", ok)
+        if not ok:
+            return orig(self, fragments, meshes, **kwargs)
+        znear = kwargs.get("znear", getattr(cameras, "znear", 1.0))
+        zfar = kwargs.get("zfar", getattr(cameras, "zfar", 100.0))
+        return our_shade.soft_phong_shading(meshes, fragments, lights, cameras, materials, texels, blend_params, znear=znear, zfar=zfar,
+                                            verts_colors_packed=vcol)
+
+    forward.__wrapped__ = orig
+    shader.SoftPhongShader.forward = forward
+    _PATCHED.append((shader.SoftPhongShader, "forward", orig, forward))
 
 
 def uninstall_python_patches():

@@ -1,7 +1,7 @@
 """End-to-end golden for the chain rasterize -> Phong shading -> softmax blend, generated FROM THE REFERENCE (build
 container only):
 
-    python tests/golden/make_golden_render.py   ->  tests/golden/render_ref.npz
+    python tests/golden/make_golden_render.py   ->  tests/golden/render_ref.npz, render_ref_k8.npz
 
 The reference's own `MeshRenderer(MeshRasterizer, SoftPhongShader)` (renderer/mesh/renderer.py:41-63, rasterizer.py:139-260,
 shader.py SoftPhongShader) with FoVPerspectiveCameras, PointLights, Materials and TexturesVertex on CPU (its C++ CPU
@@ -22,7 +22,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def main():
+def main(K=6, name="render_ref"):
     import make_golden as mg
     import _util as U
 
@@ -44,7 +44,7 @@ def main():
     sigma, gamma = 1e-4, 1e-4
     import math
 
-    settings = RasterizationSettings(image_size=48, blur_radius=math.log(1.0 / 1e-4 - 1.0) * sigma, faces_per_pixel=6,
+    settings = RasterizationSettings(image_size=48, blur_radius=math.log(1.0 / 1e-4 - 1.0) * sigma, faces_per_pixel=K,
                                      perspective_correct=True, clip_barycentric_coords=True, cull_backfaces=False,
                                      bin_size=0)
     lights = PointLights(location=((1.5, 2.0, -2.0), (-2.0, 1.0, -1.5)), ambient_color=((0.4, 0.4, 0.4),),
@@ -63,15 +63,17 @@ def main():
            "num_faces": torch.tensor([f.shape[0] for f in faces_l]), "camera_center": cameras.get_camera_center(),
            "light_location": lights.location, "light_ambient": lights.ambient_color, "light_diffuse": lights.diffuse_color,
            "light_specular": lights.specular_color, "shininess": materials.shininess, "sigma": sigma, "gamma": gamma,
-           "background": torch.tensor(blend.background_color), "blur_radius": settings.blur_radius, "K": 6, "image_size": 48,
+           "background": torch.tensor(blend.background_color), "blur_radius": settings.blur_radius, "K": K, "image_size": 48,
            "znear": 1.0, "zfar": 100.0, "pix_to_face": fr.pix_to_face, "zbuf": fr.zbuf,
            "grad_verts_colors": torch.cat([c.grad for c in cols_l]),
            # gradient wrt the NDC vertices is not separable from the camera transform here; the colour gradient and
            # the image pin the chain, vertex gradients are covered per stage by the other fixtures
            }
-    mg.save("render_ref", **out)
+    mg.save(name, **out)
     print("coverage", float((fr.pix_to_face[..., 0] >= 0).float().mean()))
 
 
 if __name__ == "__main__":
     main()
+    # the same scene at K = 8: one of the capacities of the fused soft-Phong kernels (csrc/soft_phong.hip: 1, 2, 4, 8, 16)
+    main(K=8, name="render_ref_k8")
