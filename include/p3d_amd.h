@@ -46,7 +46,14 @@ const char* p3d_error_string(int code);
 
 /* ---- meshes -------------------------------------------------------------------------- */
 
-/* Scratch bytes for p3d_rasterize_meshes / p3d_rasterize_meshes_coarse (0 when bin_size == 0). */
+/* Scratch bytes for p3d_rasterize_meshes / p3d_rasterize_meshes_coarse (0 when bin_size == 0).
+ * Sized for the WORST case, because sizing it exactly would need a host sync: the bin lists are reserved as
+ * min(F * bins, N * bins * max_faces_per_bin) int32 entries (every face in every bin, or every bin at its cap), plus
+ * per-(mesh, bin) counters, offsets and the tile plan (~20 B per bin) and per-(1024-face chunk, bin) partial counts.
+ * Only the used prefix is ever touched.  Examples at 512 x 512 (1024 internal bins per image), max_faces_per_bin =
+ * max(10000, F / 5) as the reference's wrapper picks it: one 5.8k-face mesh 24 MB; the bench batch (N = 64, F = 321k)
+ * 1.3 GB; an un-sharded batch of 512 such meshes 42 GB -- shard the batch (pytorch3d_amd/sharding.py) or lower
+ * max_faces_per_bin when that matters.  Reuse the workspace across calls; it carries no state between them. */
 size_t p3d_rasterize_meshes_workspace_bytes(int64_t F, int N, int H, int W, int bin_size, int max_faces_per_bin);
 
 /* replaces RasterizeMeshes, pytorch3d/csrc/rasterize_meshes/rasterize_meshes.h:513-562

@@ -248,8 +248,13 @@ def test_autograd_mirror_and_reference_cpu_build():
     ours = [o.detach().cpu() for o in out]
     same = ours[0] == r[0]
     set_same = (ours[0].sort(-1).values == r[0].sort(-1).values).all(-1)
-    assert set_same.float().mean().item() > 0.995, f"per-pixel face sets differ: {1 - set_same.float().mean().item()}"
-    assert same.float().mean().item() > 0.97, f"idx mismatch fraction {1 - same.float().mean().item()}"
+    n_set, n_idx = int((~set_same).sum()), int((~same).sum())
+    print(f"[mirror vs reference CPU build] pixels whose face SET differs {n_set} / {set_same.numel()}, slots whose index differs "
+          f"{n_idx} / {same.numel()} (tie swaps at shared edges, see above)")
+    # observed on MI355X (round 3): 4 of 8192 pixels with a different face set, 138 of 32768 slots with a different index
+    # (0.4 %: this scene is mostly shared edges at 64x64); the gates are twice that
+    assert n_set <= 8, n_set
+    assert n_idx <= 276, n_idx
     assert torch.allclose(ours[1], r[1], atol=1e-5, rtol=0)
     assert torch.allclose(ours[2][same], r[2][same], atol=1e-5, rtol=0)
     assert torch.allclose(ours[3][same], r[3][same], atol=1e-5, rtol=0)

@@ -94,9 +94,9 @@ def test_reference_hot_path_test_modules_pass_on_the_hip_kernels(report):
                      "TexturesAtlas.sample_textures"):
             assert patched.get(name, {}).get("fused", 0) > 0, f"{name}: the fused replacement never ran ({patched.get(name)})"
         print("fused / fallback calls of the patched reference functions:", patched)
-    for op in ("rasterize_meshes_backward", "rasterize_points", "rasterize_points_backward",
-               "accum_alphacomposite", "accum_weightedsumnorm", "accum_weightedsum", "interp_face_attrs_forward",
-               "sigmoid_alpha_blend") + (("rasterize_meshes",) if patched is None else ()):
+    # (patched: the fused rasterize_meshes calls the C ABI itself, forward and backward, not `_C.rasterize_meshes*`)
+    for op in ("rasterize_points", "rasterize_points_backward", "accum_alphacomposite", "accum_weightedsumnorm", "accum_weightedsum",
+               "interp_face_attrs_forward", "sigmoid_alpha_blend") + (("rasterize_meshes", "rasterize_meshes_backward") if patched is None else ()):
         assert calls["hip"].get(op, 0) > 0, f"{op} never reached pytorch3d_amd"
 
 
