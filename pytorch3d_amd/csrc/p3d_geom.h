@@ -317,9 +317,12 @@ P3D_HD float seg_dist2_rec(f2 p, f2 a, f2 b, double rd_l2) {
   return (rd_l2 < 0.0) ? d_point : d_seg;
 }
 
-// face_hit on a FaceRec: identical outputs, 12 divisions -> 12 (cvt, mul_f64, cvt) + 2 reciprocals.
-P3D_HD bool face_hit_rec(const FaceRec& r, f2 p, float blur_radius, bool perspective_correct, bool clip_bary,
-                         FaceHit* out) {
+// face_hit on a FaceRec: identical outputs, 12 divisions -> 12 (cvt, mul_f64, cvt) + 2 reciprocals.  In two halves so that
+// the fine kernel can stop after the depth: a sample whose depth cannot enter a full queue needs no distance
+// (half of all evaluations at the bench workload, profiles/r03/probe_counts.txt).
+//
+// First half: barycentrics (bp: before the clip, decides `inside`; out->bary: what is stored) and the depth.
+P3D_HD f3 face_depth_rec(const FaceRec& r, f2 p, bool perspective_correct, bool clip_bary, FaceHit* out) {
   const f2 a = mk2(r.v0.x, r.v0.y);
   const f2 b = mk2(r.v1.x, r.v1.y);
   const f2 c = mk2(r.v2.x, r.v2.y);
@@ -344,17 +347,29 @@ P3D_HD bool face_hit_rec(const FaceRec& r, f2 p, float blur_radius, bool perspec
     const double rd = r.wide ? recip_for_div_wide(s) : recip_for_div(s);
     bc = mk3(exact_div(w0, rd), exact_div(w1, rd), exact_div(w2, rd));
   }
-  const float pz = bc.x * r.v0.z + bc.y * r.v1.z + bc.z * r.v2.z;
+  out->z = bc.x * r.v0.z + bc.y * r.v1.z + bc.z * r.v2.z;
+  out->bary = bc;
+  return bp;
+}
+
+// Second half: the signed squared distance and the hit test (bp, out->z from face_depth_rec).
+P3D_HD bool face_dist_rec(const FaceRec& r, f2 p, float blur_radius, f3 bp, FaceHit* out) {
+  const f2 a = mk2(r.v0.x, r.v0.y);
+  const f2 b = mk2(r.v1.x, r.v1.y);
+  const f2 c = mk2(r.v2.x, r.v2.y);
   const float e01 = seg_dist2_rec(p, a, b, r.rd_l01);
   const float e02 = seg_dist2_rec(p, a, c, r.rd_l02);
   const float e12 = seg_dist2_rec(p, b, c, r.rd_l12);
   const float dist = fminf(fminf(e01, e02), e12);
   const bool inside = (bp.x > 0.0f) & (bp.y > 0.0f) & (bp.z > 0.0f);
-  const bool hit = !(pz < 0.0f) & (inside | !(dist >= blur_radius));
-  out->z = pz;
   out->dist = inside ? -dist : dist;
-  out->bary = bc;
-  return hit;
+  return !(out->z < 0.0f) & (inside | !(dist >= blur_radius));
+}
+
+P3D_HD bool face_hit_rec(const FaceRec& r, f2 p, float blur_radius, bool perspective_correct, bool clip_bary,
+                         FaceHit* out) {
+  const f3 bp = face_depth_rec(r, p, perspective_correct, clip_bary, out);
+  return face_dist_rec(r, p, blur_radius, bp, out);
 }
 
 // ---------------------------------------------------------------------------

@@ -311,7 +311,7 @@ __device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue&
     if (pix_ok && !out && !too_deep) {
       const int f = __float_as_int(r2.y);
       FaceHit h;
-      bool hit;
+      bool hit = false;
       {
         const double2 d0 = *reinterpret_cast<const double2*>(&s_rec[jj][3]);
         const double2 d1 = *reinterpret_cast<const double2*>(&s_rec[jj][4]);
@@ -323,13 +323,13 @@ __device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue&
         fr.rd_l01 = d0.y;
         fr.rd_l02 = d1.x;
         fr.rd_l12 = d1.y;
-        if constexpr (PC && !GENERAL) {
-          fr.wide = false;  // wide faces make their chunk general (stage_chunk)
-          hit = face_hit_rec(fr, p, a.blur, true, true, &h);
-        } else {
-          fr.wide = __float_as_int(r2.w) != 0;
-          hit = face_hit_rec(fr, p, a.blur, persp, clip, &h);
-        }
+        const bool pcs = PC && !GENERAL;  // wide faces make their chunk general (stage_chunk)
+        fr.wide = pcs ? false : __float_as_int(r2.w) != 0;
+        const f3 bp = face_depth_rec(fr, p, pcs || persp, pcs || clip, &h);
+        // Depth first: a sample behind the camera or one that sorts after the K-th entry of a full queue is never
+        // stored, whatever its distance -- half of the evaluations at the bench workload end here for every lane
+        // (profiles/r03/probe_counts.txt).  Not under the neighbour rule: a face may replace its queued other half.
+        if (GENERAL || (!(h.z < 0.0f) && q.admits(K, h.z, f))) hit = face_dist_rec(fr, p, a.blur, bp, &h);
       }
       if (hit) {
         const float pl[kMeshPayload] = {h.dist, h.bary.x, h.bary.y, h.bary.z};
