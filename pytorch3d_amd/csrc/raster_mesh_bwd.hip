@@ -287,14 +287,14 @@ __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
 template <int KT>
 struct RowsCfg {
   static constexpr int kWaves = KT >= 16 ? 5 : 6;     // waves per SIMD the kernel is built for (512 / kWaves registers)
-  static constexpr int kSlots = KT >= 16 ? 136 : 118;  // 4 waves x kSlots x 56 B of LDS per workgroup
+  static constexpr int kSlots = KT >= 16 ? 136 : 116;  // 4 waves x kSlots x 56 B of LDS per workgroup (a multiple of 4: bucket probing)
 };
 
 template <int KT, bool TO_VERTS>
 __global__ __launch_bounds__(256, RowsCfg<KT>::kWaves) void mesh_backward_rows_kernel(BwdArgs a) {
   constexpr int SPR = KT / 4;  // steps per 16-pixel row segment
   static_assert(KT == 4 || KT == 8 || KT == 16, "16 K samples per row segment, 64 per step");
-  using Table = WaveTable<9, RowsCfg<KT>::kSlots, TO_VERTS ? kCorners : kRows, true>;
+  using Table = WaveTable<9, RowsCfg<KT>::kSlots, TO_VERTS ? kCorners : kRows, true, true>;
   __shared__ __align__(16) int s_table[4][Table::kLdsInts];
 
   const int tid = threadIdx.x;

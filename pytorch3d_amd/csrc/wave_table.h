@@ -33,8 +33,13 @@ constexpr int kEmptyKey = -1;
 //   kCorners out[index[f * (NV/3) + j / 3] * 3 + j % 3]         per-corner xyz partials of face f sent to its vertices
 // SPILL: see kFlushAt.
 enum { kRows = 0, kPlanar = 1, kChunk = 2, kCorners = 3 };
-template <int NV, int SLOTS, int LAYOUT = kRows, bool SPILL = false>
+// BUCKET: the keys are probed four at a time (one 16-byte LDS load per bucket of four slots instead of one load per slot;
+// SLOTS % 4 == 0).  A step's probe is a chain of dependent LDS round trips whose length is that of the longest chain among
+// the wave's primitives -- a fresh primitive in a table that is 3/4 full walks ~8 slots -- and in the rasterizer's
+// backward that chain was the largest single part of the table's cost (profiles/r03/bwd_ablate.txt).
+template <int NV, int SLOTS, int LAYOUT = kRows, bool SPILL = false, bool BUCKET = false>
 struct WaveTable {
+  static_assert(!BUCKET || SLOTS % 4 == 0, "bucket probing reads the keys as aligned groups of four");
   static constexpr int kStride = (NV + 3) / 4 * 4;  // floats per slot: values are moved as 16-byte chunks
   // The table is emptied before a step when it is fuller than this.  A step adds up to 64 primitives, so by default 64
   // slots stay in reserve and the table cannot overflow.  SPILL: no reserve -- the table fills up to 3/4 between
@@ -44,8 +49,11 @@ struct WaveTable {
   static constexpr int kFlushAt = SPILL ? SLOTS * 3 / 4 : SLOTS - 64;
   static constexpr int kLdsInts = SLOTS * (2 + kStride);
 
-  volatile int* keys;   // [SLOTS] primitive id or kEmptyKey (volatile: other lanes write between my store and re-load)
-  volatile int* owner;  // [SLOTS] last visitor of the slot, stamped with the step number (never needs resetting)
+  // keys / owner are LDS pointers BY TYPE: through generic pointers their volatile accesses compile to flat_load / flat_store
+  // with system scope (sc0 sc1), which take the vector-memory path to find out that the address is LDS.
+  typedef __attribute__((address_space(3))) volatile int LdsInt;
+  LdsInt* keys;   // [SLOTS] primitive id or kEmptyKey (volatile: other lanes write between my store and re-load)
+  LdsInt* owner;  // [SLOTS] last visitor of the slot, stamped with the step number (never needs resetting)
   float* vals;          // [SLOTS][kStride]
   int used;             // occupied slots (wave-uniform)
   int gen;              // step counter (wave-uniform), > 0
@@ -75,8 +83,8 @@ struct WaveTable {
 
   __device__ __forceinline__ void init(int* lds, int lane) {
     vals = reinterpret_cast<float*>(lds);  // first: keeps the 16-byte alignment of the workgroup's array
-    keys = lds + SLOTS * kStride;
-    owner = lds + SLOTS * kStride + SLOTS;
+    keys = (LdsInt*)(lds + SLOTS * kStride);
+    owner = (LdsInt*)(lds + SLOTS * kStride + SLOTS);
     used = 0;
     gen = 0;
     for (int i = lane; i < SLOTS; i += 64) {
@@ -119,7 +127,40 @@ struct WaveTable {
     int slot = -1;
     bool fresh = false;
     bool spill = false;  // no free slot left for this lane's primitive
-    if (active) {
+    if (BUCKET && active) {
+      // Invariant (no deletions between flushes): a key lives in the first bucket of its probe sequence that had an empty
+      // slot when it was inserted, and every bucket before it is full for good -- so a lookup that tests a bucket for the
+      // key BEFORE it looks for an empty slot finds it.
+      constexpr int NB = SLOTS / 4;
+      int b = (int)(((unsigned long long)((unsigned)f * 2654435761u) * (unsigned)NB) >> 32);
+      int tries = 0;
+      for (;;) {
+        typedef int KeyQuad __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) volatile KeyQuad LdsQuad;
+        LdsInt* kb = keys + 4 * b;
+        const KeyQuad k = *(LdsQuad*)kb;  // one ds_read_b128
+        const int hit = k.x == f ? 0 : (k.y == f ? 1 : (k.z == f ? 2 : (k.w == f ? 3 : -1)));
+        if (hit >= 0) {
+          slot = 4 * b + hit;
+          break;
+        }
+        const int e = k.x == kEmptyKey ? 0 : (k.y == kEmptyKey ? 1 : (k.z == kEmptyKey ? 2 : (k.w == kEmptyKey ? 3 : -1)));
+        if (e >= 0) {
+          kb[e] = f;  // several primitives may race for one empty slot: the last store wins, the losers read the bucket again
+          if (kb[e] == f) {
+            slot = 4 * b + e;
+            fresh = true;
+            break;
+          }
+          continue;
+        }
+        b = (b + 1 == NB) ? 0 : b + 1;
+        if (SPILL && ++tries == NB) {
+          spill = true;
+          break;
+        }
+      }
+    } else if (active) {
       int h = hash(f);
       int tries = 0;
       for (;;) {
@@ -155,7 +196,8 @@ struct WaveTable {
     const int stamp = (gen << 6) | lane;
     int prev = -1;
     if (linked) {
-      const int old = atomicExch(const_cast<int*>(&owner[slot]), stamp);
+      const int old = __hip_atomic_exchange((__attribute__((address_space(3))) int*)(owner + slot), stamp, __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_WORKGROUP);
       prev = (old >> 6) == gen ? (old & 63) : -1;
     }
     bool head = linked;
