@@ -107,6 +107,35 @@ int p3d_rasterize_meshes_backward_verts(const float* face_verts, const int64_t* 
                                         int64_t V, int N, int H, int W, int K, int perspective_correct,
                                         int clip_barycentric_coords, float* grad_verts, p3d_stream_t stream);
 
+/* ---- row cover: what the forward knows about empty image regions, handed to the backward (round 3) ----
+ * The reference's autograd node saves pix_to_face for the backward (renderer/mesh/rasterize_meshes.py:291-296) and the
+ * backward kernel reads all N*H*W*K entries of it to find the samples that hold a face (rasterize_meshes.cu:593-603).  At
+ * the bench workload 68 % of those reads find nothing.  The forward can say so for free: `cover` is (N, ceil(H/16),
+ * ceil(W/16)) int32; bit r of word (n, cy, cx) is set iff some pixel of output row 16*cy + r, columns 16*cx .. 16*cx+15 of
+ * image n holds a face (pix_to_face[n, y, x, 0] >= 0).  The autograd nodes of pytorch3d_amd/rasterize_meshes.py save it
+ * next to pix_to_face; a backward without cover (the `_C.rasterize_meshes_backward` drop-in) reads everything, as before.
+ * The backward TRUSTS the cover: a clear bit skips the row without looking. */
+size_t p3d_rasterize_meshes_cover_bytes(int N, int H, int W);
+
+/* p3d_rasterize_meshes + the row cover of its output (cover may be null: then identical to p3d_rasterize_meshes). */
+int p3d_rasterize_meshes_with_cover(const float* face_verts, const int64_t* mesh_to_face_first_idx,
+                                    const int64_t* num_faces_per_mesh, const int64_t* clipped_faces_neighbor_idx, int64_t F,
+                                    int N, int H, int W, float blur_radius, int faces_per_pixel, int bin_size,
+                                    int max_faces_per_bin, int perspective_correct, int clip_barycentric_coords,
+                                    int cull_backfaces, int64_t* pix_to_face, float* zbuf, float* bary, float* dists,
+                                    int32_t* cover, void* workspace, size_t workspace_bytes, p3d_stream_t stream);
+
+/* the two backward entry points with the cover of THAT pix_to_face (null: all rows are read) */
+int p3d_rasterize_meshes_backward_with_cover(const float* face_verts, const int64_t* pix_to_face, const float* grad_zbuf,
+                                             const float* grad_bary, const float* grad_dists, const int32_t* cover, int64_t F,
+                                             int N, int H, int W, int K, int perspective_correct,
+                                             int clip_barycentric_coords, float* grad_face_verts, p3d_stream_t stream);
+int p3d_rasterize_meshes_backward_verts_with_cover(const float* face_verts, const int64_t* faces, const int64_t* pix_to_face,
+                                                   const float* grad_zbuf, const float* grad_bary, const float* grad_dists,
+                                                   const int32_t* cover, int64_t F, int64_t V, int N, int H, int W, int K,
+                                                   int perspective_correct, int clip_barycentric_coords, float* grad_verts,
+                                                   p3d_stream_t stream);
+
 /* ---- packed vertices <-> per-face vertices (optional fast path of the L2 function) ------ */
 
 /* replaces the Python-side gather `face_verts = verts_packed[faces_packed]`

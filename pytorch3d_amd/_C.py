@@ -112,6 +112,16 @@ def rasterize_meshes(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, cli
                      blur_radius, faces_per_pixel, bin_size, max_faces_per_bin, perspective_correct,
                      clip_barycentric_coords, cull_backfaces):
     """RasterizeMeshes, rasterize_meshes.h:513-562.  Returns (pix_to_face, zbuf, bary, dists)."""
+    return _rasterize_meshes_covered(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx,
+                                     image_size, blur_radius, faces_per_pixel, bin_size, max_faces_per_bin, perspective_correct,
+                                     clip_barycentric_coords, cull_backfaces, want_cover=False)[0]
+
+
+def _rasterize_meshes_covered(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, image_size,
+                              blur_radius, faces_per_pixel, bin_size, max_faces_per_bin, perspective_correct,
+                              clip_barycentric_coords, cull_backfaces, want_cover=True):
+    """rasterize_meshes + the row cover of its output (include/p3d_amd.h: p3d_rasterize_meshes_with_cover) for the autograd
+    nodes of this package: ((pix_to_face, zbuf, bary, dists), cover or None)."""
     dev = _same_device(("face_verts", face_verts), ("mesh_to_face_first_idx", mesh_to_face_first_idx),
                        ("num_faces_per_mesh", num_faces_per_mesh),
                        ("clipped_faces_neighbor_idx", clipped_faces_neighbor_idx))
@@ -135,15 +145,17 @@ def rasterize_meshes(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, cli
     with torch.cuda.device(dev):
         out = _mesh_outputs(N, H, W, K, dev)
         if out[0].numel() == 0:
-            return out
+            return out, None
         nbytes = lib.p3d_rasterize_meshes_workspace_bytes(F, N, H, W, bin_size, M) if binned else 0
         ws = _workspace(nbytes, dev)
-        rc = lib.p3d_rasterize_meshes(_ptr(fv), _ptr(first), _ptr(count), _ptr(nb), F, N, H, W, float(blur_radius), K,
-                                      bin_size if binned else 0, M if binned else 0, int(bool(perspective_correct)),
-                                      int(bool(clip_barycentric_coords)), int(bool(cull_backfaces)), _ptr(out[0]),
-                                      _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _ptr(ws), ws.numel(), _stream(dev))
+        cover = torch.empty((N, (H + 15) // 16, (W + 15) // 16), dtype=torch.int32, device=dev) if want_cover else None
+        rc = lib.p3d_rasterize_meshes_with_cover(
+            _ptr(fv), _ptr(first), _ptr(count), _ptr(nb), F, N, H, W, float(blur_radius), K, bin_size if binned else 0,
+            M if binned else 0, int(bool(perspective_correct)), int(bool(clip_barycentric_coords)), int(bool(cull_backfaces)),
+            _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _ptr(cover) if want_cover else None, _ptr(ws), ws.numel(),
+            _stream(dev))
         _lib.check(rc, "rasterize_meshes")
-    return out
+    return out, cover
 
 
 def _rasterize_meshes_naive(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx,
@@ -211,9 +223,19 @@ def _rasterize_meshes_fine(face_verts, bin_faces, clipped_faces_neighbor_idx, im
     return out
 
 
+def cover_ptr(cover, N, H, W):
+    """Pointer of a row cover after checking that it is the cover of an (N, H, W, .) rasterization; None -> null."""
+    if cover is None:
+        return None
+    if cover.dtype != torch.int32 or tuple(cover.shape) != (N, (H + 15) // 16, (W + 15) // 16) or not cover.is_contiguous():
+        raise RuntimeError("row cover does not belong to this pix_to_face")
+    return _ptr(cover)
+
+
 def rasterize_meshes_backward(face_verts, pix_to_face, grad_zbuf, grad_bary, grad_dists, perspective_correct,
-                              clip_barycentric_coords):
-    """RasterizeMeshesBackward, rasterize_meshes.h:211-252.  Returns grad_face_verts (F,3,3)."""
+                              clip_barycentric_coords, _cover=None):
+    """RasterizeMeshesBackward, rasterize_meshes.h:211-252.  Returns grad_face_verts (F,3,3).
+    _cover (not part of the reference's signature): the row cover of THIS pix_to_face from _rasterize_meshes_covered."""
     dev = _same_device(("face_verts", face_verts), ("pix_to_face", pix_to_face), ("grad_zbuf", grad_zbuf),
                        ("grad_bary", grad_bary), ("grad_dists", grad_dists))
     # float atomics: the accumulation order is not deterministic (rasterize_meshes.cu:587)
@@ -229,9 +251,9 @@ def rasterize_meshes_backward(face_verts, pix_to_face, grad_zbuf, grad_bary, gra
         out = torch.empty((F, 3, 3), dtype=torch.float32, device=dev)
         if F == 0:
             return out
-        rc = lib.p3d_rasterize_meshes_backward(_ptr(fv), _ptr(p2f), _ptr(gz), _ptr(gb), _ptr(gd), F, N, H, W, K,
-                                               int(bool(perspective_correct)), int(bool(clip_barycentric_coords)),
-                                               _ptr(out), _stream(dev))
+        rc = lib.p3d_rasterize_meshes_backward_with_cover(
+            _ptr(fv), _ptr(p2f), _ptr(gz), _ptr(gb), _ptr(gd), cover_ptr(_cover, N, H, W), F, N, H, W, K,
+            int(bool(perspective_correct)), int(bool(clip_barycentric_coords)), _ptr(out), _stream(dev))
         _lib.check(rc, "rasterize_meshes_backward")
     return out
 

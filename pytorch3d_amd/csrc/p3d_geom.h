@@ -134,12 +134,14 @@ P3D_HD f3 bary_clip(f3 b) {
   return mk3(qdiv<FAST>(w0, s), qdiv<FAST>(w1, s), qdiv<FAST>(w2, s));
 }
 
-// Squared distance from p to segment (a, b) (geometry_utils.cuh:340-352).
+// Squared distance from p to segment (a, b) (geometry_utils.cuh:340-352).  FAST (backward only): the distances only
+// RANK the three edges there, see tri_dist2_bwd.
+template <bool FAST = false>
 P3D_HD float seg_dist2(f2 p, f2 a, f2 b) {
   const float bax = b.x - a.x;
   const float bay = b.y - a.y;
   const float l2 = bax * bax + bay * bay;
-  float t = (bax * (p.x - a.x) + bay * (p.y - a.y)) / l2;
+  float t = qdiv<FAST>(bax * (p.x - a.x) + bay * (p.y - a.y), l2);
   // degenerate edge (geometry_utils.cuh:345): distance to b.  Both results are formed and one is selected --
   // a branch here costs more than the five operations it would skip, and it sits in the hottest loop.
   const float ex = p.x - b.x;
@@ -444,31 +446,18 @@ P3D_HD TriGrad bary_coords_bwd(f2 p, f2 v0, f2 v1, f2 v2, f3 g) {
   const float inv_area = qdiv<true>(1.0f, area);
   const float inv_area2 = qdiv<true>(1.0f, area2);
 
-  // w0 = e0(p, v1, v2) / area(v2, v0, v1)
+  // w_k = e_k / area with e0 = edge_fn(p, v1, v2), e1 = edge_fn(p, v2, v0), e2 = edge_fn(p, v0, v1), area = edge_fn(v2, v0, v1)
+  // (geometry_utils.cuh:101-161).  Numerators: one edge_fn_bwd each.  Denominator: the reference runs edge_fn_bwd(v2, v0, v1, .)
+  // three times with upstream g_k * (-e_k / area^2); it is linear in the upstream, so the three are summed first.
   const EdgeGrad n0 = edge_fn_bwd(p, v1, v2, g.x * inv_area);
-  const EdgeGrad a0 = edge_fn_bwd(v2, v0, v1, g.x * (-e0 * inv_area2));
-  const f2 w0_v0 = a0.da;
-  const f2 w0_v1 = add2(n0.da, a0.db);
-  const f2 w0_v2 = add2(n0.db, a0.dp);
-
-  // w1 = e1(p, v2, v0) / area
   const EdgeGrad n1 = edge_fn_bwd(p, v2, v0, g.y * inv_area);
-  const EdgeGrad a1 = edge_fn_bwd(v2, v0, v1, g.y * (-e1 * inv_area2));
-  const f2 w1_v0 = add2(n1.db, a1.da);
-  const f2 w1_v1 = a1.db;
-  const f2 w1_v2 = add2(n1.da, a1.dp);
-
-  // w2 = e2(p, v0, v1) / area
   const EdgeGrad n2 = edge_fn_bwd(p, v0, v1, g.z * inv_area);
-  const EdgeGrad a2 = edge_fn_bwd(v2, v0, v1, g.z * (-e2 * inv_area2));
-  const f2 w2_v0 = add2(n2.da, a2.da);
-  const f2 w2_v1 = add2(n2.db, a2.db);
-  const f2 w2_v2 = a2.dp;
+  const EdgeGrad ar = edge_fn_bwd(v2, v0, v1, -(g.x * e0 + g.y * e1 + g.z * e2) * inv_area2);
 
   TriGrad r;
-  r.d0 = add2(add2(w0_v0, w1_v0), w2_v0);
-  r.d1 = add2(add2(w0_v1, w1_v1), w2_v1);
-  r.d2 = add2(add2(w0_v2, w1_v2), w2_v2);
+  r.d0 = add2(add2(n1.db, n2.da), ar.da);
+  r.d1 = add2(add2(n0.da, n2.db), ar.db);
+  r.d2 = add2(add2(n0.db, n1.da), ar.dp);
   return r;
 }
 
@@ -559,9 +548,12 @@ P3D_HD SegGrad seg_dist2_bwd(f2 p, f2 a, f2 b, float g) {
 // Gradient of tri_dist2 wrt the three vertices: only the closest edge gets one,
 // ties resolved e01, e02, e12 (geometry_utils.cuh:441-459).
 P3D_HD TriGrad tri_dist2_bwd(f2 p, f2 v0, f2 v1, f2 v2, float g) {
-  const float e01 = seg_dist2(p, v0, v1);
-  const float e02 = seg_dist2(p, v0, v2);
-  const float e12 = seg_dist2(p, v1, v2);
+  // The distances only choose the edge.  With the reciprocal instead of the IEEE division (10 instructions each) two
+  // edges that tie to within an ulp may swap: they tie where the nearest point is their common vertex, and there both
+  // give that vertex the same gradient and the other end point none (t saturates at 0 or 1).
+  const float e01 = seg_dist2<true>(p, v0, v1);
+  const float e02 = seg_dist2<true>(p, v0, v2);
+  const float e12 = seg_dist2<true>(p, v1, v2);
   // Which edge is closest (ties: e01, then e02, then e12); 3 = none (NaN distances).  The three candidate
   // branches of the reference are folded into ONE evaluation on selected endpoints: lanes of a wave pick
   // different edges, and divergent branches would run the edge gradient three times.

@@ -66,6 +66,8 @@ struct MeshArgs {
   float* zbuf;
   float* bary;
   float* dists;
+  int* cover;  // row cover of the output (include/p3d_amd.h: p3d_rasterize_meshes_with_cover), zeroed by the launcher; or null
+  int CY, CX;  // its 16 x 16 pixel blocks per image
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -353,6 +355,24 @@ __device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue&
         if (ins && q.admits(K, h.z, f)) q.insert(K, h.z, f, pl);
       }
     }
+  }
+}
+
+// Row cover (MeshArgs::cover): one wave's 8x8 sub-tile, lane -> input pixel (sy0 + lane / 8, sx0 + lane % 8), `any` = the
+// pixel holds at least one face.  Output pixel (H - 1 - y, W - 1 - x) belongs to block (yo / 16, xo / 16), bit yo % 16.
+// A sub-tile touches at most 2 x 2 blocks (one when H and W are multiples of 8); everything but the ballots is scalar.
+__device__ __forceinline__ void cover_mark(const MeshArgs& a, int n, int sy0, bool any, int yo, int xo, int lane) {
+  unsigned long long rem = __ballot(any);
+  const int wid = (yo >> 4) * a.CX + (xo >> 4);
+  while (rem) {
+    const int w0 = __builtin_amdgcn_readlane(wid, __builtin_ctzll(rem));
+    const unsigned long long same = __ballot(any && wid == w0);
+    unsigned bits = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if ((same >> (8 * j)) & 0xffull) bits |= 1u << ((a.H - 1 - (sy0 + j)) & 15);
+    rem &= ~same;
+    if (lane == 0) atomicOr(a.cover + ((int64_t)n * a.CY) * a.CX + w0, (int)bits);
   }
 }
 
@@ -707,8 +727,15 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
         const int yo = sy0 + (l2 >> 3), xo = sx0 + (l2 & 7);
         write_pixel<Queue, KT, IN_REGS>(a, q, ((int64_t)n * H + (H - 1 - yo)) * W + (W - 1 - xo));
       }
+      if (a.cover != nullptr && (!SPLIT || w == 0)) {  // uniform
+        int l2;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l2));
+        const int yo = sy0 + (l2 >> 3), xo = sx0 + (l2 & 7);
+        cover_mark(a, n, sy0, yo < y_end && xo < x_end && q.valid(0), H - 1 - yo, W - 1 - xo, l2);
+      }
     } else {
       if (wave_ok) write_subtile_fill_patch<Queue, KT, IN_REGS>(a, q, true, n, sy0, sx0, y_end, x_end, lane, pix_ok, yi, xi);
+      if (a.cover != nullptr && wave_ok && (!SPLIT || w == 0)) cover_mark(a, n, sy0, pix_ok && q.valid(0), H - 1 - yi, W - 1 - xi, lane);
     }
   }
   if constexpr (BINNED && !SPLIT && EXACT && (KT & 3) == 0) {
@@ -827,13 +854,36 @@ P3D_API size_t p3d_rasterize_fine_workspace_bytes(int N, int BH, int BW, int M) 
          align_up((rows + 1) * sizeof(int64_t), 256) + 256;
 }
 
-P3D_API int p3d_rasterize_meshes_naive(const float* face_verts, const int64_t* mesh_first, const int64_t* mesh_count,
-                                       const int64_t* neighbor, int64_t F, int N, int H, int W, float blur_radius, int K,
-                                       int persp, int clip, int cull, int64_t* p2f, float* zbuf, float* bary,
-                                       float* dists, p3d_stream_t stream) {
+P3D_API size_t p3d_rasterize_meshes_cover_bytes(int N, int H, int W) {
+  if (N <= 0 || H <= 0 || W <= 0) return 0;
+  return (size_t)N * (size_t)((H + 15) / 16) * (size_t)((W + 15) / 16) * sizeof(int32_t);
+}
+
+// the cover starts empty; the waves that write a pixel with a face set its bit
+static int cover_begin(MeshArgs* a, int32_t* cover, hipStream_t s) {
+  a->cover = cover;
+  a->CY = (a->H + 15) / 16;
+  a->CX = (a->W + 15) / 16;
+  if (cover == nullptr) return P3D_OK;
+  const size_t bytes = p3d_rasterize_meshes_cover_bytes(a->N, a->H, a->W);
+  return (bytes == 0 || hipMemsetAsync(cover, 0, bytes, s) == hipSuccess) ? P3D_OK : P3D_ERR_LAUNCH;
+}
+
+static int mesh_naive_impl(const float* face_verts, const int64_t* mesh_first, const int64_t* mesh_count,
+                           const int64_t* neighbor, int64_t F, int N, int H, int W, float blur_radius, int K, int persp,
+                           int clip, int cull, int64_t* p2f, float* zbuf, float* bary, float* dists, int32_t* cover,
+                           p3d_stream_t stream) {
   (void)F;
   const int rc = check_common(N, H, W, K);
   if (rc != P3D_OK) return rc;
+  if (cover != nullptr) {
+    MeshArgs z{};
+    z.N = N;
+    z.H = H;
+    z.W = W;
+    const int st = cover_begin(&z, cover, (hipStream_t)stream);  // also for K == 0: nothing is covered
+    if (st != P3D_OK) return st;
+  }
   if ((int64_t)N * H * W * K == 0) return P3D_OK;
   if ((!face_verts || !neighbor) && F > 0) return P3D_ERR_INVALID_ARG;
   if (!mesh_first || !mesh_count || !p2f || !zbuf || !bary || !dists) return P3D_ERR_INVALID_ARG;
@@ -855,13 +905,24 @@ P3D_API int p3d_rasterize_meshes_naive(const float* face_verts, const int64_t* m
   a.zbuf = zbuf;
   a.bary = bary;
   a.dists = dists;
+  a.cover = cover;  // zeroed above
+  a.CY = (H + 15) / 16;
+  a.CX = (W + 15) / 16;
   set_tiles(&a, H > W ? H : W, 1, 1);
   return launch_mesh_raster<false>(a, (hipStream_t)stream);
 }
 
+P3D_API int p3d_rasterize_meshes_naive(const float* face_verts, const int64_t* mesh_first, const int64_t* mesh_count,
+                                       const int64_t* neighbor, int64_t F, int N, int H, int W, float blur_radius, int K,
+                                       int persp, int clip, int cull, int64_t* p2f, float* zbuf, float* bary,
+                                       float* dists, p3d_stream_t stream) {
+  return mesh_naive_impl(face_verts, mesh_first, mesh_count, neighbor, F, N, H, W, blur_radius, K, persp, clip, cull, p2f,
+                         zbuf, bary, dists, nullptr, stream);
+}
+
 static int mesh_fine_from_csr(const float* face_verts, const int64_t* neighbor, const BinCSR& csr, int N, int H, int W,
                               const BinGeom& g, float blur_radius, int K, int persp, int clip, int cull, int64_t* p2f,
-                              float* zbuf, float* bary, float* dists, hipStream_t stream) {
+                              float* zbuf, float* bary, float* dists, hipStream_t stream, int32_t* cover = nullptr) {
   MeshArgs a{};
   a.face_verts = face_verts;
   a.neighbor = neighbor;
@@ -879,21 +940,30 @@ static int mesh_fine_from_csr(const float* face_verts, const int64_t* neighbor, 
   a.zbuf = zbuf;
   a.bary = bary;
   a.dists = dists;
+  const int st = cover_begin(&a, cover, stream);
+  if (st != P3D_OK) return st;
   set_tiles(&a, g.bin_size, g.BH, g.BW);
   return launch_mesh_raster<true>(a, stream);
 }
 
-P3D_API int p3d_rasterize_meshes(const float* face_verts, const int64_t* mesh_first, const int64_t* mesh_count,
-                                 const int64_t* neighbor, int64_t F, int N, int H, int W, float blur_radius, int K,
-                                 int bin_size, int max_faces_per_bin, int persp, int clip, int cull, int64_t* p2f,
-                                 float* zbuf, float* bary, float* dists, void* workspace, size_t workspace_bytes,
-                                 p3d_stream_t stream) {
+P3D_API int p3d_rasterize_meshes_with_cover(const float* face_verts, const int64_t* mesh_first, const int64_t* mesh_count,
+                                            const int64_t* neighbor, int64_t F, int N, int H, int W, float blur_radius,
+                                            int K, int bin_size, int max_faces_per_bin, int persp, int clip, int cull,
+                                            int64_t* p2f, float* zbuf, float* bary, float* dists, int32_t* cover,
+                                            void* workspace, size_t workspace_bytes, p3d_stream_t stream) {
   if (bin_size <= 0 || max_faces_per_bin <= 0) {
-    return p3d_rasterize_meshes_naive(face_verts, mesh_first, mesh_count, neighbor, F, N, H, W, blur_radius, K, persp,
-                                      clip, cull, p2f, zbuf, bary, dists, stream);
+    return mesh_naive_impl(face_verts, mesh_first, mesh_count, neighbor, F, N, H, W, blur_radius, K, persp, clip, cull,
+                           p2f, zbuf, bary, dists, cover, stream);
   }
   const int rc = check_common(N, H, W, K);
   if (rc != P3D_OK) return rc;
+  if (cover != nullptr && (int64_t)N * H * W * K == 0) {
+    MeshArgs z{};
+    z.N = N;
+    z.H = H;
+    z.W = W;
+    return cover_begin(&z, cover, (hipStream_t)stream);
+  }
   if ((int64_t)N * H * W * K == 0) return P3D_OK;
   if ((!face_verts || !neighbor) && F > 0) return P3D_ERR_INVALID_ARG;
   if (!mesh_first || !mesh_count || !p2f || !zbuf || !bary || !dists) return P3D_ERR_INVALID_ARG;
@@ -909,7 +979,17 @@ P3D_API int p3d_rasterize_meshes(const float* face_verts, const int64_t* mesh_fi
   if (st != P3D_OK) return st;
   BinCSR csr{ws.offset, ws.total, ws.list, TilePlan{ws.arank, ws.bg_list, ws.plan_hdr, ws.heavy_list}};
   return mesh_fine_from_csr(face_verts, neighbor, csr, N, H, W, g, blur_radius, K, persp, clip, cull, p2f, zbuf, bary,
-                            dists, s);
+                            dists, s, cover);
+}
+
+P3D_API int p3d_rasterize_meshes(const float* face_verts, const int64_t* mesh_first, const int64_t* mesh_count,
+                                 const int64_t* neighbor, int64_t F, int N, int H, int W, float blur_radius, int K,
+                                 int bin_size, int max_faces_per_bin, int persp, int clip, int cull, int64_t* p2f,
+                                 float* zbuf, float* bary, float* dists, void* workspace, size_t workspace_bytes,
+                                 p3d_stream_t stream) {
+  return p3d_rasterize_meshes_with_cover(face_verts, mesh_first, mesh_count, neighbor, F, N, H, W, blur_radius, K, bin_size,
+                                         max_faces_per_bin, persp, clip, cull, p2f, zbuf, bary, dists, nullptr, workspace,
+                                         workspace_bytes, stream);
 }
 
 P3D_API int p3d_rasterize_meshes_coarse(const float* face_verts, const int64_t* mesh_first, const int64_t* mesh_count,

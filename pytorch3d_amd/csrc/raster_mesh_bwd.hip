@@ -60,8 +60,15 @@ struct BwdArgs {
   int N, H, W, K;
   int RY, RX;  // regions per image
   int persp, clip;
-  int debug;  // P3D_DEBUG_BWD ablation bits (profiles/ablate.py): 1 no compute, 2 no accumulate, 4 no vertex gathers, 8 no global atomics in the table flush, 16 / 32 see wave_table.h, 64 no per-lane slot permutation
+  const int* cover;  // row cover written by the forward (p3d_rasterize_meshes_with_cover) or null; (N, CY, CX) words
+  int CY, CX;
 };
+
+// Rows of the wave's 16 x 16 area that may hold a sample (bit r: row ay + r); all of them without a cover.
+__device__ __forceinline__ unsigned area_rows(const BwdArgs& a, int n, int ay, int ax) {
+  if (a.cover == nullptr) return 0xffffu;
+  return (unsigned)a.cover[((int64_t)n * a.CY + (ay >> 4)) * a.CX + (ax >> 4)] & 0xffffu;
+}
 
 // Row loaders: KT contiguous elements starting at a (KT * elemsize)-aligned address.
 template <int KT>
@@ -156,17 +163,18 @@ __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
   const int ax = rx * kRegion + (w & 1) * 16;
   const int H = a.H, W = a.W, K = a.K;
   if (ay >= H || ax >= W) return;  // wave-uniform; no workgroup barriers in this kernel
+  const unsigned rowmask = area_rows(a, n, ay, ax);
+  if (rowmask == 0) return;  // the forward wrote no face into this area (uniform)
 
   Table tab;
   tab.init(s_table[w], lane);
   tab.index = a.faces;
   tab.index_limit = a.V;
-  tab.no_atomics = (P3D_DBG(a) & 8) != 0;
-  tab.dbg = P3D_DBG(a);
   const bool persp = a.persp != 0, clip = a.clip != 0;
 
 #pragma unroll 1
   for (int tile = 0; tile < 4; ++tile) {
+    if (((rowmask >> ((tile >> 1) * 8)) & 0xffu) == 0) continue;  // uniform
     const int yo = ay + (tile >> 1) * 8 + (lane >> 3);
     const int xo = ax + (tile & 1) * 8 + (lane & 7);
     const bool ok = yo < H && xo < W;
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
       // m distinct within every 2x2 pixel block -- the same (pixel, slot) samples, spread so that a step sees ~4x fewer
       // lanes per face.  The permutation is done by the loads (pairs are 16 / 8 / 8 / 24 bytes of the four rows): it
       // costs no VALU and no registers (a butterfly of conditional swaps over the 48 row registers spilled 76 of them).
-      const int m = (KT >= 4 && !(P3D_DBG(a) & 64)) ? (((lane & 1) | (((lane >> 3) & 1) << 1)) & (KT / 2 - 1)) : 0;
+      const int m = KT >= 4 ? (((lane & 1) | (((lane >> 3) & 1) << 1)) & (KT / 2 - 1)) : 0;
       if (ok) load_idx_row_pairs<KT>(a.p2f + base, m, f);
       bool any = false;
 #pragma unroll
@@ -201,21 +209,11 @@ __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
         if (__ballot(f[k] >= 0) == 0) continue;  // wave-uniform
         FaceGrad r;
         if (f[k] >= 0) {
-          const float* g = a.face_verts + (int64_t)((P3D_DBG(a) & 4) ? 0 : f[k]) * 9;
+          const float* g = a.face_verts + (int64_t)f[k] * 9;
           const f3 v0 = mk3(g[0], g[1], g[2]);
           const f3 v1 = mk3(g[3], g[4], g[5]);
           const f3 v2 = mk3(g[6], g[7], g[8]);
-          if (P3D_DBG(a) & 1) {
-#pragma unroll
-            for (int j = 0; j < 9; ++j) r.g[j] = v0.x + gz[k] + gd[k] + gb[3 * k];
-          } else {
-            r = face_sample_bwd(v0, v1, v2, p, gz[k], mk3(gb[3 * k], gb[3 * k + 1], gb[3 * k + 2]), gd[k], persp, clip,
-                                false);
-          }
-        }
-        if (P3D_DBG(a) & 2) {
-          if (f[k] >= 0 && r.g[0] == 1234.5f) a.grad_fv[0] = r.g[1];
-          continue;
+          r = face_sample_bwd(v0, v1, v2, p, gz[k], mk3(gb[3 * k], gb[3 * k + 1], gb[3 * k + 2]), gd[k], persp, clip, false);
         }
         tab.add(a.grad_fv, lane, f[k], r.g);
       }
@@ -288,11 +286,64 @@ template <int KT>
 struct RowsCfg {
   static constexpr int kWaves = KT >= 16 ? 5 : 6;     // waves per SIMD the kernel is built for (512 / kWaves registers)
   static constexpr int kSlots = KT >= 16 ? 136 : 116;  // 4 waves x kSlots x 56 B of LDS per workgroup (a multiple of 4: bucket probing)
+  static constexpr int kPix = 64 / KT;                 // pixels per 64-sample step
 };
+
+// Lane <-> sample inside a step: lane = slot * kPix + pixel, i.e. the kPix neighbouring pixels of ONE slot sit in adjacent
+// lanes (the loads address sample pixel * KT + slot of the same contiguous 64: same cache lines, permuted).  Neighbouring
+// pixels hold the same face at the same slot more often than not, so a face's samples form RUNS of adjacent lanes, and
+// runs can be summed with DPP row shifts -- VALU operations at ~3 cycles each, where a round of the table's list summation
+// is ten ds_bpermute at ~24 (profiles/microbench/valu_issue_mi355x.txt).  run_reduce is a segmented inclusive scan
+// (distances 1, 2, 4, 8 inside the group of kPix lanes); the last lane of a run ends up with the run's total and stays,
+// the others leave the step (f = -1).  The table then sees each face once per run instead of once per sample.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);  // lanes shifted in from outside the row read 0
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+template <int D, int PIX>
+__device__ __forceinline__ void run_level(bool e, float (&g)[9]) {
+  if constexpr (D < PIX) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const float sum = g[j] + dpp_f<0x110 + D>(g[j]);  // row_shr:D -- the partial sum D lanes to the left (one v_add_f32_dpp)
+      g[j] = e ? sum : g[j];
+    }
+  }
+}
+
+template <int PIX>
+__device__ __forceinline__ void run_reduce(int& f, float (&g)[9], int lane) {
+  const int pix = lane & (PIX - 1);
+  // Every shift is its own statement, executed by all 64 lanes: a DPP operand read from a lane that EXEC has switched off
+  // comes back as 0 on gfx9, so none of them may end up behind the short circuit of an && (the first version did: runs
+  // that started at a group's first pixel lost that pixel).
+  const int f_left = dpp_i<0x111>(f);   // row_shr:1
+  const int f_right = dpp_i<0x101>(f);  // row_shl:1
+  // e_d: lanes i - d .. i hold the same face (and are inside the group)
+  const int e1 = (pix >= 1) & (f >= 0) & (f_left == f);
+  const int e1_left = dpp_i<0x111>(e1);
+  const int e2 = PIX > 2 ? (e1 & e1_left) : 0;
+  const int e2_left = dpp_i<0x112>(e2);
+  const int e4 = PIX > 4 ? (e2 & e2_left) : 0;
+  const int e4_left = dpp_i<0x114>(e4);
+  const int e8 = PIX > 8 ? (e4 & e4_left) : 0;
+  const bool continues = (pix < PIX - 1) & (f_right == f);  // the lane to the right carries the run on
+  run_level<1, PIX>(e1 != 0, g);
+  run_level<2, PIX>(e2 != 0, g);
+  run_level<4, PIX>(e4 != 0, g);
+  run_level<8, PIX>(e8 != 0, g);
+  if (continues) f = -1;
+}
 
 template <int KT, bool TO_VERTS>
 __global__ __launch_bounds__(256, RowsCfg<KT>::kWaves) void mesh_backward_rows_kernel(BwdArgs a) {
   constexpr int SPR = KT / 4;  // steps per 16-pixel row segment
+  constexpr int PIX = RowsCfg<KT>::kPix;
   static_assert(KT == 4 || KT == 8 || KT == 16, "16 K samples per row segment, 64 per step");
   using Table = WaveTable<9, RowsCfg<KT>::kSlots, TO_VERTS ? kCorners : kRows, true, true>;
   __shared__ __align__(16) int s_table[4][Table::kLdsInts];
@@ -309,6 +360,11 @@ __global__ __launch_bounds__(256, RowsCfg<KT>::kWaves) void mesh_backward_rows_k
   const int ax = rx * kRegion + (w & 1) * 16;
   const int H = a.H, W = a.W;
   if (ay >= H || ax >= W) return;  // wave-uniform; no workgroup barriers in this kernel
+  const int rows = min(16, H - ay);
+  // Rows to walk: with the forward's row cover only those that hold a face -- at the bench workload 68 % of the 64-sample
+  // steps hold none, and reading their pix_to_face to find that out was a third of this kernel (profiles/r03/bwd_ablate.txt).
+  unsigned todo = area_rows(a, n, ay, ax) & ((1u << rows) - 1u);
+  if (todo == 0) return;  // uniform
 
   Table tab;
   tab.init(s_table[w], lane);
@@ -316,40 +372,49 @@ __global__ __launch_bounds__(256, RowsCfg<KT>::kWaves) void mesh_backward_rows_k
   tab.index_limit = a.V;
   const bool persp = a.persp != 0, clip = a.clip != 0;
 
-  const int rows = min(16, H - ay);
-  const int seg = min(16, W - ax) * KT;  // samples of a row segment inside the image
-  float px[SPR];                           // NDC x of this lane's pixel in step s of a row (rasterize_meshes.cu:458-462)
+  const int seg = min(16, W - ax) * KT;               // samples of a row segment inside the image
+  const int e = (lane & (PIX - 1)) * KT + lane / PIX;  // this lane's sample within a step's 64
+  float px[SPR];                                       // NDC x of this lane's pixel in step s of a row (rasterize_meshes.cu:458-462)
 #pragma unroll
-  for (int s = 0; s < SPR; ++s) px[s] = pix_to_ndc(W - 1 - (ax + (64 * s + lane) / KT), W, H);
+  for (int s = 0; s < SPR; ++s) px[s] = pix_to_ndc(W - 1 - (ax + s * PIX + (lane & (PIX - 1))), W, H);
   const int64_t area_base = (((int64_t)n * H + ay) * W + ax) * KT;
   const int64_t row_pitch = (int64_t)W * KT;
-  const int steps = rows * SPR;
 
-  // pix_to_face one step ahead: the only load every step needs (background costs nothing else)
-  int f_nxt = lane < seg ? (int)a.p2f[area_base + lane] : -1;
+  // pix_to_face one step ahead: the only load every step needs (steps without a sample cost nothing else)
+  int rn = __builtin_ctz(todo), sn = 0;  // the next step: row, part of the row
+  todo &= todo - 1;
+  int f_nxt = e < seg ? (int)a.p2f[area_base + (int64_t)rn * row_pitch + e] : -1;
 #pragma unroll 1
-  for (int u = 0; u < steps; ++u) {
-    const int r = u / SPR, s = u % SPR;  // SPR is a power of two
-    const int f = f_nxt;
+  while (rn >= 0) {
+    const int r = rn, s = sn;
+    int f = f_nxt;
+    if (++sn == SPR) {
+      sn = 0;
+      rn = todo ? __builtin_ctz(todo) : -1;
+      todo &= todo - 1;  // (0 stays 0)
+    }
     {
-      const int un = u + 1, rn = un / SPR, sn = un % SPR;
-      const int e = 64 * sn + lane;
-      f_nxt = (un < steps && e < seg) ? (int)a.p2f[area_base + (int64_t)rn * row_pitch + e] : -1;
+      const int en = 64 * sn + e;
+      f_nxt = (rn >= 0 && en < seg) ? (int)a.p2f[area_base + (int64_t)rn * row_pitch + en] : -1;
     }
     if (__ballot(f >= 0) == 0) continue;  // wave-uniform: nothing rendered in these 64 samples
     FaceGrad g;
     if (f >= 0) {
       const int64_t rb = area_base + (int64_t)r * row_pitch + 64 * s;  // uniform
-      const float gz = a.grad_zbuf[rb + lane], gd = a.grad_dists[rb + lane];
+      const float gz = a.grad_zbuf[rb + e], gd = a.grad_dists[rb + e];
       const float* gbp = a.grad_bary + 3 * rb;
-      const f3 gb = mk3(gbp[3 * lane], gbp[3 * lane + 1], gbp[3 * lane + 2]);
+      const f3 gb = mk3(gbp[3 * e], gbp[3 * e + 1], gbp[3 * e + 2]);
       const float* q = a.face_verts + (int64_t)f * 9;
       float pxs = px[0];
 #pragma unroll
       for (int c = 1; c < SPR; ++c) pxs = s == c ? px[c] : pxs;
       const f2 p = mk2(pxs, pix_to_ndc(H - 1 - (ay + r), H, W));
       g = face_sample_bwd(mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), mk3(q[6], q[7], q[8]), p, gz, gb, gd, persp, clip, false);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 9; ++j) g.g[j] = 0.0f;  // read by the neighbours' shifts, never added
     }
+    run_reduce<PIX>(f, g.g, lane);
     tab.add(a.grad_fv, lane, f, g.g);
   }
   if (tab.used > 0) tab.flush(a.grad_fv, lane);
@@ -364,7 +429,7 @@ using namespace p3d;
 namespace {
 int launch_mesh_backward(const float* face_verts, const int64_t* faces, int64_t V, const int64_t* p2f, const float* grad_zbuf,
                          const float* grad_bary, const float* grad_dists, int N, int H, int W, int K, int persp, int clip,
-                         float* grad_out, hipStream_t s) {
+                         float* grad_out, const int32_t* cover, hipStream_t s) {
   BwdArgs a;
   a.V = V;
   a.face_verts = face_verts;
@@ -382,12 +447,9 @@ int launch_mesh_backward(const float* face_verts, const int64_t* faces, int64_t 
   a.RX = (int)ceil_div(W, kRegion);
   a.persp = persp;
   a.clip = clip;
-#ifdef P3D_ABLATION
-  {
-    const char* e = getenv("P3D_DEBUG_BWD");
-    a.debug = e ? atoi(e) : 0;
-  }
-#endif
+  a.cover = cover;
+  a.CY = (H + 15) / 16;
+  a.CX = (W + 15) / 16;
   const int64_t blocks = (int64_t)N * a.RY * a.RX;
   if (blocks > 0x7fffffffll) return P3D_ERR_INVALID_ARG;
   LaunchScope ls("mesh_backward", s);
@@ -411,10 +473,10 @@ int launch_mesh_backward(const float* face_verts, const int64_t* faces, int64_t 
 }
 }  // namespace
 
-P3D_API int p3d_rasterize_meshes_backward(const float* face_verts, const int64_t* p2f, const float* grad_zbuf,
-                                          const float* grad_bary, const float* grad_dists, int64_t F, int N, int H,
-                                          int W, int K, int persp, int clip, float* grad_face_verts,
-                                          p3d_stream_t stream) {
+P3D_API int p3d_rasterize_meshes_backward_with_cover(const float* face_verts, const int64_t* p2f, const float* grad_zbuf,
+                                                     const float* grad_bary, const float* grad_dists, const int32_t* cover,
+                                                     int64_t F, int N, int H, int W, int K, int persp, int clip,
+                                                     float* grad_face_verts, p3d_stream_t stream) {
   if (F < 0 || N < 0 || H < 0 || W < 0 || K < 0) return P3D_ERR_INVALID_ARG;
   if (F == 0) return P3D_OK;
   if (!grad_face_verts || !face_verts) return P3D_ERR_INVALID_ARG;
@@ -423,13 +485,22 @@ P3D_API int p3d_rasterize_meshes_backward(const float* face_verts, const int64_t
   if ((int64_t)N * H * W * K == 0) return P3D_OK;
   if (!p2f || !grad_zbuf || !grad_bary || !grad_dists) return P3D_ERR_INVALID_ARG;
   return launch_mesh_backward(face_verts, nullptr, -1, p2f, grad_zbuf, grad_bary, grad_dists, N, H, W, K, persp, clip,
-                              grad_face_verts, s);
+                              grad_face_verts, cover, s);
 }
 
-P3D_API int p3d_rasterize_meshes_backward_verts(const float* face_verts, const int64_t* faces, const int64_t* p2f,
-                                                const float* grad_zbuf, const float* grad_bary, const float* grad_dists,
-                                                int64_t F, int64_t V, int N, int H, int W, int K, int persp, int clip,
-                                                float* grad_verts, p3d_stream_t stream) {
+P3D_API int p3d_rasterize_meshes_backward(const float* face_verts, const int64_t* p2f, const float* grad_zbuf,
+                                          const float* grad_bary, const float* grad_dists, int64_t F, int N, int H,
+                                          int W, int K, int persp, int clip, float* grad_face_verts,
+                                          p3d_stream_t stream) {
+  return p3d_rasterize_meshes_backward_with_cover(face_verts, p2f, grad_zbuf, grad_bary, grad_dists, nullptr, F, N, H, W, K,
+                                                  persp, clip, grad_face_verts, stream);
+}
+
+P3D_API int p3d_rasterize_meshes_backward_verts_with_cover(const float* face_verts, const int64_t* faces, const int64_t* p2f,
+                                                           const float* grad_zbuf, const float* grad_bary,
+                                                           const float* grad_dists, const int32_t* cover, int64_t F,
+                                                           int64_t V, int N, int H, int W, int K, int persp, int clip,
+                                                           float* grad_verts, p3d_stream_t stream) {
   if (F < 0 || V < 0 || N < 0 || H < 0 || W < 0 || K < 0) return P3D_ERR_INVALID_ARG;
   if (V == 0) return P3D_OK;
   if (!grad_verts) return P3D_ERR_INVALID_ARG;
@@ -438,5 +509,13 @@ P3D_API int p3d_rasterize_meshes_backward_verts(const float* face_verts, const i
   if (F == 0 || (int64_t)N * H * W * K == 0) return P3D_OK;
   if (!face_verts || !faces || !p2f || !grad_zbuf || !grad_bary || !grad_dists) return P3D_ERR_INVALID_ARG;
   return launch_mesh_backward(face_verts, faces, V, p2f, grad_zbuf, grad_bary, grad_dists, N, H, W, K, persp, clip,
-                              grad_verts, s);
+                              grad_verts, cover, s);
+}
+
+P3D_API int p3d_rasterize_meshes_backward_verts(const float* face_verts, const int64_t* faces, const int64_t* p2f,
+                                                const float* grad_zbuf, const float* grad_bary, const float* grad_dists,
+                                                int64_t F, int64_t V, int N, int H, int W, int K, int persp, int clip,
+                                                float* grad_verts, p3d_stream_t stream) {
+  return p3d_rasterize_meshes_backward_verts_with_cover(face_verts, faces, p2f, grad_zbuf, grad_bary, grad_dists, nullptr, F, V,
+                                                        N, H, W, K, persp, clip, grad_verts, stream);
 }

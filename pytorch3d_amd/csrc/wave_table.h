@@ -78,8 +78,6 @@ struct WaveTable {
     }
     return out + (int64_t)f * NV + j;
   }
-  bool no_atomics = false;  // ablation only (profiles/ablate.py): drop the global atomics of flush()
-  int dbg = 0;              // ablation only (results become wrong): 16 skip the list summation, 32 skip the table update
 
   __device__ __forceinline__ void init(int* lds, int lane) {
     vals = reinterpret_cast<float*>(lds);  // first: keeps the 16-byte alignment of the workgroup's array
@@ -109,7 +107,7 @@ struct WaveTable {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
           float* o = dest(out, f, j);
-          if (o && !no_atomics) unsafeAtomicAdd(o, vals[s * kStride + j]);
+          if (o) unsafeAtomicAdd(o, vals[s * kStride + j]);
         }
         keys[s] = kEmptyKey;
       }
@@ -188,7 +186,7 @@ struct WaveTable {
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
         float* o = dest(out, f, j);
-        if (o && !no_atomics) unsafeAtomicAdd(o, g[j]);
+        if (o) unsafeAtomicAdd(o, g[j]);
       }
     }
     const bool linked = active && !spill;
@@ -204,7 +202,7 @@ struct WaveTable {
     if (__ballot(prev >= 0)) {  // wave-uniform: some primitive is hit by more than one lane
       head = linked && owner[slot] == stamp;  // the last visitor heads the list
       // after step s every lane holds the sum of the 2^s list entries starting at itself
-      while (__ballot(prev >= 0) && !(dbg & 16)) {
+      while (__ballot(prev >= 0)) {
         const int src = prev >= 0 ? prev : lane;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -215,7 +213,7 @@ struct WaveTable {
         prev = prev >= 0 ? pp : -1;
       }
     }
-    if (head && !(dbg & 32)) {
+    if (head) {
       float4* row = reinterpret_cast<float4*>(vals + slot * kStride);
 #pragma unroll
       for (int c = 0; c < kStride / 4; ++c) {

@@ -164,11 +164,12 @@ class _RasterizeFaceVerts(torch.autograd.Function):
     def forward(ctx, face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx,
                 image_size=(256, 256), blur_radius=0.01, faces_per_pixel=0, bin_size=0, max_faces_per_bin=0,
                 perspective_correct=False, clip_barycentric_coords=False, cull_backfaces=False):
-        pix_to_face, zbuf, barycentric_coords, dists = _C.rasterize_meshes(
+        (pix_to_face, zbuf, barycentric_coords, dists), cover = _C._rasterize_meshes_covered(
             face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, image_size,
             blur_radius, faces_per_pixel, bin_size, max_faces_per_bin, perspective_correct, clip_barycentric_coords,
             cull_backfaces)
-        ctx.save_for_backward(face_verts, pix_to_face)
+        # the forward's row cover rides with pix_to_face (include/p3d_amd.h): the backward skips what the forward left empty
+        ctx.save_for_backward(face_verts, pix_to_face, cover)
         ctx.mark_non_differentiable(pix_to_face)
         # do not let autograd materialise a zero "gradient" for the int64 pix_to_face (1 GB at the bench size)
         ctx.set_materialize_grads(False)
@@ -178,7 +179,7 @@ class _RasterizeFaceVerts(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_pix_to_face, grad_zbuf, grad_barycentric_coords, grad_dists):
-        face_verts, pix_to_face = ctx.saved_tensors
+        face_verts, pix_to_face, cover = ctx.saved_tensors
         if grad_zbuf is None and grad_barycentric_coords is None and grad_dists is None:
             return (None,) * 12
         if grad_zbuf is None:
@@ -190,7 +191,7 @@ class _RasterizeFaceVerts(torch.autograd.Function):
                                                   device=pix_to_face.device)
         grad_face_verts = _C.rasterize_meshes_backward(face_verts, pix_to_face, grad_zbuf, grad_barycentric_coords,
                                                        grad_dists, ctx.perspective_correct,
-                                                       ctx.clip_barycentric_coords)
+                                                       ctx.clip_barycentric_coords, _cover=cover)
         return (grad_face_verts,) + (None,) * 11
 
 
@@ -213,10 +214,10 @@ class _RasterizeMeshVerts(torch.autograd.Function):
                 rc = lib.p3d_gather_face_verts(_C._ptr(verts_c), _C._ptr(faces_c), V, F, _C._ptr(face_verts),
                                                _C._stream(verts.device))
                 _lib.check(rc, "gather_face_verts")
-        pix_to_face, zbuf, barycentric_coords, dists = _C.rasterize_meshes(
+        (pix_to_face, zbuf, barycentric_coords, dists), cover = _C._rasterize_meshes_covered(
             face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, image_size, blur_radius,
             faces_per_pixel, bin_size, max_faces_per_bin, perspective_correct, clip_barycentric_coords, cull_backfaces)
-        ctx.save_for_backward(face_verts, faces_c, pix_to_face)
+        ctx.save_for_backward(face_verts, faces_c, pix_to_face, cover)
         ctx.mark_non_differentiable(pix_to_face)
         ctx.set_materialize_grads(False)
         ctx.V = V
@@ -227,7 +228,7 @@ class _RasterizeMeshVerts(torch.autograd.Function):
     def backward(ctx, grad_pix_to_face, grad_zbuf, grad_barycentric_coords, grad_dists):
         from . import _lib
 
-        face_verts, faces, pix_to_face = ctx.saved_tensors
+        face_verts, faces, pix_to_face, cover = ctx.saved_tensors
         if grad_zbuf is None and grad_barycentric_coords is None and grad_dists is None:
             return (None,) * 13
         _refuse_when_deterministic()
@@ -240,9 +241,10 @@ class _RasterizeMeshVerts(torch.autograd.Function):
         lib = _lib.load()
         with torch.cuda.device(dev):
             grad_verts = torch.empty((ctx.V, 3), dtype=torch.float32, device=dev)
-            rc = lib.p3d_rasterize_meshes_backward_verts(
+            rc = lib.p3d_rasterize_meshes_backward_verts_with_cover(
                 _C._ptr(face_verts), _C._ptr(faces), _C._ptr(pix_to_face), _C._ptr(gz), _C._ptr(gb), _C._ptr(gd),
-                faces.shape[0], ctx.V, N, H, W, K, ctx.flags[0], ctx.flags[1], _C._ptr(grad_verts), _C._stream(dev))
+                _C.cover_ptr(cover, N, H, W), faces.shape[0], ctx.V, N, H, W, K, ctx.flags[0], ctx.flags[1], _C._ptr(grad_verts),
+                _C._stream(dev))
             _lib.check(rc, "rasterize_meshes_backward")
         return (grad_verts,) + (None,) * 12
 
@@ -422,8 +424,9 @@ class _RasterizeMeshWorld(torch.autograd.Function):
                 rc = lib.p3d_transform_gather_face_verts(_C._ptr(verts_c), _C._ptr(faces_c), _C._ptr(face_first), _C._ptr(mats), V, F,
                                                          N, mats.shape[0], _C._ptr(face_verts), _C._stream(dev))
                 _lib.check(rc, "transform_gather_face_verts")
-        out = _C.rasterize_meshes(face_verts, face_first, num_faces, nbr, im_size, blur, K, bin_size, cap, persp, clip, cull)
-        ctx.save_for_backward(verts_c, faces_c, vert_first, mats, face_verts, out[0])
+        out, cover = _C._rasterize_meshes_covered(face_verts, face_first, num_faces, nbr, im_size, blur, K, bin_size, cap, persp, clip,
+                                                  cull)
+        ctx.save_for_backward(verts_c, faces_c, vert_first, mats, face_verts, out[0], cover)
         ctx.mark_non_differentiable(out[0])
         ctx.set_materialize_grads(False)
         ctx.flags = (int(persp), int(clip))
@@ -433,7 +436,7 @@ class _RasterizeMeshWorld(torch.autograd.Function):
     def backward(ctx, _g_idx, grad_zbuf, grad_bary, grad_dists):
         from . import _lib
 
-        verts, faces, vert_first, mats, face_verts, pix_to_face = ctx.saved_tensors
+        verts, faces, vert_first, mats, face_verts, pix_to_face, cover = ctx.saved_tensors
         if grad_zbuf is None and grad_bary is None and grad_dists is None:
             return (None,) * 8
         _refuse_when_deterministic()
@@ -447,9 +450,9 @@ class _RasterizeMeshWorld(torch.autograd.Function):
         V = verts.shape[0]
         with torch.cuda.device(dev):
             g_ndc = torch.empty((V, 3), dtype=torch.float32, device=dev)
-            rc = lib.p3d_rasterize_meshes_backward_verts(
-                _C._ptr(face_verts), _C._ptr(faces), _C._ptr(pix_to_face), _C._ptr(gz), _C._ptr(gb), _C._ptr(gd), faces.shape[0], V,
-                N, H, W, K, ctx.flags[0], ctx.flags[1], _C._ptr(g_ndc), _C._stream(dev))
+            rc = lib.p3d_rasterize_meshes_backward_verts_with_cover(
+                _C._ptr(face_verts), _C._ptr(faces), _C._ptr(pix_to_face), _C._ptr(gz), _C._ptr(gb), _C._ptr(gd),
+                _C.cover_ptr(cover, N, H, W), faces.shape[0], V, N, H, W, K, ctx.flags[0], ctx.flags[1], _C._ptr(g_ndc), _C._stream(dev))
             _lib.check(rc, "rasterize_meshes_backward")
             g_world = torch.empty((V, 3), dtype=torch.float32, device=dev)
             rc = lib.p3d_transform_verts_backward(_C._ptr(verts), _C._ptr(vert_first), _C._ptr(mats), _C._ptr(g_ndc), V,

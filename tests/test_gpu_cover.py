@@ -1,0 +1,141 @@
+"""Row cover (include/p3d_amd.h: p3d_rasterize_meshes_with_cover): the forward's summary of which 16-pixel row segments of
+pix_to_face hold a face, saved by the autograd nodes next to pix_to_face so that the backward does not read the empty ones.
+
+  * the cover equals the one computed from pix_to_face itself, bit for bit, on every forward kernel variant (K with and
+    without a vector-row path, register / memory queues, split mode for few tiles, naive path, clipped-face neighbours, image
+    sizes that are not multiples of 8 or 16, non-square images);
+  * the backward with the cover returns what the backward without it returns (same kernel, same samples; float atomics make
+    the last bits order-dependent), for both output forms (per face, per vertex) and for the kernels of every K class;
+  * the L2 autograd function carries it (its gradient equals the cover-less `_C` backward).
+"""
+import ctypes
+
+import pytest
+import torch
+
+import _util as U
+
+pytestmark = pytest.mark.gpu
+
+
+def cover_from_pix_to_face(p2f):
+    N, H, W, _ = p2f.shape
+    CY, CX = (H + 15) // 16, (W + 15) // 16
+    has = torch.zeros((N, CY * 16, CX * 16), dtype=torch.bool, device=p2f.device)
+    has[:, :H, :W] = p2f[..., 0] >= 0
+    rows = has.view(N, CY, 16, CX, 16).any(-1)  # (N, CY, 16, CX)
+    bits = (rows.to(torch.int32) << torch.arange(16, device=p2f.device, dtype=torch.int32).view(1, 1, 16, 1)).sum(2)
+    return bits.to(torch.int32)
+
+
+def _batch(n, seed, fmin=200, fmax=900):
+    import pytorch3d_amd as p3d
+
+    d = torch.device("cuda:0")
+    verts, faces = U.hetero_batch(n, seed=seed, fmin=fmin, fmax=fmax)
+    m = p3d.PackedMeshes([v.to(d) for v in verts], [f.to(d) for f in faces])
+    fv = m.verts_packed()[m.faces_packed()].contiguous()
+    return m, fv, m.mesh_to_faces_packed_first_idx(), m.num_faces_per_mesh()
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 5, 8, 12, 16, 20])
+@pytest.mark.parametrize("size,bin_size,n", [((64, 64), 0, 2), ((96, 96), 32, 1), ((100, 77), 16, 3), ((250, 250), 32, 6),
+                                            ((37, 53), 0, 2)])
+def test_cover_is_the_cover_of_pix_to_face(K, size, bin_size, n):
+    from pytorch3d_amd import _C
+
+    m, fv, first, cnt = _batch(n, seed=K + size[0])
+    nbr = torch.full((fv.shape[0],), -1, dtype=torch.int64, device=fv.device)
+    for blur in (0.0, 2e-3):
+        out, cover = _C._rasterize_meshes_covered(fv, first, cnt, nbr, size, blur, K, bin_size, 5000 if bin_size else 0, True, True,
+                                                  False)
+        plain = _C.rasterize_meshes(fv, first, cnt, nbr, size, blur, K, bin_size, 5000 if bin_size else 0, True, True, False)
+        assert all(torch.equal(a, b) for a, b in zip(out, plain))  # the cover changes nothing else
+        want = cover_from_pix_to_face(out[0])
+        assert cover.shape == want.shape and cover.dtype == torch.int32
+        assert torch.equal(cover, want), (int((cover != want).sum()), cover.numel())
+        assert int((want != 0).sum()) > 0 and int((want == 0).sum()) >= 0
+
+
+def test_cover_with_clipped_face_neighbours():
+    """the general loop nest (faces split by the near plane carry neighbour indices) ends in the same write path"""
+    from pytorch3d_amd import _C
+
+    m, fv, first, cnt = _batch(3, seed=5)
+    F = fv.shape[0]
+    nbr = torch.full((F,), -1, dtype=torch.int64, device=fv.device)
+    pairs = torch.arange(0, F - 1, 7, device=fv.device)
+    nbr[pairs], nbr[pairs + 1] = pairs + 1, pairs
+    out, cover = _C._rasterize_meshes_covered(fv, first, cnt, nbr, (128, 128), 1e-3, 4, 32, 5000, True, True, False)
+    assert torch.equal(cover, cover_from_pix_to_face(out[0]))
+
+
+@pytest.mark.parametrize("K", [1, 2, 4, 6, 8, 16])
+def test_backward_with_cover_equals_backward_without(K):
+    from pytorch3d_amd import _C, _lib
+
+    m, fv, first, cnt = _batch(4, seed=40 + K, fmin=300, fmax=1500)
+    nbr = torch.full((fv.shape[0],), -1, dtype=torch.int64, device=fv.device)
+    size = (120, 200)  # not multiples of 16 or 32: partial areas on both edges
+    out, cover = _C._rasterize_meshes_covered(fv, first, cnt, nbr, size, 1e-3, K, 32, 5000, True, True, False)
+    gen = torch.Generator().manual_seed(K)
+    gz, gb, gd = [torch.randn(t.shape, generator=gen).to(fv.device) for t in out[1:]]
+    a = _C.rasterize_meshes_backward(fv, out[0], gz, gb, gd, True, True)
+    b = _C.rasterize_meshes_backward(fv, out[0], gz, gb, gd, True, True, _cover=cover)
+    a2 = _C.rasterize_meshes_backward(fv, out[0], gz, gb, gd, True, True)
+    # two runs of the SAME call differ by the order of the float atomics; the cover must not add to that
+    noise = (a - a2).abs().max().item()
+    scale = a.abs().max().item()
+    assert (a - b).abs().max().item() <= max(4 * noise, 1e-5 * scale), ((a - b).abs().max().item(), noise, scale)
+    # per-vertex form
+    lib = _lib.load()
+    faces = m.faces_packed().contiguous()
+    V = m.verts_packed().shape[0]
+    N, H, W, _ = out[0].shape
+    res = []
+    for cv in (None, cover):
+        g = torch.empty((V, 3), dtype=torch.float32, device=fv.device)
+        rc = lib.p3d_rasterize_meshes_backward_verts_with_cover(
+            _C._ptr(fv), _C._ptr(faces), _C._ptr(out[0]), _C._ptr(gz), _C._ptr(gb), _C._ptr(gd), _C.cover_ptr(cv, N, H, W),
+            faces.shape[0], V, N, H, W, K, 1, 1, _C._ptr(g), _C._stream(fv.device))
+        _lib.check(rc, "backward_verts_with_cover")
+        res.append(g)
+    assert torch.allclose(res[0], res[1], rtol=1e-4, atol=1e-5 * res[0].abs().max().item())
+
+
+def test_an_empty_cover_means_no_gradient_at_all():
+    """the backward trusts the cover: with an all-zero one it touches nothing but the memset of its output"""
+    from pytorch3d_amd import _C
+
+    m, fv, first, cnt = _batch(2, seed=3)
+    nbr = torch.full((fv.shape[0],), -1, dtype=torch.int64, device=fv.device)
+    out, cover = _C._rasterize_meshes_covered(fv, first, cnt, nbr, (64, 64), 1e-3, 8, 0, 0, True, True, False)
+    g = [torch.ones_like(t) for t in out[1:]]
+    z = _C.rasterize_meshes_backward(fv, out[0], g[0], g[1], g[2], True, True, _cover=torch.zeros_like(cover))
+    assert float(z.abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        _C.rasterize_meshes_backward(fv, out[0], g[0], g[1], g[2], True, True, _cover=cover[:1])
+
+
+def test_autograd_function_carries_the_cover():
+    import pytorch3d_amd as p3d
+    from pytorch3d_amd import _C
+
+    d = torch.device("cuda:0")
+    verts, faces = U.hetero_batch(3, seed=77, fmin=300, fmax=1200)
+    vg = [v.to(d).requires_grad_(True) for v in verts]
+    meshes = p3d.PackedMeshes(vg, [f.to(d) for f in faces])
+    out = p3d.rasterize_meshes(meshes, image_size=(90, 130), blur_radius=1e-3, faces_per_pixel=8, perspective_correct=True,
+                               clip_barycentric_coords=True)
+    node = out[1].grad_fn
+    saved = [t for t in getattr(node, "saved_tensors", ()) if t is not None and t.dtype == torch.int32]
+    assert saved and torch.equal(saved[0], cover_from_pix_to_face(out[0]))
+    gen = torch.Generator().manual_seed(1)
+    g = [torch.randn(o.shape, generator=gen).to(d) for o in out[1:]]
+    torch.autograd.backward(list(out[1:]), g)
+    fv = meshes.verts_packed().detach()[meshes.faces_packed()]
+    gf = _C.rasterize_meshes_backward(fv, out[0], g[0], g[1], g[2], True, True)  # no cover
+    want = torch.zeros_like(meshes.verts_packed().detach()).index_put_((meshes.faces_packed().reshape(-1),), gf.reshape(-1, 3),
+                                                                       accumulate=True)
+    got = torch.cat([v.grad for v in vg])
+    assert torch.allclose(got, want, rtol=1e-3, atol=1e-5 * want.abs().max().item())
