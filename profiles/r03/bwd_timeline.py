@@ -49,4 +49,18 @@ for use_cover in (False, True):
     print("  mean waves in flight per CU (24 slots) at 20 points of the CU's own span, all waves:", (infl_all / len(cus)).round(1).tolist())
     print("  ... working waves:", (infl_work / len(cus)).round(1).tolist())
     print("  wave starts per CU per 1/20 span:", (starts / len(cus)).round(1).tolist())
+    ks = key * 4 + simd
+    mx_inflight, mean_inflight = [], []
+    for c in np.unique(ks)[:256]:
+        mc = ks == c
+        ev = np.concatenate([np.stack([st[mc], np.ones(mc.sum())], 1), np.stack([en[mc], -np.ones(mc.sum())], 1)])
+        ev = ev[np.argsort(ev[:, 0], kind="stable")]
+        run = np.cumsum(ev[:, 1])
+        mx_inflight.append(run.max())
+        mean_inflight.append(((en - st)[mc].sum()) / (en[mc].max() - st[mc].min()))
+    print("  per SIMD (first 256 SIMDs): waves in flight max over time: min %d median %d max %d; time-mean %.1f" % (
+        min(mx_inflight), np.median(mx_inflight), max(mx_inflight), np.mean(mean_inflight)))
+    wgs = np.arange(len(st)) // 4
+    same = [len(set(simd[i * 4:(i + 1) * 4])) for i in range(0, 4000, 7)]
+    print("  distinct SIMDs among the 4 waves of a workgroup (sample):", np.bincount(same).tolist())
     print("  sum of working-wave durations / (mean span x CUs x 24 slots) = %.2f" % (dur.sum() / (spans.mean() * len(cus) * 24)))

@@ -59,6 +59,7 @@ struct BwdArgs {
   int64_t V;  // vertices behind `faces` (index check of the fused scatter), -1 without
   int N, H, W, K;
   int RY, RX;  // regions per image
+  unsigned scatter, nblocks;  // workgroup b works on region (b * scatter) % nblocks (launch_mesh_backward)
   int persp, clip;
   const int* cover;  // row cover written by the forward (p3d_rasterize_meshes_with_cover) or null; (N, CY, CX) words
   int CY, CX;
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
   const int lane = tid & 63;
   const int w = tid >> 6;
   // region of this workgroup, 16x16 area of this wave
-  long long t = blockIdx.x;
+  long long t = (long long)(((unsigned long long)blockIdx.x * a.scatter) % a.nblocks);
   const int rx = (int)(t % a.RX);
   t /= a.RX;
   const int ry = (int)(t % a.RY);
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(256, RowsCfg<KT>::kWaves) void mesh_backward_rows_k
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = tid >> 6;
-  long long t = blockIdx.x;
+  long long t = (long long)(((unsigned long long)blockIdx.x * a.scatter) % a.nblocks);
   const int rx = (int)(t % a.RX);
   t /= a.RX;
   const int ry = (int)(t % a.RY);
@@ -452,6 +453,26 @@ int launch_mesh_backward(const float* face_verts, const int64_t* faces, int64_t 
   a.CX = (W + 15) / 16;
   const int64_t blocks = (int64_t)N * a.RY * a.RX;
   if (blocks > 0x7fffffffll) return P3D_ERR_INVALID_ARG;
+  // Regions in scattered order.  Workgroups reach XCDs and CUs round robin by index, and in (image, row, column) order the
+  // index of a region says where in the image it is: the CUs that drew the image borders ran empty while the ones with the
+  // image centres queued work -- 12 of 24 wave slots per CU busy on average, some CUs at 0 (profiles/r03/bwd_timeline.txt).
+  // b -> (b * scatter) mod blocks with an odd multiplier near blocks / golden ratio, coprime to blocks: a bijection that
+  // puts neighbouring indices far apart.
+  {
+    auto gcd = [](uint64_t x, uint64_t y) {
+      while (y) {
+        const uint64_t r = x % y;
+        x = y;
+        y = r;
+      }
+      return x;
+    };
+    uint64_t m = (uint64_t)((double)blocks * 0.6180339887) | 1u;
+    while (gcd(m, (uint64_t)blocks) != 1) m += 2;
+    a.scatter = (unsigned)(m % (uint64_t)blocks);
+    if (blocks == 1) a.scatter = 1;
+    a.nblocks = (unsigned)blocks;
+  }
   LaunchScope ls("mesh_backward", s);
   const unsigned grid = (unsigned)blocks;
 #define P3D_LAUNCH_MESH_BWD(TV)                                                  \
