@@ -125,16 +125,20 @@ int p3d_rasterize_meshes_with_cover(const float* face_verts, const int64_t* mesh
                                     int cull_backfaces, int64_t* pix_to_face, float* zbuf, float* bary, float* dists,
                                     int32_t* cover, void* workspace, size_t workspace_bytes, p3d_stream_t stream);
 
-/* the two backward entry points with the cover of THAT pix_to_face (null: all rows are read) */
+/* the two backward entry points with the cover of THAT pix_to_face (null: all rows are read).  workspace (optional, may be
+ * null; p3d_rasterize_meshes_backward_workspace_bytes): room for the list of covered 16 x 16 areas, so that the launch holds
+ * only workgroups with work -- workgroups reach the CUs round robin, and a mix of empty and full ones leaves CUs idle. */
+size_t p3d_rasterize_meshes_backward_workspace_bytes(int N, int H, int W);
 int p3d_rasterize_meshes_backward_with_cover(const float* face_verts, const int64_t* pix_to_face, const float* grad_zbuf,
                                              const float* grad_bary, const float* grad_dists, const int32_t* cover, int64_t F,
                                              int N, int H, int W, int K, int perspective_correct,
-                                             int clip_barycentric_coords, float* grad_face_verts, p3d_stream_t stream);
+                                             int clip_barycentric_coords, float* grad_face_verts, void* workspace,
+                                             size_t workspace_bytes, p3d_stream_t stream);
 int p3d_rasterize_meshes_backward_verts_with_cover(const float* face_verts, const int64_t* faces, const int64_t* pix_to_face,
                                                    const float* grad_zbuf, const float* grad_bary, const float* grad_dists,
                                                    const int32_t* cover, int64_t F, int64_t V, int N, int H, int W, int K,
                                                    int perspective_correct, int clip_barycentric_coords, float* grad_verts,
-                                                   p3d_stream_t stream);
+                                                   void* workspace, size_t workspace_bytes, p3d_stream_t stream);
 
 /* ---- packed vertices <-> per-face vertices (optional fast path of the L2 function) ------ */
 

@@ -63,4 +63,12 @@ for use_cover in (False, True):
     wgs = np.arange(len(st)) // 4
     same = [len(set(simd[i * 4:(i + 1) * 4])) for i in range(0, 4000, 7)]
     print("  distinct SIMDs among the 4 waves of a workgroup (sample):", np.bincount(same).tolist())
+    per_cu = np.array([(en - st)[(key == c) & act].sum() for c in cus]) / spans.mean()
+    print("  time-mean working waves in flight per CU: min %.1f p10 %.1f median %.1f p90 %.1f max %.1f" % (
+        per_cu.min(), np.percentile(per_cu, 10), np.median(per_cu), np.percentile(per_cu, 90), per_cu.max()))
+    nall = np.array([(key == c).sum() for c in cus]); nwork = np.array([((key == c) & act).sum() for c in cus])
+    order = np.argsort(per_cu)
+    print("  CUs with the least working waves: (key xcc/se/sh/cu, waves, working)", [(int(cus[i]) >> 8, (int(cus[i]) >> 5) & 7, (int(cus[i]) >> 4) & 1, int(cus[i]) & 15, int(nall[i]), int(nwork[i])) for i in order[:12]])
+    print("  CUs with the most: ", [(int(cus[i]) >> 8, (int(cus[i]) >> 5) & 7, (int(cus[i]) >> 4) & 1, int(cus[i]) & 15, int(nall[i]), int(nwork[i])) for i in order[-6:]])
+    print("  waves per CU: min %d median %d max %d; distinct raw hwid CU fields: cu %s sh %s se %s" % (nall.min(), np.median(nall), nall.max(), np.unique(cu).tolist(), np.unique(sh).tolist(), np.unique(se).tolist()))
     print("  sum of working-wave durations / (mean span x CUs x 24 slots) = %.2f" % (dur.sum() / (spans.mean() * len(cus) * 24)))

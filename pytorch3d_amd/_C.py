@@ -232,6 +232,12 @@ def cover_ptr(cover, N, H, W):
     return _ptr(cover)
 
 
+def backward_workspace(cover, N, H, W, dev):
+    """Scratch of the covered backward (the list of areas with work); empty without a cover."""
+    n = _lib.load().p3d_rasterize_meshes_backward_workspace_bytes(N, H, W) if cover is not None else 0
+    return _workspace(n, dev)
+
+
 def rasterize_meshes_backward(face_verts, pix_to_face, grad_zbuf, grad_bary, grad_dists, perspective_correct,
                               clip_barycentric_coords, _cover=None):
     """RasterizeMeshesBackward, rasterize_meshes.h:211-252.  Returns grad_face_verts (F,3,3).
@@ -251,9 +257,10 @@ def rasterize_meshes_backward(face_verts, pix_to_face, grad_zbuf, grad_bary, gra
         out = torch.empty((F, 3, 3), dtype=torch.float32, device=dev)
         if F == 0:
             return out
+        ws = backward_workspace(_cover, N, H, W, dev)
         rc = lib.p3d_rasterize_meshes_backward_with_cover(
             _ptr(fv), _ptr(p2f), _ptr(gz), _ptr(gb), _ptr(gd), cover_ptr(_cover, N, H, W), F, N, H, W, K,
-            int(bool(perspective_correct)), int(bool(clip_barycentric_coords)), _ptr(out), _stream(dev))
+            int(bool(perspective_correct)), int(bool(clip_barycentric_coords)), _ptr(out), _ptr(ws), ws.numel(), _stream(dev))
         _lib.check(rc, "rasterize_meshes_backward")
     return out
 

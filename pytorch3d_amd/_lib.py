@@ -40,10 +40,12 @@ _SIGNATURES = {
     "p3d_rasterize_meshes_with_cover": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_f32, c_int, c_int,
                                                 c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size,
                                                 c_ptr]),
+    "p3d_rasterize_meshes_backward_workspace_bytes": (c_size, [c_int, c_int, c_int]),
     "p3d_rasterize_meshes_backward_with_cover": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int,
-                                                         c_int, c_int, c_int, c_ptr, c_ptr]),
+                                                         c_int, c_int, c_int, c_ptr, c_ptr, c_size, c_ptr]),
     "p3d_rasterize_meshes_backward_verts_with_cover": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64,
-                                                               c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
+                                                               c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_size,
+                                                               c_ptr]),
     "p3d_gather_face_verts": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     "p3d_scatter_face_grads": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     "p3d_transform_gather_face_verts": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_ptr]),

@@ -59,7 +59,9 @@ struct BwdArgs {
   int64_t V;  // vertices behind `faces` (index check of the fused scatter), -1 without
   int N, H, W, K;
   int RY, RX;  // regions per image
-  unsigned scatter, nblocks;  // workgroup b works on region (b * scatter) % nblocks (launch_mesh_backward)
+  unsigned scatter, nblocks;  // work item b is region / area (b * scatter) % nblocks (launch_mesh_backward)
+  const int* area_list;       // rows kernel: the 16 x 16 areas that hold a face (area_list_kernel), or null: all of them
+  const int* area_count;
   int persp, clip;
   const int* cover;  // row cover written by the forward (p3d_rasterize_meshes_with_cover) or null; (N, CY, CX) words
   int CY, CX;
@@ -283,6 +285,20 @@ __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
 //     uniform; pix_to_face of the next step is requested before the current one is computed.
 // Table machinery (wave_table.h) unchanged: per step every lane contributes one sample.
 // ---------------------------------------------------------------------------------------------------------------------
+// The areas (words of the cover) that hold a face, in roughly ascending order (one atomic per wave of 64 words).
+__global__ __launch_bounds__(256) void area_list_kernel(const int* __restrict__ cover, int nareas, int* __restrict__ list,
+                                                         int* __restrict__ count) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool on = i < nareas && (cover[i] & 0xffff) != 0;
+  const unsigned long long m = __ballot(on);
+  if (m == 0) return;
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == 0) base = atomicAdd(count, __popcll(m));
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (on) list[base + mask_rank(m)] = i;
+}
+
 template <int KT>
 struct RowsCfg {
   static constexpr int kWaves = KT >= 16 ? 5 : 6;     // waves per SIMD the kernel is built for (512 / kWaves registers)
@@ -351,16 +367,25 @@ __global__ __launch_bounds__(256, RowsCfg<KT>::kWaves) void mesh_backward_rows_k
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int w = tid >> 6;
-  long long t = (long long)(((unsigned long long)blockIdx.x * a.scatter) % a.nblocks);
-  const int rx = (int)(t % a.RX);
-  t /= a.RX;
-  const int ry = (int)(t % a.RY);
-  const int n = (int)(t / a.RY);
-  const int ay = ry * kRegion + (w >> 1) * 16;
-  const int ax = rx * kRegion + (w & 1) * 16;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // One wave per 16 x 16 area.  With a cover the areas come from the list of those that hold a face (every workgroup
+  // then carries four working waves: workgroups reach the CUs round robin, not by load, and a mix of empty and full ones
+  // left half of the wave slots unused, profiles/r03/bwd_timeline.txt); without one, all areas in scattered order.
+  const unsigned item = blockIdx.x * 4u + (unsigned)w;
+  unsigned area;
+  if (a.area_list != nullptr) {
+    if (item >= (unsigned)*a.area_count) return;
+    area = (unsigned)a.area_list[item];
+  } else {
+    if (item >= a.nblocks) return;
+    area = (unsigned)(((unsigned long long)item * a.scatter) % a.nblocks);
+  }
+  const int cx = (int)(area % (unsigned)a.CX);
+  const unsigned t = area / (unsigned)a.CX;
+  const int cy = (int)(t % (unsigned)a.CY);
+  const int n = (int)(t / (unsigned)a.CY);
+  const int ay = cy * 16, ax = cx * 16;
   const int H = a.H, W = a.W;
-  if (ay >= H || ax >= W) return;  // wave-uniform; no workgroup barriers in this kernel
   const int rows = min(16, H - ay);
   // Rows to walk: with the forward's row cover only those that hold a face -- at the bench workload 68 % of the 64-sample
   // steps hold none, and reading their pix_to_face to find that out was a third of this kernel (profiles/r03/bwd_ablate.txt).
@@ -427,10 +452,27 @@ __global__ __launch_bounds__(256, RowsCfg<KT>::kWaves) void mesh_backward_rows_k
 
 using namespace p3d;
 
+P3D_API size_t p3d_rasterize_meshes_backward_workspace_bytes(int N, int H, int W);
+
 namespace {
+unsigned scatter_multiplier(uint64_t items) {
+  if (items <= 1) return 1;
+  auto gcd = [](uint64_t x, uint64_t y) {
+    while (y) {
+      const uint64_t r = x % y;
+      x = y;
+      y = r;
+    }
+    return x;
+  };
+  uint64_t m = (uint64_t)((double)items * 0.6180339887) | 1u;
+  while (gcd(m, items) != 1) m += 2;
+  return (unsigned)(m % items);
+}
+
 int launch_mesh_backward(const float* face_verts, const int64_t* faces, int64_t V, const int64_t* p2f, const float* grad_zbuf,
                          const float* grad_bary, const float* grad_dists, int N, int H, int W, int K, int persp, int clip,
-                         float* grad_out, const int32_t* cover, hipStream_t s) {
+                         float* grad_out, const int32_t* cover, void* workspace, size_t workspace_bytes, hipStream_t s) {
   BwdArgs a;
   a.V = V;
   a.face_verts = face_verts;
@@ -451,30 +493,28 @@ int launch_mesh_backward(const float* face_verts, const int64_t* faces, int64_t 
   a.cover = cover;
   a.CY = (H + 15) / 16;
   a.CX = (W + 15) / 16;
-  const int64_t blocks = (int64_t)N * a.RY * a.RX;
-  if (blocks > 0x7fffffffll) return P3D_ERR_INVALID_ARG;
-  // Regions in scattered order.  Workgroups reach XCDs and CUs round robin by index, and in (image, row, column) order the
-  // index of a region says where in the image it is: the CUs that drew the image borders ran empty while the ones with the
-  // image centres queued work -- 12 of 24 wave slots per CU busy on average, some CUs at 0 (profiles/r03/bwd_timeline.txt).
-  // b -> (b * scatter) mod blocks with an odd multiplier near blocks / golden ratio, coprime to blocks: a bijection that
-  // puts neighbouring indices far apart.
-  {
-    auto gcd = [](uint64_t x, uint64_t y) {
-      while (y) {
-        const uint64_t r = x % y;
-        x = y;
-        y = r;
-      }
-      return x;
-    };
-    uint64_t m = (uint64_t)((double)blocks * 0.6180339887) | 1u;
-    while (gcd(m, (uint64_t)blocks) != 1) m += 2;
-    a.scatter = (unsigned)(m % (uint64_t)blocks);
-    if (blocks == 1) a.scatter = 1;
-    a.nblocks = (unsigned)blocks;
+  a.area_list = nullptr;
+  a.area_count = nullptr;
+  const bool rows_kernel = K == 4 || K == 8 || K == 16;
+  // Work items in scattered order: workgroups reach XCDs and CUs round robin by index, and in (image, row, column) order
+  // the index says where in the image the item is -- the CUs that drew the borders ran empty while the ones with the image
+  // centres queued work.  b -> (b * scatter) mod items, odd multiplier near items / golden ratio, coprime: a bijection.
+  const int64_t items = rows_kernel ? (int64_t)N * a.CY * a.CX : (int64_t)N * a.RY * a.RX;
+  if (items > 0x7fffffffll) return P3D_ERR_INVALID_ARG;
+  a.nblocks = (unsigned)items;
+  a.scatter = scatter_multiplier((uint64_t)items);
+  if (rows_kernel && cover != nullptr && workspace != nullptr &&
+      workspace_bytes >= p3d_rasterize_meshes_backward_workspace_bytes(N, H, W)) {
+    int* count = static_cast<int*>(workspace);
+    int* list = count + 16;
+    if (hipMemsetAsync(count, 0, sizeof(int), s) != hipSuccess) return P3D_ERR_LAUNCH;
+    LaunchScope ls("mesh_backward_areas", s);
+    area_list_kernel<<<(unsigned)ceil_div(items, 256), 256, 0, s>>>(cover, (int)items, list, count);
+    a.area_list = list;
+    a.area_count = count;
   }
   LaunchScope ls("mesh_backward", s);
-  const unsigned grid = (unsigned)blocks;
+  const unsigned grid = rows_kernel ? (unsigned)ceil_div(items, 4) : (unsigned)items;
 #define P3D_LAUNCH_MESH_BWD(TV)                                                  \
   switch (K) {                                                                   \
     case 1: mesh_backward_kernel<1, TV><<<grid, 256, 0, s>>>(a); break;          \
@@ -494,10 +534,16 @@ int launch_mesh_backward(const float* face_verts, const int64_t* faces, int64_t 
 }
 }  // namespace
 
+P3D_API size_t p3d_rasterize_meshes_backward_workspace_bytes(int N, int H, int W) {
+  if (N <= 0 || H <= 0 || W <= 0) return 0;
+  return ((size_t)N * (size_t)((H + 15) / 16) * (size_t)((W + 15) / 16) + 16) * sizeof(int);
+}
+
 P3D_API int p3d_rasterize_meshes_backward_with_cover(const float* face_verts, const int64_t* p2f, const float* grad_zbuf,
                                                      const float* grad_bary, const float* grad_dists, const int32_t* cover,
                                                      int64_t F, int N, int H, int W, int K, int persp, int clip,
-                                                     float* grad_face_verts, p3d_stream_t stream) {
+                                                     float* grad_face_verts, void* workspace, size_t workspace_bytes,
+                                                     p3d_stream_t stream) {
   if (F < 0 || N < 0 || H < 0 || W < 0 || K < 0) return P3D_ERR_INVALID_ARG;
   if (F == 0) return P3D_OK;
   if (!grad_face_verts || !face_verts) return P3D_ERR_INVALID_ARG;
@@ -506,7 +552,7 @@ P3D_API int p3d_rasterize_meshes_backward_with_cover(const float* face_verts, co
   if ((int64_t)N * H * W * K == 0) return P3D_OK;
   if (!p2f || !grad_zbuf || !grad_bary || !grad_dists) return P3D_ERR_INVALID_ARG;
   return launch_mesh_backward(face_verts, nullptr, -1, p2f, grad_zbuf, grad_bary, grad_dists, N, H, W, K, persp, clip,
-                              grad_face_verts, cover, s);
+                              grad_face_verts, cover, workspace, workspace_bytes, s);
 }
 
 P3D_API int p3d_rasterize_meshes_backward(const float* face_verts, const int64_t* p2f, const float* grad_zbuf,
@@ -514,14 +560,15 @@ P3D_API int p3d_rasterize_meshes_backward(const float* face_verts, const int64_t
                                           int W, int K, int persp, int clip, float* grad_face_verts,
                                           p3d_stream_t stream) {
   return p3d_rasterize_meshes_backward_with_cover(face_verts, p2f, grad_zbuf, grad_bary, grad_dists, nullptr, F, N, H, W, K,
-                                                  persp, clip, grad_face_verts, stream);
+                                                  persp, clip, grad_face_verts, nullptr, 0, stream);
 }
 
 P3D_API int p3d_rasterize_meshes_backward_verts_with_cover(const float* face_verts, const int64_t* faces, const int64_t* p2f,
                                                            const float* grad_zbuf, const float* grad_bary,
                                                            const float* grad_dists, const int32_t* cover, int64_t F,
                                                            int64_t V, int N, int H, int W, int K, int persp, int clip,
-                                                           float* grad_verts, p3d_stream_t stream) {
+                                                           float* grad_verts, void* workspace, size_t workspace_bytes,
+                                                           p3d_stream_t stream) {
   if (F < 0 || V < 0 || N < 0 || H < 0 || W < 0 || K < 0) return P3D_ERR_INVALID_ARG;
   if (V == 0) return P3D_OK;
   if (!grad_verts) return P3D_ERR_INVALID_ARG;
@@ -530,7 +577,7 @@ P3D_API int p3d_rasterize_meshes_backward_verts_with_cover(const float* face_ver
   if (F == 0 || (int64_t)N * H * W * K == 0) return P3D_OK;
   if (!face_verts || !faces || !p2f || !grad_zbuf || !grad_bary || !grad_dists) return P3D_ERR_INVALID_ARG;
   return launch_mesh_backward(face_verts, faces, V, p2f, grad_zbuf, grad_bary, grad_dists, N, H, W, K, persp, clip,
-                              grad_verts, cover, s);
+                              grad_verts, cover, workspace, workspace_bytes, s);
 }
 
 P3D_API int p3d_rasterize_meshes_backward_verts(const float* face_verts, const int64_t* faces, const int64_t* p2f,
@@ -538,5 +585,5 @@ P3D_API int p3d_rasterize_meshes_backward_verts(const float* face_verts, const i
                                                 int64_t F, int64_t V, int N, int H, int W, int K, int persp, int clip,
                                                 float* grad_verts, p3d_stream_t stream) {
   return p3d_rasterize_meshes_backward_verts_with_cover(face_verts, faces, p2f, grad_zbuf, grad_bary, grad_dists, nullptr, F, V,
-                                                        N, H, W, K, persp, clip, grad_verts, stream);
+                                                        N, H, W, K, persp, clip, grad_verts, nullptr, 0, stream);
 }

@@ -95,9 +95,10 @@ def test_backward_with_cover_equals_backward_without(K):
     res = []
     for cv in (None, cover):
         g = torch.empty((V, 3), dtype=torch.float32, device=fv.device)
+        ws = _C.backward_workspace(cv, N, H, W, fv.device)
         rc = lib.p3d_rasterize_meshes_backward_verts_with_cover(
             _C._ptr(fv), _C._ptr(faces), _C._ptr(out[0]), _C._ptr(gz), _C._ptr(gb), _C._ptr(gd), _C.cover_ptr(cv, N, H, W),
-            faces.shape[0], V, N, H, W, K, 1, 1, _C._ptr(g), _C._stream(fv.device))
+            faces.shape[0], V, N, H, W, K, 1, 1, _C._ptr(g), _C._ptr(ws), ws.numel(), _C._stream(fv.device))
         _lib.check(rc, "backward_verts_with_cover")
         res.append(g)
     assert torch.allclose(res[0], res[1], rtol=1e-4, atol=1e-5 * res[0].abs().max().item())
