@@ -57,7 +57,7 @@ inline BinGeom make_internal_geom(int H, int W, int user_bin_size) {
 
 // Which bins hold primitives ("active") and which are background, written by the offsets scan at no extra launch:
 //   arank[row]  number of active rows before `row`          (valid for every row); bit 31: the row is in heavy_list
-//   bg_list[j]  the j-th background row, ascending           (j < hdr[1])
+//   bg_list[j]  the j-th background row, ascending           (j < hdr[1]); bg_list[rows - 1 - e]: the e-th ACTIVE row (e < hdr[0])
 //   heavy_list  rows with at least kHeavyRow primitives, in arrival order, at most kHeavyCap of them
 //   hdr         {A = active rows, B = background rows, rows appended to heavy_list (may exceed kHeavyCap: use min)}
 // The fine rasterizers use it to let the workgroups of active tiles write the -1 fill of the background tiles

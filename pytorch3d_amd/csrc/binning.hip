@@ -274,11 +274,14 @@ constexpr int kPlanShift = 40;
 constexpr long long kPlanMask = (1ll << kPlanShift) - 1;
 __device__ __forceinline__ long long plan_pack(int total) { return (long long)total + (total > 0 ? (1ll << kPlanShift) : 0ll); }
 // row `i` with running exclusive sum `ex` (packed) and own count `v`: offset, active rank, background list entry
-__device__ __forceinline__ void plan_emit(int64_t i, long long ex, int v, int64_t* offset, int* arank, int* bg_list,
-                                          int* plan_hdr, int* heavy_list) {
+__device__ __forceinline__ void plan_emit(int64_t i, long long ex, int v, int64_t rows, int64_t* offset, int* arank,
+                                          int* bg_list, int* plan_hdr, int* heavy_list) {
   offset[i] = ex & kPlanMask;
   int r = (int)(ex >> kPlanShift);
-  if (v <= 0) bg_list[i - r] = (int)i;
+  if (v <= 0)
+    bg_list[i - r] = (int)i;
+  else
+    bg_list[rows - 1 - r] = (int)i;  // the active rows from the back of the same array (A + B = rows)
   if (v >= kHeavyRow) {  // plan_hdr[2] was zeroed by an earlier kernel / phase of this launch
     const int pos = atomicAdd(&plan_hdr[2], 1);
     if (pos < kHeavyCap) {
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(1024) void bin_scan_offsets_kernel(const int* __res
   const long long ex = block_exclusive_scan_1024(i < rows ? plan_pack(v) : 0, wsum, &all);
   if (i < rows) {
     if (arank)
-      plan_emit(i, base + ex, v, offset, arank, bg_list, plan_hdr, heavy_list);
+      plan_emit(i, base + ex, v, rows, offset, arank, bg_list, plan_hdr, heavy_list);
     else
       offset[i] = (base + ex) & kPlanMask;
   }
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(1024) void bin_scan_small_kernel(int* __restrict__ 
     }
     long long all;
     const long long ex = block_exclusive_scan_1024(row < rows ? plan_pack(t) : 0, wsum, &all);
-    if (row < rows) plan_emit(row, carry + ex, t, offset, arank, bg_list, plan_hdr, heavy_list);
+    if (row < rows) plan_emit(row, carry + ex, t, rows, offset, arank, bg_list, plan_hdr, heavy_list);
     carry += all;
     __syncthreads();  // wsum is rewritten by the next step
   }

@@ -46,6 +46,7 @@ constexpr int kMeshPayload = 4; // dist, bary.x, bary.y, bary.z
 // bench meshes under SoftRas blur (full queues): 256 tiles 0.151 -> 0.084 ms, 1024 tiles 0.095 -> 0.115 ms (four queues
 // per pixel cull later than one), 2048 tiles 0.094 -> 0.224 ms.
 constexpr int kSplitMaxTiles = 512;
+constexpr unsigned kActiveRun = 32;  // consecutive active tiles an XCD takes at a time (mesh_raster_kernel: "Active tiles only")
 
 #ifndef P3D_FINE_WAVES_PER_SIMD
 #define P3D_FINE_WAVES_PER_SIMD 4  // caps the fine kernel at 128 VGPRs: 4 waves/SIMD instead of 2
@@ -570,7 +571,32 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
       blk -= (unsigned)kHeavyCap;
     }
   }
-  if (!front && !tile_of_block(a.tm, blk, &tc)) return;
+  // Active tiles only.  Workgroups reach the CUs round robin by index, not by load (profiles/r03/bwd_timeline.txt: the
+  // backward ran with half of its wave slots empty until every workgroup carried work), and 3 of 5 tiles of the bench launch
+  // are background: with the piggyback fill their workgroups only return, but a CU that draws a run of them idles.  The
+  // tile plan lists the active rows (from the back of bg_list); blocks walk that list -- in runs of kActiveRun consecutive
+  // rows per XCD (blockIdx % 8), which keeps neighbouring tiles and their faces in one L2 -- and the rest of the grid returns.
+  bool listed = false;
+  if constexpr (BINNED && !SPLIT && EXACT && (KT & 3) == 0) {
+    if (a.heavy_front && !front) {
+      const int A = a.csr.plan.hdr[0];
+      if (A > 0) {  // (no active tile at all: the background tiles fill themselves, in the tile map's order)
+        const unsigned q = blk >> 3, x = blk & 7u;
+        const unsigned e = ((q / kActiveRun) * 8u + x) * kActiveRun + (q % kActiveRun);
+        if (e >= (unsigned)A) return;  // uniform
+        const int64_t rows = (int64_t)a.N * a.tm.BH * a.tm.BW;
+        const int arow = a.csr.plan.bg_list[rows - 1 - e];
+        const int per_image = a.tm.BH * a.tm.BW;
+        tc.n = arow / per_image;
+        const int rem = arow - tc.n * per_image;
+        tc.by = rem / a.tm.BW;
+        tc.bx = rem - tc.by * a.tm.BW;
+        tc.ty = tc.tx = 0;
+        listed = true;
+      }
+    }
+  }
+  if (!front && !listed && !tile_of_block(a.tm, blk, &tc)) return;
   const int n = tc.n, by = tc.by, bx = tc.bx, ty = tc.ty, tx = tc.tx;
 
   const int H = a.H, W = a.W;
@@ -794,7 +820,7 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
   const bool split = BINNED && grid <= (unsigned)kSplitMaxTiles;
   // heavy tiles at the front of the grid: when the lists carry a tile plan and a tile is a bin
   a.heavy_front = BINNED && !split && a.csr.plan.hdr != nullptr && a.tm.Ty == 1 && a.tm.Tx == 1 && grid > 4u * kHeavyCap;
-  if (a.heavy_front) grid += (unsigned)kHeavyCap;
+  if (a.heavy_front) grid = (grid + 8u * kActiveRun - 1u) / (8u * kActiveRun) * (8u * kActiveRun) + (unsigned)kHeavyCap;
   const size_t dyn_lds = 0;
 #define P3D_LAUNCH_FINE(KT_, REGS_, EXACT_, Q_) launch_fine_variant<Q_, KT_, REGS_, BINNED, EXACT_>(a, grid, split, dyn_lds, stream)
 #define P3D_LAUNCH_FINE_W(KT_, WAVES_, Q_) mesh_raster_kernel<Q_, KT_, true, BINNED, false, WAVES_><<<grid, kStage, 0, stream>>>(a)
