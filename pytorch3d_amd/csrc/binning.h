@@ -64,11 +64,14 @@ inline BinGeom make_internal_geom(int H, int W, int user_bin_size) {
 // (raster_mesh.hip: "piggyback fill"): active row number r fills background rows [r * q, (r + 1) * q), q = ceil(B / A).
 constexpr int kHeavyRow = 384;   // primitives in a bin's list from which its tile is dispatched ahead of all others
 constexpr int kHeavyCap = 1024;  // workgroups reserved at the front of the fine grid for them
+constexpr int kPlanClasses = 64;  // list-length classes of the tile order (binning.hip: plan_class)
+constexpr int kPlanHdr = 4;       // plan_hdr: {A, B, heavy rows, order valid}, then kPlanClasses counts, then kPlanClasses cursors
 struct TilePlan {
   const int* arank;
   const int* bg_list;
   const int* hdr;
   const int* heavy_list;
+  const int* order = nullptr;  // the active rows by descending list length (kPlanClasses classes), valid when hdr[3] != 0
 };
 
 // Device-side CSR view consumed by the fine kernels.
@@ -88,8 +91,9 @@ struct BinWorkspace {
   int* list;         // (capacity)
   int* arank;        // (N*nbins)  TilePlan
   int* bg_list;      // (N*nbins)
-  int* plan_hdr;     // (4)
+  int* plan_hdr;     // (4 + 2 * kPlanClasses)
   int* heavy_list;   // (kHeavyCap)
+  int* order;        // (N*nbins)
   int64_t max_chunks;
   int64_t capacity;
 };

@@ -21,10 +21,11 @@ constexpr int kWavesPerChunk = kBinChunk / kWave;  // 16
 // plan: chunk_start[n] = sum_{m<n} ceil(count[m] / 1024); chunk_start[N] = total chunks.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void bin_plan_kernel(const int64_t* __restrict__ count, int N,
-                                                        int* __restrict__ chunk_start) {
+                                                        int* __restrict__ chunk_start, int* __restrict__ plan_hdr) {
   __shared__ int scan[1024];
   __shared__ int carry_s;
   const int tid = threadIdx.x;
+  if (tid < 2 * kPlanClasses) plan_hdr[kPlanHdr + tid] = 0;  // class histogram and cursors of the tile order (plan_class)
   if (tid == 0) carry_s = 0;
   __syncthreads();
   for (int base = 0; base < N; base += 1024) {
@@ -273,6 +274,13 @@ __global__ __launch_bounds__(256) void bin_scan_rows_kernel(int* __restrict__ co
 constexpr int kPlanShift = 40;
 constexpr long long kPlanMask = (1ll << kPlanShift) - 1;
 __device__ __forceinline__ long long plan_pack(int total) { return (long long)total + (total > 0 ? (1ll << kPlanShift) : 0ll); }
+// Tile order.  Workgroups reach the CUs round robin by index, so the ORDER of the fine kernel's work items is its load
+// balance (profiles/r03/bwd_timeline.txt).  The active rows are listed by descending list length -- a counting sort over
+// kPlanClasses classes of 8 primitives, folded into the two kernels of the offsets scan: the block sums build the class
+// histogram (LDS, then one global atomic per class and block), the offsets scan reserves each block's range per class and
+// scatters its rows.  Dealt longest-first every CU draws the same mix, and the launch has no tail of long tiles.
+__device__ __forceinline__ int plan_class(int v) { return kPlanClasses - 1 - min(v >> 3, kPlanClasses - 1); }  // 0 = longest
+
 // row `i` with running exclusive sum `ex` (packed) and own count `v`: offset, active rank, background list entry
 __device__ __forceinline__ void plan_emit(int64_t i, long long ex, int v, int64_t rows, int64_t* offset, int* arank,
                                           int* bg_list, int* plan_hdr, int* heavy_list) {
@@ -316,16 +324,25 @@ __global__ __launch_bounds__(1024) void bin_block_sums_kernel(const int* __restr
   __shared__ long long wsum[16];
   const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
   long long all;
-  block_exclusive_scan_1024(i < rows ? plan_pack(total[i]) : 0, wsum, &all);
+  const int v = i < rows ? total[i] : 0;
+  block_exclusive_scan_1024(i < rows ? plan_pack(v) : 0, wsum, &all);
   if (threadIdx.x == 0) blocksum[blockIdx.x] = all;
   if (plan_hdr && blockIdx.x == 0 && threadIdx.x == 0) plan_hdr[2] = 0;  // the heavy-row counter of the scan that follows
+  if (plan_hdr) {  // uniform
+    __shared__ int hist[kPlanClasses];
+    if (threadIdx.x < kPlanClasses) hist[threadIdx.x] = 0;
+    __syncthreads();
+    if (v > 0) atomicAdd(&hist[plan_class(v)], 1);
+    __syncthreads();
+    if (threadIdx.x < kPlanClasses && hist[threadIdx.x] > 0) atomicAdd(&plan_hdr[kPlanHdr + threadIdx.x], hist[threadIdx.x]);
+  }
 }
 
 __global__ __launch_bounds__(1024) void bin_scan_offsets_kernel(const int* __restrict__ total, int64_t rows,
                                                                 const long long* __restrict__ blocksum,
                                                                 int64_t* __restrict__ offset, int* __restrict__ arank,
                                                                 int* __restrict__ bg_list, int* __restrict__ plan_hdr,
-                                                                int* __restrict__ heavy_list) {
+                                                                int* __restrict__ heavy_list, int* __restrict__ order) {
   __shared__ long long wsum[16];
   __shared__ long long part[16];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -353,7 +370,24 @@ __global__ __launch_bounds__(1024) void bin_scan_offsets_kernel(const int* __res
     if (plan_hdr) {
       plan_hdr[0] = (int)(end >> kPlanShift);
       plan_hdr[1] = (int)(rows - (end >> kPlanShift));
+      plan_hdr[3] = order != nullptr ? 1 : 0;
     }
+  }
+  if (order != nullptr) {  // uniform: this block's active rows into their classes' ranges (see plan_class)
+    __shared__ int hist[kPlanClasses], start[kPlanClasses];
+    if (tid < kPlanClasses) hist[tid] = 0;
+    __syncthreads();
+    const int cls = v > 0 ? plan_class(v) : -1;
+    if (cls >= 0) atomicAdd(&hist[cls], 1);
+    __syncthreads();
+    if (tid < kPlanClasses) {
+      int before = 0;
+      for (int c = 0; c < tid; ++c) before += plan_hdr[kPlanHdr + c];  // (final: written by the kernel before this one)
+      start[tid] = before + (hist[tid] > 0 ? atomicAdd(&plan_hdr[kPlanHdr + kPlanClasses + tid], hist[tid]) : 0);
+      hist[tid] = 0;
+    }
+    __syncthreads();
+    if (cls >= 0) order[start[cls] + atomicAdd(&hist[cls], 1)] = (int)i;
   }
 }
 
@@ -368,7 +402,10 @@ __global__ __launch_bounds__(1024) void bin_scan_small_kernel(int* __restrict__ 
                                                               int* __restrict__ bg_list, int* __restrict__ plan_hdr,
                                                               int* __restrict__ heavy_list) {
   __shared__ int cs[kSelfPlanMax + 1];
-  if (threadIdx.x == 0) plan_hdr[2] = 0;  // visible to the atomics below after plan_in_lds's barrier
+  if (threadIdx.x == 0) {
+    plan_hdr[2] = 0;  // visible to the atomics below after plan_in_lds's barrier
+    plan_hdr[3] = 0;  // no sorted order for small launches
+  }
   __shared__ long long wsum[16];
   plan_in_lds(count, N, cs);
   const int tid = threadIdx.x;
@@ -536,8 +573,9 @@ bool bin_carve(Arena& arena, int64_t E, int N, const BinGeom& g, int M, BinWorks
   ws->list = arena.take<int>((size_t)ws->capacity);
   ws->arank = arena.take<int>((size_t)N * g.nbins);
   ws->bg_list = arena.take<int>((size_t)N * g.nbins);
-  ws->plan_hdr = arena.take<int>(4);
+  ws->plan_hdr = arena.take<int>(4 + 2 * kPlanClasses);
   ws->heavy_list = arena.take<int>(kHeavyCap);
+  ws->order = arena.take<int>((size_t)N * g.nbins);
   return arena.ok();
 }
 
@@ -557,7 +595,7 @@ int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t*
   const int* cs = small ? nullptr : ws.chunk_start;
   if (!small) {
     LaunchScope ls("bin_plan", stream);
-    bin_plan_kernel<<<1, 1024, 0, stream>>>(count, N, ws.chunk_start);
+    bin_plan_kernel<<<1, 1024, 0, stream>>>(count, N, ws.chunk_start, ws.plan_hdr);
   }
   const unsigned chunks = (unsigned)ws.max_chunks;
   {
@@ -586,7 +624,7 @@ int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t*
     const unsigned nb = (unsigned)ceil_div(rows, 1024);
     bin_block_sums_kernel<<<nb, 1024, 0, stream>>>(ws.total, rows, ws.blocksum, ws.plan_hdr);
     bin_scan_offsets_kernel<<<nb, 1024, 0, stream>>>(ws.total, rows, ws.blocksum, ws.offset, ws.arank, ws.bg_list, ws.plan_hdr,
-                                                     ws.heavy_list);
+                                                     ws.heavy_list, ws.order);
   }
   {
     LaunchScope ls("bin_fill", stream);
@@ -610,7 +648,7 @@ int exclusive_scan_i32(const int* in, int64_t n, long long* blocksum, int64_t* o
   if (n <= 0) return P3D_OK;
   const unsigned nb = (unsigned)ceil_div(n, 1024);
   bin_block_sums_kernel<<<nb, 1024, 0, stream>>>(in, n, blocksum, nullptr);
-  bin_scan_offsets_kernel<<<nb, 1024, 0, stream>>>(in, n, blocksum, out, nullptr, nullptr, nullptr, nullptr);
+  bin_scan_offsets_kernel<<<nb, 1024, 0, stream>>>(in, n, blocksum, out, nullptr, nullptr, nullptr, nullptr, nullptr);
   return launch_status();
 }
 

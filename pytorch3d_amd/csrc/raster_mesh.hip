@@ -581,11 +581,17 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
     if (a.heavy_front && !front) {
       const int A = a.csr.plan.hdr[0];
       if (A > 0) {  // (no active tile at all: the background tiles fill themselves, in the tile map's order)
-        const unsigned q = blk >> 3, x = blk & 7u;
-        const unsigned e = ((q / kActiveRun) * 8u + x) * kActiveRun + (q % kActiveRun);
-        if (e >= (unsigned)A) return;  // uniform
-        const int64_t rows = (int64_t)a.N * a.tm.BH * a.tm.BW;
-        const int arow = a.csr.plan.bg_list[rows - 1 - e];
+        int arow;
+        if (a.csr.plan.order != nullptr && a.csr.plan.hdr[3] != 0) {
+          if (blk >= (unsigned)A) return;  // uniform
+          arow = a.csr.plan.order[blk];    // longest lists first (binning.hip: plan_order_kernel)
+        } else {
+          const unsigned q = blk >> 3, x = blk & 7u;
+          const unsigned e = ((q / kActiveRun) * 8u + x) * kActiveRun + (q % kActiveRun);
+          if (e >= (unsigned)A) return;  // uniform
+          const int64_t rows = (int64_t)a.N * a.tm.BH * a.tm.BW;
+          arow = a.csr.plan.bg_list[rows - 1 - e];
+        }
         const int per_image = a.tm.BH * a.tm.BW;
         tc.n = arow / per_image;
         const int rem = arow - tc.n * per_image;
@@ -1003,7 +1009,7 @@ P3D_API int p3d_rasterize_meshes_with_cover(const float* face_verts, const int64
   int st = bin_build(kTriangles, face_verts, nullptr, mesh_first, mesh_count, F, N, g, max_faces_per_bin,
                      sqrtf(blur_radius), ws, s);
   if (st != P3D_OK) return st;
-  BinCSR csr{ws.offset, ws.total, ws.list, TilePlan{ws.arank, ws.bg_list, ws.plan_hdr, ws.heavy_list}};
+  BinCSR csr{ws.offset, ws.total, ws.list, TilePlan{ws.arank, ws.bg_list, ws.plan_hdr, ws.heavy_list, ws.order}};
   return mesh_fine_from_csr(face_verts, neighbor, csr, N, H, W, g, blur_radius, K, persp, clip, cull, p2f, zbuf, bary,
                             dists, s, cover);
 }
