@@ -56,22 +56,21 @@ inline BinGeom make_internal_geom(int H, int W, int user_bin_size) {
 }
 
 // Which bins hold primitives ("active") and which are background, written by the offsets scan at no extra launch:
-//   arank[row]  number of active rows before `row`          (valid for every row); bit 31: the row is in heavy_list
-//   bg_list[j]  the j-th background row, ascending           (j < hdr[1]); bg_list[rows - 1 - e]: the e-th ACTIVE row (e < hdr[0])
-//   heavy_list  rows with at least kHeavyRow primitives, in arrival order, at most kHeavyCap of them
-//   hdr         {A = active rows, B = background rows, rows appended to heavy_list (may exceed kHeavyCap: use min)}
-// The fine rasterizers use it to let the workgroups of active tiles write the -1 fill of the background tiles
-// (raster_mesh.hip: "piggyback fill"): active row number r fills background rows [r * q, (r + 1) * q), q = ceil(B / A).
-constexpr int kHeavyRow = 384;   // primitives in a bin's list from which its tile is dispatched ahead of all others
-constexpr int kHeavyCap = 1024;  // workgroups reserved at the front of the fine grid for them
-constexpr int kPlanClasses = 64;  // list-length classes of the tile order (binning.hip: plan_class)
-constexpr int kPlanHdr = 4;       // plan_hdr: {A, B, heavy rows, order valid}, then kPlanClasses counts, then kPlanClasses cursors
+//   arank[row]  number of active rows before `row`          (valid for every row)
+//   bg_list[j]  the j-th background row, ascending           (j < hdr[1])
+//   order[e]    the active rows by descending list length    (e < hdr[0]; kPlanClasses classes of 8 primitives,
+//               binning.hip: plan_class), valid when hdr[3] != 0 (not written by the single-workgroup scan of small launches)
+//   hdr         {A = active rows, B = background rows, unused, order valid}, then the class counts and cursors of the sort
+// The fine rasterizers use it to walk the tiles in a balanced order (raster_mesh.hip: "Which tile") and to let the
+// workgroups of active tiles write the -1 fill of the background tiles ("piggyback fill"): active row number r fills
+// background rows [r * q, (r + 1) * q), q = ceil(B / A).
+constexpr int kPlanClasses = 64;  // list-length classes of the tile order
+constexpr int kPlanHdr = 4;       // first class counter in plan_hdr
 struct TilePlan {
   const int* arank;
   const int* bg_list;
   const int* hdr;
-  const int* heavy_list;
-  const int* order = nullptr;  // the active rows by descending list length (kPlanClasses classes), valid when hdr[3] != 0
+  const int* order;
 };
 
 // Device-side CSR view consumed by the fine kernels.
@@ -92,7 +91,6 @@ struct BinWorkspace {
   int* arank;        // (N*nbins)  TilePlan
   int* bg_list;      // (N*nbins)
   int* plan_hdr;     // (4 + 2 * kPlanClasses)
-  int* heavy_list;   // (kHeavyCap)
   int* order;        // (N*nbins)
   int64_t max_chunks;
   int64_t capacity;

@@ -282,21 +282,10 @@ __device__ __forceinline__ long long plan_pack(int total) { return (long long)to
 __device__ __forceinline__ int plan_class(int v) { return kPlanClasses - 1 - min(v >> 3, kPlanClasses - 1); }  // 0 = longest
 
 // row `i` with running exclusive sum `ex` (packed) and own count `v`: offset, active rank, background list entry
-__device__ __forceinline__ void plan_emit(int64_t i, long long ex, int v, int64_t rows, int64_t* offset, int* arank,
-                                          int* bg_list, int* plan_hdr, int* heavy_list) {
+__device__ __forceinline__ void plan_emit(int64_t i, long long ex, int v, int64_t* offset, int* arank, int* bg_list) {
   offset[i] = ex & kPlanMask;
-  int r = (int)(ex >> kPlanShift);
-  if (v <= 0)
-    bg_list[i - r] = (int)i;
-  else
-    bg_list[rows - 1 - r] = (int)i;  // the active rows from the back of the same array (A + B = rows)
-  if (v >= kHeavyRow) {  // plan_hdr[2] was zeroed by an earlier kernel / phase of this launch
-    const int pos = atomicAdd(&plan_hdr[2], 1);
-    if (pos < kHeavyCap) {
-      heavy_list[pos] = (int)i;
-      r |= (int)0x80000000;
-    }
-  }
+  const int r = (int)(ex >> kPlanShift);
+  if (v <= 0) bg_list[i - r] = (int)i;
   arank[i] = r;
 }
 
@@ -327,7 +316,6 @@ __global__ __launch_bounds__(1024) void bin_block_sums_kernel(const int* __restr
   const int v = i < rows ? total[i] : 0;
   block_exclusive_scan_1024(i < rows ? plan_pack(v) : 0, wsum, &all);
   if (threadIdx.x == 0) blocksum[blockIdx.x] = all;
-  if (plan_hdr && blockIdx.x == 0 && threadIdx.x == 0) plan_hdr[2] = 0;  // the heavy-row counter of the scan that follows
   if (plan_hdr) {  // uniform
     __shared__ int hist[kPlanClasses];
     if (threadIdx.x < kPlanClasses) hist[threadIdx.x] = 0;
@@ -342,7 +330,7 @@ __global__ __launch_bounds__(1024) void bin_scan_offsets_kernel(const int* __res
                                                                 const long long* __restrict__ blocksum,
                                                                 int64_t* __restrict__ offset, int* __restrict__ arank,
                                                                 int* __restrict__ bg_list, int* __restrict__ plan_hdr,
-                                                                int* __restrict__ heavy_list, int* __restrict__ order) {
+                                                                int* __restrict__ order) {
   __shared__ long long wsum[16];
   __shared__ long long part[16];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -360,7 +348,7 @@ __global__ __launch_bounds__(1024) void bin_scan_offsets_kernel(const int* __res
   const long long ex = block_exclusive_scan_1024(i < rows ? plan_pack(v) : 0, wsum, &all);
   if (i < rows) {
     if (arank)
-      plan_emit(i, base + ex, v, rows, offset, arank, bg_list, plan_hdr, heavy_list);
+      plan_emit(i, base + ex, v, offset, arank, bg_list);
     else
       offset[i] = (base + ex) & kPlanMask;
   }
@@ -399,13 +387,9 @@ __global__ __launch_bounds__(1024) void bin_scan_offsets_kernel(const int* __res
 __global__ __launch_bounds__(1024) void bin_scan_small_kernel(int* __restrict__ counts, const int64_t* __restrict__ count,
                                                               int N, int nbins, int M, int* __restrict__ total,
                                                               int64_t* __restrict__ offset, int* __restrict__ arank,
-                                                              int* __restrict__ bg_list, int* __restrict__ plan_hdr,
-                                                              int* __restrict__ heavy_list) {
+                                                              int* __restrict__ bg_list, int* __restrict__ plan_hdr) {
   __shared__ int cs[kSelfPlanMax + 1];
-  if (threadIdx.x == 0) {
-    plan_hdr[2] = 0;  // visible to the atomics below after plan_in_lds's barrier
-    plan_hdr[3] = 0;  // no sorted order for small launches
-  }
+  if (threadIdx.x == 0) plan_hdr[3] = 0;  // no sorted order from this kernel (small launches run the split kernels)
   __shared__ long long wsum[16];
   plan_in_lds(count, N, cs);
   const int tid = threadIdx.x;
@@ -429,7 +413,7 @@ __global__ __launch_bounds__(1024) void bin_scan_small_kernel(int* __restrict__ 
     }
     long long all;
     const long long ex = block_exclusive_scan_1024(row < rows ? plan_pack(t) : 0, wsum, &all);
-    if (row < rows) plan_emit(row, carry + ex, t, rows, offset, arank, bg_list, plan_hdr, heavy_list);
+    if (row < rows) plan_emit(row, carry + ex, t, offset, arank, bg_list);
     carry += all;
     __syncthreads();  // wsum is rewritten by the next step
   }
@@ -574,7 +558,6 @@ bool bin_carve(Arena& arena, int64_t E, int N, const BinGeom& g, int M, BinWorks
   ws->arank = arena.take<int>((size_t)N * g.nbins);
   ws->bg_list = arena.take<int>((size_t)N * g.nbins);
   ws->plan_hdr = arena.take<int>(4 + 2 * kPlanClasses);
-  ws->heavy_list = arena.take<int>(kHeavyCap);
   ws->order = arena.take<int>((size_t)N * g.nbins);
   return arena.ok();
 }
@@ -613,7 +596,7 @@ int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t*
   if (small) {
     LaunchScope ls("bin_scan_small", stream);
     bin_scan_small_kernel<<<1, 1024, 0, stream>>>(ws.counts, count, N, g.nbins, M, ws.total, ws.offset, ws.arank, ws.bg_list,
-                                                  ws.plan_hdr, ws.heavy_list);
+                                                  ws.plan_hdr);
   } else {
     {
       LaunchScope ls("bin_scan_rows", stream);
@@ -624,7 +607,7 @@ int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t*
     const unsigned nb = (unsigned)ceil_div(rows, 1024);
     bin_block_sums_kernel<<<nb, 1024, 0, stream>>>(ws.total, rows, ws.blocksum, ws.plan_hdr);
     bin_scan_offsets_kernel<<<nb, 1024, 0, stream>>>(ws.total, rows, ws.blocksum, ws.offset, ws.arank, ws.bg_list, ws.plan_hdr,
-                                                     ws.heavy_list, ws.order);
+                                                     ws.order);
   }
   {
     LaunchScope ls("bin_fill", stream);
@@ -648,7 +631,7 @@ int exclusive_scan_i32(const int* in, int64_t n, long long* blocksum, int64_t* o
   if (n <= 0) return P3D_OK;
   const unsigned nb = (unsigned)ceil_div(n, 1024);
   bin_block_sums_kernel<<<nb, 1024, 0, stream>>>(in, n, blocksum, nullptr);
-  bin_scan_offsets_kernel<<<nb, 1024, 0, stream>>>(in, n, blocksum, out, nullptr, nullptr, nullptr, nullptr, nullptr);
+  bin_scan_offsets_kernel<<<nb, 1024, 0, stream>>>(in, n, blocksum, out, nullptr, nullptr, nullptr, nullptr);
   return launch_status();
 }
 

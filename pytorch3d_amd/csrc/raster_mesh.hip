@@ -46,7 +46,6 @@ constexpr int kMeshPayload = 4; // dist, bary.x, bary.y, bary.z
 // bench meshes under SoftRas blur (full queues): 256 tiles 0.151 -> 0.084 ms, 1024 tiles 0.095 -> 0.115 ms (four queues
 // per pixel cull later than one), 2048 tiles 0.094 -> 0.224 ms.
 constexpr int kSplitMaxTiles = 512;
-constexpr unsigned kActiveRun = 32;  // consecutive active tiles an XCD takes at a time (mesh_raster_kernel: "Active tiles only")
 
 #ifndef P3D_FINE_WAVES_PER_SIMD
 #define P3D_FINE_WAVES_PER_SIMD 4  // caps the fine kernel at 128 VGPRs: 4 waves/SIMD instead of 2
@@ -62,7 +61,7 @@ struct MeshArgs {
   TileMap tm;
   float blur, sqrt_blur;
   int persp, clip, cull;
-  int heavy_front;  // the first kHeavyCap workgroups of the grid take the tiles of csr.plan.heavy_list (launcher decides)
+  int walk_plan;  // blocks take their tiles from csr.plan (active tiles longest-first, then background): launcher decides
   int64_t* p2f;
   float* zbuf;
   float* bary;
@@ -548,61 +547,36 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
   __shared__ ChunkOrderScratch s_ord;
   __shared__ int s_wcnt[kStage / kWave];
 
-  // Heavy tiles first.  The launch ends with a tail: the few tiles whose lists hold many hundred faces run 250-330 us
-  // each (profiles/r02_fine_timeline.txt: the last 150 us of a 1.5 ms launch), and in the tile map's order they start at
-  // arbitrary times.  The offsets scan lists the rows with >= kHeavyRow faces (binning.h: TilePlan::heavy_list); the
-  // first kHeavyCap workgroups of the grid take those tiles, everybody else skips them (bit 31 of arank).
+  // Which tile.  With a tile plan (binning.h: the lists came from bin_build and a tile is a bin) the blocks walk the ACTIVE
+  // tiles, longest list first, and then the background ones.  Workgroups reach the CUs round robin by index, not by load
+  // (profiles/r03/bwd_timeline.txt: the backward ran with half of its wave slots empty until every workgroup carried
+  // work), so the order of the work items is the load balance: in image order (3 of 5 tiles of the bench launch are
+  // background, and the few tiles with many hundred faces -- 250-330 us each, profiles/r02_fine_timeline.txt -- start at
+  // arbitrary times) some CUs idle while others queue; dealt longest-first every CU draws the same mix and the launch has no
+  // tail.  Measured: 1.19 -> 1.04 ms.  Otherwise (naive path, caller's bins, split mode): the XCD-aware tile map.
   TileCoord tc;
   unsigned blk = SPLIT ? blockIdx.x >> 2 : blockIdx.x;
-  bool front = false;
-  if (BINNED && !SPLIT && a.heavy_front) {
-    if (blk < (unsigned)kHeavyCap) {
-      const int nh = a.csr.plan.hdr[2];
-      if ((int)blk >= (nh < kHeavyCap ? nh : kHeavyCap)) return;  // uniform
-      const int hrow = a.csr.plan.heavy_list[blk];
-      const int per_image = a.tm.BH * a.tm.BW;
-      tc.n = hrow / per_image;
-      const int rem = hrow - tc.n * per_image;
-      tc.by = rem / a.tm.BW;
-      tc.bx = rem - tc.by * a.tm.BW;
-      tc.ty = tc.tx = 0;
-      front = true;
-    } else {
-      blk -= (unsigned)kHeavyCap;
-    }
-  }
-  // Active tiles only.  Workgroups reach the CUs round robin by index, not by load (profiles/r03/bwd_timeline.txt: the
-  // backward ran with half of its wave slots empty until every workgroup carried work), and 3 of 5 tiles of the bench launch
-  // are background: with the piggyback fill their workgroups only return, but a CU that draws a run of them idles.  The
-  // tile plan lists the active rows (from the back of bg_list); blocks walk that list -- in runs of kActiveRun consecutive
-  // rows per XCD (blockIdx % 8), which keeps neighbouring tiles and their faces in one L2 -- and the rest of the grid returns.
   bool listed = false;
-  if constexpr (BINNED && !SPLIT && EXACT && (KT & 3) == 0) {
-    if (a.heavy_front && !front) {
-      const int A = a.csr.plan.hdr[0];
-      if (A > 0) {  // (no active tile at all: the background tiles fill themselves, in the tile map's order)
-        int arow;
-        if (a.csr.plan.order != nullptr && a.csr.plan.hdr[3] != 0) {
-          if (blk >= (unsigned)A) return;  // uniform
-          arow = a.csr.plan.order[blk];    // longest lists first (binning.hip: plan_order_kernel)
-        } else {
-          const unsigned q = blk >> 3, x = blk & 7u;
-          const unsigned e = ((q / kActiveRun) * 8u + x) * kActiveRun + (q % kActiveRun);
-          if (e >= (unsigned)A) return;  // uniform
-          const int64_t rows = (int64_t)a.N * a.tm.BH * a.tm.BW;
-          arow = a.csr.plan.bg_list[rows - 1 - e];
-        }
-        const int per_image = a.tm.BH * a.tm.BW;
-        tc.n = arow / per_image;
-        const int rem = arow - tc.n * per_image;
-        tc.by = rem / a.tm.BW;
-        tc.bx = rem - tc.by * a.tm.BW;
-        tc.ty = tc.tx = 0;
-        listed = true;
-      }
+  if (BINNED && !SPLIT && a.walk_plan && a.csr.plan.hdr[3] != 0) {  // uniform
+    const unsigned A = (unsigned)a.csr.plan.hdr[0], B = (unsigned)a.csr.plan.hdr[1];
+    int row;
+    if (blk < A) {
+      row = a.csr.plan.order[blk];
+    } else if (blk < A + B) {
+      if (EXACT && (KT & 3) == 0 && A > 0) return;  // piggyback fill (below): the active workgroups write this tile
+      row = a.csr.plan.bg_list[blk - A];
+    } else {
+      return;
     }
+    const int per_image = a.tm.BH * a.tm.BW;
+    tc.n = row / per_image;
+    const int rem = row - tc.n * per_image;
+    tc.by = rem / a.tm.BW;
+    tc.bx = rem - tc.by * a.tm.BW;
+    tc.ty = tc.tx = 0;
+    listed = true;
   }
-  if (!front && !listed && !tile_of_block(a.tm, blk, &tc)) return;
+  if (!listed && !tile_of_block(a.tm, blk, &tc)) return;
   const int n = tc.n, by = tc.by, bx = tc.bx, ty = tc.ty, tx = tc.tx;
 
   const int H = a.H, W = a.W;
@@ -646,10 +620,6 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
   if (piggy) {
     plan_a = a.csr.plan.hdr[0];
     plan_b = a.csr.plan.hdr[1];
-  }
-  if (BINNED && !SPLIT && a.heavy_front && !front && count >= kHeavyRow) {
-    const int64_t row = ((int64_t)n * a.tm.BH + by) * a.tm.BW + bx;
-    if (a.csr.plan.arank[row] < 0) return;  // one of the front workgroups has this tile (uniform)
   }
   if (count <= 0) {
     if (piggy && plan_a > 0) return;  // an active workgroup writes this tile (uniform)
@@ -774,7 +744,7 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
     if (piggy && plan_b > 0) {
       const int64_t row = ((int64_t)n * a.tm.BH + by) * a.tm.BW + bx;
       const int q_bg = (plan_b + plan_a - 1) / plan_a;
-      const long long j0 = (long long)(a.csr.plan.arank[row] & 0x7fffffff) * q_bg;
+      const long long j0 = (long long)a.csr.plan.arank[row] * q_bg;
       const long long j1 = j0 + q_bg < (long long)plan_b ? j0 + q_bg : (long long)plan_b;
       const int per_image = a.tm.BH * a.tm.BW;
       for (long long j = j0; j < j1; ++j) {  // uniform: scalar loads and arithmetic
@@ -824,9 +794,8 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
   const int K = a.K;
   // few tiles (one image, a small batch): one workgroup per sub-tile with the candidate list dealt to its four waves
   const bool split = BINNED && grid <= (unsigned)kSplitMaxTiles;
-  // heavy tiles at the front of the grid: when the lists carry a tile plan and a tile is a bin
-  a.heavy_front = BINNED && !split && a.csr.plan.hdr != nullptr && a.tm.Ty == 1 && a.tm.Tx == 1 && grid > 4u * kHeavyCap;
-  if (a.heavy_front) grid = (grid + 8u * kActiveRun - 1u) / (8u * kActiveRun) * (8u * kActiveRun) + (unsigned)kHeavyCap;
+  // tiles in the plan's order: when the lists carry a tile plan and a tile is a bin (grid = bins = active + background rows)
+  a.walk_plan = BINNED && !split && a.csr.plan.hdr != nullptr && a.csr.plan.order != nullptr && a.tm.Ty == 1 && a.tm.Tx == 1;
   const size_t dyn_lds = 0;
 #define P3D_LAUNCH_FINE(KT_, REGS_, EXACT_, Q_) launch_fine_variant<Q_, KT_, REGS_, BINNED, EXACT_>(a, grid, split, dyn_lds, stream)
 #define P3D_LAUNCH_FINE_W(KT_, WAVES_, Q_) mesh_raster_kernel<Q_, KT_, true, BINNED, false, WAVES_><<<grid, kStage, 0, stream>>>(a)
@@ -1009,7 +978,7 @@ P3D_API int p3d_rasterize_meshes_with_cover(const float* face_verts, const int64
   int st = bin_build(kTriangles, face_verts, nullptr, mesh_first, mesh_count, F, N, g, max_faces_per_bin,
                      sqrtf(blur_radius), ws, s);
   if (st != P3D_OK) return st;
-  BinCSR csr{ws.offset, ws.total, ws.list, TilePlan{ws.arank, ws.bg_list, ws.plan_hdr, ws.heavy_list, ws.order}};
+  BinCSR csr{ws.offset, ws.total, ws.list, TilePlan{ws.arank, ws.bg_list, ws.plan_hdr, ws.order}};
   return mesh_fine_from_csr(face_verts, neighbor, csr, N, H, W, g, blur_radius, K, persp, clip, cull, p2f, zbuf, bary,
                             dists, s, cover);
 }

@@ -383,7 +383,7 @@ P3D_API int p3d_rasterize_points(const float* points, const int64_t* first, cons
   if (st != P3D_OK) return st;
   PointArgs a{};
   fill_args(&a, points, radius, N, H, W, K, idxs, zbuf, dists);
-  a.csr = BinCSR{ws.offset, ws.total, ws.list, TilePlan{ws.arank, ws.bg_list, ws.plan_hdr, ws.heavy_list}};
+  a.csr = BinCSR{ws.offset, ws.total, ws.list, TilePlan{ws.arank, ws.bg_list, ws.plan_hdr, ws.order}};
   set_tiles(&a, g.bin_size, g.BH, g.BW);
   return launch_point_raster<true>(a, s);
 }
