@@ -71,23 +71,17 @@ def main():
         v.grad = n.grad = b.grad = tex.grad = None
         fn(Mesh(v, m.faces_packed(), n), Frag(p2f, b), L, cam, M, tex).backward(g)
 
-    # ABL_VARIANTS="0 1 2 4 7": P3D_DEBUG_SHADE ablation bits of the backward (1 no table accumulation, 2 no lighting
-    # math, 4 no gbary / gtexels stores; results are wrong for anything but 0)
-    for var in os.environ.get("ABL_VARIANTS", "0").split():
-        os.environ["P3D_DEBUG_SHADE"] = var
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
-        lib.p3d_profile_reset()
-        lib.p3d_profile_enable(1)
-        for _ in range(5):
-            step()
-        torch.cuda.synchronize()
-        lib.p3d_profile_enable(0)
-        print(f"P3D_DEBUG_SHADE={var}: " + ", ".join(f"{k} {ms / cnt:.3f} ms" for k, (cnt, ms) in
-                                                    sorted(_lib.profile_snapshot().items()) if k.startswith("phong")), flush=True)
-    os.environ.pop("P3D_DEBUG_SHADE", None)
-
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    lib.p3d_profile_reset()
+    lib.p3d_profile_enable(1)
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    lib.p3d_profile_enable(0)
+    print(", ".join(f"{k} {ms / cnt:.3f} ms" for k, (cnt, ms) in sorted(_lib.profile_snapshot().items()) if k.startswith("phong")),
+          flush=True)
 
 if __name__ == "__main__":
     main()

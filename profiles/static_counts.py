@@ -108,7 +108,7 @@ def main():
         print("\n# mesh_backward, K = 8 (whole kernel)")
         lines, err = compile_s("raster_mesh_bwd.hip", [], tmp)
         ks, rs = kernels(lines), resources(err)
-        name = [n for n in ks if "mesh_backward_kernel<8, false>" in n][0]
+        name = [n for n in ks if "mesh_backward_rows_kernel<8, true>" in n][0]  # per-vertex output: what the autograd nodes run
         print("%-22s %s  VGPR %s scratch %s" % ("product", summary(count(ks[name])), rs[name][0], rs[name][2]))
         print("\n# points_fine (whole kernel) per queue capacity")
         lines, err = compile_s("raster_points.hip", [], tmp)

@@ -1,14 +1,8 @@
 // p3d_common.h -- launch plumbing shared by the gfx950 translation units.
 #pragma once
 
-// Ablation switches (P3D_DEBUG_FWD / _BWD / _SHADE environment variables, read by profiles/ablate.py and friends)
-// exist only in builds made with -DP3D_ABLATION (P3D_EXTRA_FLAGS, into a separate library via P3D_LIB_PATH).  The
-// product build never calls getenv and every `P3D_DBG(a) & bit` test folds to 0 at compile time.
-#ifdef P3D_ABLATION
-#define P3D_DBG(a) ((a).debug)
-#else
-#define P3D_DBG(a) 0
-#endif
+// (No ablation switches in the sources: the probe and ablation builds whose records are under profiles/ were made from
+// temporary patches into a separate library, P3D_LIB_PATH -- the scripts that read them say so.)
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>

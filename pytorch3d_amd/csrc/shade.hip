@@ -38,7 +38,6 @@ struct ShadeArgs {
   float* gparams;        // (N, 25) or null: gradient of the per-image parameters (zeroed by the launcher, accumulated)
   int N, H, W, K, RY, RX, AW;
   int64_t HWK;
-  int debug;  // P3D_DEBUG_SHADE ablation bits (profiles/shade_bench.py): 1 no table accumulation, 2 no lighting math, 4 no gbary / gtexels stores
 };
 
 // ---- forward: one thread per sample, blockIdx.y = image ----------------------------------------------------------
@@ -152,7 +151,6 @@ __global__ __launch_bounds__(256) void phong_bwd_kernel(ShadeArgs a) {
       const int r = (int)(((float)e + 0.5f) * inv_run);
       const int64_t p = (((int64_t)n * H + y0 + r) * W + x0) * K + (e - r * run);
       int f = ok ? (int)a.p2f[p] : -1;
-      if (P3D_DBG(a) & 2) f = -1;
       float g[NV];
       float gb[3] = {0.f, 0.f, 0.f};
       float go[3] = {0.f, 0.f, 0.f};
@@ -160,7 +158,7 @@ __global__ __launch_bounds__(256) void phong_bwd_kernel(ShadeArgs a) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) go[j] = a.gcolors[p * 3 + j];
       }
-      if (D == 6 && ok && f < 0 && !(P3D_DBG(a) & 4)) {
+      if (D == 6 && ok && f < 0) {
         // background sample with caller-supplied texels: colour = ambient * texel (+ a constant)
 #pragma unroll
         for (int j = 0; j < 3; ++j) a.gtexels[p * 3 + j] = amb[j] * go[j];
@@ -185,16 +183,16 @@ __global__ __launch_bounds__(256) void phong_bwd_kernel(ShadeArgs a) {
         }
         float dtex[3];
         shade_sample_bwd<D, POINT, PG>(c, amb, kd, ks, pw0, a.attrs + (int64_t)f * NV, b, tex_in, go, g, gb, dtex, pg);
-        if (D == 6 && !(P3D_DBG(a) & 4)) {
+        if (D == 6) {
 #pragma unroll
           for (int j = 0; j < 3; ++j) a.gtexels[p * 3 + j] = dtex[j];
         }
       }
-      if (ok && !(P3D_DBG(a) & 4)) {
+      if (ok) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) a.gbary[p * 3 + j] = gb[j];
       }
-      if (__ballot(f >= 0) == 0 || (P3D_DBG(a) & 1)) continue;  // wave-uniform
+      if (__ballot(f >= 0) == 0) continue;  // wave-uniform
       tab.add(a.gattrs, lane, f, g);
     }
   }
@@ -301,12 +299,6 @@ P3D_API int p3d_phong_shade_backward(const float* grad_colors, const int64_t* pi
   a.AW = K >= 4 ? 16 : (K == 3 ? 24 : (K == 2 ? 32 : 64));  // >= 64 samples per row of the area
   a.RY = (int)ceil_div(H, 16);
   a.RX = (int)ceil_div(W, a.AW);
-#ifdef P3D_ABLATION
-  {
-    const char* e = getenv("P3D_DEBUG_SHADE");
-    a.debug = e ? atoi(e) : 0;
-  }
-#endif
   const int64_t blocks = ceil_div((int64_t)N * a.RY * a.RX, 4);
   if (blocks > 0x7fffffff) return P3D_ERR_INVALID_ARG;
   LaunchScope ls("phong_bwd", s);
