@@ -16,7 +16,7 @@ import json
 import os
 import sys
 
-OURS = {"mesh_raster_kernel": "mesh_fine", "mesh_backward": "mesh_backward", "points_raster": "points_fine",
+OURS = {"mesh_raster_kernel": "mesh_fine", "area_list_kernel": "mesh_backward_areas", "mesh_backward": "mesh_backward", "points_raster": "points_fine",
         "bin_count": "bin_count", "bin_fill": "bin_fill", "bin_scan_offsets": "bin_scan_offsets",
         "bin_scan_rows": "bin_scan_rows", "bin_scan_small": "bin_scan_small", "bin_plan": "bin_plan", "gather_faces": "gather_face_verts",
         "scatter_face": "scatter_face_grads"}
@@ -32,7 +32,7 @@ def short(name):
 def main():
     src, dst = sys.argv[1], sys.argv[2]
     lines = ["# rocprofv3 summary (" + os.path.basename(dst) + ")", "",
-             "Command: `python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs` under `rocprofv3` "
+             "Command: `python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs --no-dropin` under `rocprofv3` "
              "(profiles/run_rocprof.sh), MI355X / gfx950.", ""]
     f = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
     if f:
@@ -41,7 +41,7 @@ def main():
         lines += ["## `--kernel-trace --stats`: per-kernel time (all launches incl. warm-up)", "",
                   "| kernel | calls | avg us | min us | max us | % of GPU time |", "|---|---|---|---|---|---|"]
         for r in rows[:16]:
-            nm = short(r["Name"]) or r["Name"].split("(")[0][-70:]
+            nm = short(r["Name"]) or r["Name"].replace("(anonymous namespace)::", "").split("(")[0][-70:]
             lines.append(f"| {nm} | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | "
                          f"{float(r['MaxNs'])/1e3:.1f} | {100*float(r['TotalDurationNs'])/tot:.2f} |")
         lines.append("")
@@ -66,7 +66,9 @@ def main():
             for c, v in cs.items():
                 pmc[k][c] = sum(v) / len(v)
     if pmc:
-        lines += ["## PMC passes (per-launch averages; each `--pmc` set collected in its own run)", ""]
+        lines += ["## PMC passes (per-launch averages; each `--pmc` set collected in its own run)", "",
+                  "rocprofv3's `VGPR_Count` column reads HALF the wave64 allocation on gfx950 (mesh_fine: 64 <-> `.vgpr_count` 121, "
+                  "allocated 128; mesh_backward: 40 <-> 75, allocated 80); the ISA figures are in `profiles/r03/static_counts.txt`.", ""]
         for k in sorted(pmc, key=lambda k: -pmc[k].get("SQ_WAVE_CYCLES", 0)):
             m = meta[k]
             lines += [f"### {k}", "",
