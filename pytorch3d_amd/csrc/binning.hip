@@ -441,6 +441,9 @@ __global__ __launch_bounds__(kBinChunk) void bin_fill_kernel(const float* __rest
   __shared__ int cs_l[kSelfPlanMax + 1];
   __shared__ unsigned short wpre[ORDERED ? kWavesPerChunk : 1][kMaxBins];  // per-wave counts, then prefixes (<= 1024)
   __shared__ int base_t[kMaxBins];                                         // this chunk's row prefix per bin
+  // where this chunk's entries of a bin start in the list (row offset + row prefix): one coalesced read per workgroup.
+  // Looked up per (primitive, bin) in the placement loop it was a dependent global round trip in every iteration.
+  __shared__ int64_t dst_t[kMaxBins];
   const int nbins = BH * BW;
   if (ORDERED)
     for (int i = threadIdx.x; i < kWavesPerChunk * kMaxBins / 2; i += kBinChunk)
@@ -456,14 +459,17 @@ __global__ __launch_bounds__(kBinChunk) void bin_fill_kernel(const float* __rest
     // atomic with return).  The list order inside a chunk is then arbitrary -- only for consumers
     // whose result does not depend on it (point rasterization: top-K under a total order).
     int* pos_t = base_t;
-    for (int b = threadIdx.x; b < nbins; b += kBinChunk) pos_t[b] = counts[(int64_t)blockIdx.x * nbins + b];
-    __syncthreads();
     const int64_t row0u = (int64_t)c.n * nbins;
+    for (int b = threadIdx.x; b < nbins; b += kBinChunk) {
+      pos_t[b] = counts[(int64_t)blockIdx.x * nbins + b];
+      dst_t[b] = offset[row0u + b];
+    }
+    __syncthreads();
     for (int by = c.r.y0; by <= c.r.y1; ++by) {
       for (int bx = c.r.x0; bx <= c.r.x1; ++bx) {
         const int b = by * BW + bx;
         const int pos = atomicAdd(&pos_t[b], 1);
-        if (pos < M) list[offset[row0u + b] + pos] = (int)c.e;
+        if (pos < M) list[dst_t[b] + pos] = (int)c.e;
       }
     }
     return;
@@ -477,8 +483,10 @@ __global__ __launch_bounds__(kBinChunk) void bin_fill_kernel(const float* __rest
   }
   __syncthreads();
   // pass B: exclusive prefix over the 16 waves, seeded with this chunk's row prefix
+  const int64_t row0 = (int64_t)c.n * nbins;
   for (int b = threadIdx.x; b < nbins; b += kBinChunk) {
     base_t[b] = counts[(int64_t)blockIdx.x * nbins + b];
+    dst_t[b] = offset[row0 + b];
     int run = 0;
     for (int j = 0; j < kWavesPerChunk; ++j) {
       const int v = wpre[ORDERED ? j : 0][b];
@@ -488,7 +496,6 @@ __global__ __launch_bounds__(kBinChunk) void bin_fill_kernel(const float* __rest
   }
   __syncthreads();
   // pass C: place
-  const int64_t row0 = (int64_t)c.n * nbins;
   for (int by = c.u.y0; by <= c.u.y1; ++by) {
     for (int bx = c.u.x0; bx <= c.u.x1; ++bx) {
       const bool mem = rect_has(c.r, by, bx);
@@ -496,7 +503,7 @@ __global__ __launch_bounds__(kBinChunk) void bin_fill_kernel(const float* __rest
       if (mem) {
         const int b = by * BW + bx;
         const int pos = base_t[b] + wpre[ORDERED ? w : 0][b] + mask_rank(m);
-        if (pos < M) list[offset[row0 + b] + pos] = (int)c.e;
+        if (pos < M) list[dst_t[b] + pos] = (int)c.e;
       }
     }
   }
