@@ -42,7 +42,7 @@ def _newest(paths):
 
 
 def _extra_flags():
-    return os.environ.get("P3D_EXTRA_FLAGS", "").split()  # e.g. -DP3D_FWD_STATS, -DP3D_FINE_WAVES_PER_SIMD=3
+    return os.environ.get("P3D_EXTRA_FLAGS", "").split()  # flags of a temporary probe / experiment build (always into a separate library: P3D_LIB_PATH)
 
 
 def _flag_signature():

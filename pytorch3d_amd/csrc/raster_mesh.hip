@@ -47,9 +47,7 @@ constexpr int kMeshPayload = 4; // dist, bary.x, bary.y, bary.z
 // per pixel cull later than one), 2048 tiles 0.094 -> 0.224 ms.
 constexpr int kSplitMaxTiles = 512;
 
-#ifndef P3D_FINE_WAVES_PER_SIMD
-#define P3D_FINE_WAVES_PER_SIMD 4  // caps the fine kernel at 128 VGPRs: 4 waves/SIMD instead of 2
-#endif
+constexpr int kFineWaves = 4;  // waves per SIMD the fine kernels are built for: caps them at 128 VGPRs (measured: 3 cost 17 %)
 
 struct MeshArgs {
   const float* face_verts;
@@ -535,7 +533,7 @@ __device__ __forceinline__ void merge_absorb(Queue& q, int K, const float* slab,
 // workgroup makes every wave walk the tile's whole list for its own sub-tile: with one image on the chip (BASELINE
 // configs[1]: 256 tiles for 256 CUs) the launch lasts as long as the longest such walk (~0.2 ms on the cow), while three
 // quarters of the CUs idle.
-template <typename Queue, int KT, bool IN_REGS, bool BINNED, bool EXACT, int WAVES = P3D_FINE_WAVES_PER_SIMD, bool PC = false,
+template <typename Queue, int KT, bool IN_REGS, bool BINNED, bool EXACT, int WAVES = kFineWaves, bool PC = false,
           bool SPLIT = false>
 __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) {
   __shared__ float s_merge[SPLIT ? 3 * kMergeWords * KT * kWave : 1];
@@ -770,14 +768,14 @@ void launch_fine_variant(const MeshArgs& a, unsigned grid, bool split, size_t dy
     if (split) {
       // the merge slab (3 x 6 x KT x 64 floats beside the staging arrays) bounds the split kernel's occupancy: declare what
       // the LDS allows (K = 8: 66 KB -> 2 workgroups per CU, K = 4: 47 KB -> 3) instead of an unattainable 4
-      constexpr int kSplitWaves = KT >= 8 ? 2 : (KT >= 4 ? 3 : P3D_FINE_WAVES_PER_SIMD);
+      constexpr int kSplitWaves = KT >= 8 ? 2 : (KT >= 4 ? 3 : kFineWaves);
       mesh_raster_kernel<Q, KT, REGS, BINNED, EXACT, kSplitWaves, false, true><<<grid * 4, kStage, 0, stream>>>(a);
       return;
     }
   }
   if constexpr (REGS && EXACT) {
     if (a.persp && a.clip) {
-      mesh_raster_kernel<typename PcQueue<Q>::type, KT, REGS, BINNED, EXACT, P3D_FINE_WAVES_PER_SIMD, true><<<grid, kStage, dyn_lds, stream>>>(a);
+      mesh_raster_kernel<typename PcQueue<Q>::type, KT, REGS, BINNED, EXACT, kFineWaves, true><<<grid, kStage, dyn_lds, stream>>>(a);
       return;
     }
   }

@@ -39,14 +39,9 @@ namespace {
 
 constexpr int kRegion = 32;  // pixels per workgroup-region side (four 16x16 wave areas)
 // 4 waves x 182 slots x (8 + 12*4) B = 40768 B of LDS -> 4 workgroups per CU
-#ifndef P3D_BWD_SLOTS
-#define P3D_BWD_SLOTS 182
-#endif
-#ifndef P3D_BWD_SPILL
-#define P3D_BWD_SPILL false
-#endif
-using FaceTable = WaveTable<9, P3D_BWD_SLOTS, kRows, P3D_BWD_SPILL>;
-using FaceTableV = WaveTable<9, P3D_BWD_SLOTS, kCorners, P3D_BWD_SPILL>;  // flushed straight to grad_verts through faces_packed
+constexpr int kBwdSlots = 182;
+using FaceTable = WaveTable<9, kBwdSlots, kRows>;
+using FaceTableV = WaveTable<9, kBwdSlots, kCorners>;  // flushed straight to grad_verts through faces_packed
 
 struct BwdArgs {
   const float* face_verts;

@@ -94,13 +94,7 @@ struct ShadeTable {
   // for 5 / 4 workgroups per CU (D = 6: 32 KB, D = 9: 40 KB) rather than for the worst case of a step (64 consecutive
   // samples can name 64 faces): they run in SPILL mode (wave_table.h).  Measured on the config-3 fragments, D = 6:
   // 182 slots (2 WG/CU) 4.3 ms, 144 (3 WG/CU) 3.3 ms, 106 (4 WG/CU) 2.9 ms, 90 (5 WG/CU) 2.6 ms, 75 (6 WG/CU) 2.65 ms; D = 9: 110 slots (3 WG/CU) 3.6 ms, 83 (4 WG/CU) 3.2 ms.
-#ifndef P3D_SHADE_SLOTS6
-#define P3D_SHADE_SLOTS6 90
-#endif
-#ifndef P3D_SHADE_SLOTS9
-#define P3D_SHADE_SLOTS9 83
-#endif
-  static constexpr int kSlots = D == 6 ? P3D_SHADE_SLOTS6 : P3D_SHADE_SLOTS9;
+  static constexpr int kSlots = D == 6 ? 90 : 83;
   using T = WaveTable<NV, kSlots, false, true>;
 };
 

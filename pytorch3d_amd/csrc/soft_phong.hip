@@ -209,11 +209,9 @@ struct SoftTable {
   using T = WaveTable<NV, kSlots, false, true>;
 };
 
-#ifndef P3D_SOFT_PHONG_BWD_WAVES
-#define P3D_SOFT_PHONG_BWD_WAVES 3  // measured (D = 9, K = 8): 146 VGPRs at 3 waves 3.84 ms; capped at 128 (72 B of scratch) 4.80 ms
-#endif
+constexpr int kSoftPhongBwdWaves = 3;  // measured (D = 9, K = 8): 146 VGPRs at 3 waves 3.84 ms; capped at 128 (72 B of scratch) 4.80 ms
 template <int D, bool POINT, bool PG, int KT>
-__global__ __launch_bounds__(256, P3D_SOFT_PHONG_BWD_WAVES) void soft_phong_bwd_kernel(SoftPhongArgs a) {
+__global__ __launch_bounds__(256, kSoftPhongBwdWaves) void soft_phong_bwd_kernel(SoftPhongArgs a) {
 #pragma clang fp contract(fast)  // gradient-only arithmetic (tolerance-gated): let mul+add fuse into FMA
   using Tab = typename SoftTable<D>::T;
   constexpr int NV = 3 * D;

@@ -130,13 +130,8 @@ __global__ __launch_bounds__(256) void sample_uv_fwd_kernel(TexArgs a) {
 
 // Per wave: 128 slots for the per-face uv partials (6 values, 40 B) + 320 slots for the map gradient keyed by texel (up to
 // 4 channels, 24 B): 12.5 KB -> 50 KB per workgroup, three workgroups per CU.
-#ifndef P3D_UV_SLOTS
-#define P3D_UV_SLOTS 128
-#define P3D_TEXEL_SLOTS 320
-#define P3D_UV_SPILL false
-#endif
-using UvTable = WaveTable<6, P3D_UV_SLOTS, kRows, P3D_UV_SPILL>;
-using TexelTable = WaveTable<4, P3D_TEXEL_SLOTS, kChunk, P3D_UV_SPILL>;
+using UvTable = WaveTable<6, 128, kRows>;
+using TexelTable = WaveTable<4, 320, kChunk>;
 
 template <bool NEAREST>
 __global__ __launch_bounds__(256) void sample_uv_bwd_kernel(TexArgs a, int64_t span) {
