@@ -29,7 +29,8 @@ def open_lib(path):
     from pytorch3d_amd import _lib
 
     lib = ctypes.CDLL(path)
-    for name in ("p3d_rasterize_meshes_workspace_bytes", "p3d_rasterize_meshes", "p3d_rasterize_meshes_backward_verts",
+    for name in ("p3d_rasterize_meshes_workspace_bytes", "p3d_rasterize_meshes_with_cover", "p3d_rasterize_meshes_backward_verts_with_cover",
+                 "p3d_rasterize_meshes_backward_workspace_bytes",
                  "p3d_profile_enable", "p3d_profile_collect", "p3d_profile_num_entries", "p3d_profile_entry", "p3d_profile_reset"):
         res, args = _lib._SIGNATURES[name]
         fn = getattr(lib, name)
@@ -58,7 +59,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--image-size", type=int, default=512)
     ap.add_argument("--faces-per-pixel", type=int, default=8)
-    ap.add_argument("--scale", type=float, default=None, help="hetero_batch torus scale override (default: the bench's)")
+    ap.add_argument("--torus-div", type=float, default=1.0, help="hetero_batch torus_div: 1.0 = SURVEY 8(d) config 3 as written (the bench headline), 1.5 = the lighter batch of rounds 1-3")
     ap.add_argument("variants", nargs="*")
     args = ap.parse_args()
 
@@ -69,7 +70,7 @@ def main():
     d = torch.device("cuda:0")
     B, H, K = args.batch, args.image_size, args.faces_per_pixel
     blur = math.log(1.0 / 1e-4 - 1.0) * 1e-4
-    verts, faces = U.hetero_batch(B, seed=0)
+    verts, faces = U.hetero_batch(B, seed=0, torus_div=args.torus_div)
     m = p3d.PackedMeshes([v.to(d) for v in verts], [f.to(d) for f in faces])
     vp, fp = m.verts_packed().contiguous(), m.faces_packed().contiguous()
     fv = vp[fp].contiguous()
@@ -87,13 +88,18 @@ def main():
         return (torch.empty((B, H, H, K), dtype=torch.int64, device=d), torch.empty((B, H, H, K), device=d),
                 torch.empty((B, H, H, K, 3), device=d), torch.empty((B, H, H, K), device=d))
 
+    cover = torch.empty((B, (H + 15) // 16, (H + 15) // 16), dtype=torch.int32, device=d)
+    bws = torch.empty((int(_lib.load().p3d_rasterize_meshes_backward_workspace_bytes(B, H, H)),), dtype=torch.uint8, device=d)
+
     def run(lib, out, gv, ws):
-        rc = lib.p3d_rasterize_meshes(fv.data_ptr(), first.data_ptr(), count.data_ptr(), nbr.data_ptr(), F, B, H, H, blur, K, bin_size, M,
-                                      1, 1, 0, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(),
-                                      ws.data_ptr(), ws.numel(), stream)
+        # what the L2 mirror (and bench.py) runs: the forward writes the row cover, the backward walks it
+        rc = lib.p3d_rasterize_meshes_with_cover(fv.data_ptr(), first.data_ptr(), count.data_ptr(), nbr.data_ptr(), F, B, H, H, blur, K,
+                                                 bin_size, M, 1, 1, 0, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
+                                                 out[3].data_ptr(), cover.data_ptr(), ws.data_ptr(), ws.numel(), stream)
         assert rc == 0, rc
-        rc = lib.p3d_rasterize_meshes_backward_verts(fv.data_ptr(), fp.data_ptr(), out[0].data_ptr(), gz.data_ptr(), gb.data_ptr(),
-                                                     gd.data_ptr(), F, V, B, H, H, K, 1, 1, gv.data_ptr(), stream)
+        rc = lib.p3d_rasterize_meshes_backward_verts_with_cover(fv.data_ptr(), fp.data_ptr(), out[0].data_ptr(), gz.data_ptr(),
+                                                                gb.data_ptr(), gd.data_ptr(), cover.data_ptr(), F, V, B, H, H, K, 1, 1,
+                                                                gv.data_ptr(), bws.data_ptr(), bws.numel(), stream)
         assert rc == 0, rc
 
     product = _lib.load()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Fold the rocprofv3 CSVs written by profiles/run_rocprof.sh into a committed summary.
 
-    python profiles/summarize.py gpurun_out/prof profiles/r01_v3   ->  profiles/r01_v3_rocprof.md
+    python profiles/summarize.py gpurun_out/prof profiles/r01_v3 [torus_div]  ->  profiles/r01_v3_rocprof.md
                                                                         profiles/traffic.json (read by bench.py)
 
 HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are collected in
@@ -94,7 +94,8 @@ def main():
         fh.write("\n".join(lines) + "\n")
     here = os.path.dirname(os.path.abspath(__file__))
     with open(os.path.join(here, "traffic.json"), "w") as fh:
-        json.dump({k: v["hbm_bytes"] for k, v in traffic.items()} | {"_detail": traffic, "_source": os.path.basename(dst)},
+        json.dump({k: v["hbm_bytes"] for k, v in traffic.items()} | {"_detail": traffic, "_source": os.path.basename(dst),
+                                                                    "_torus_div": float(sys.argv[3]) if len(sys.argv) > 3 else 1.0},
                   fh, indent=1)
     print("\n".join(lines))
 

@@ -613,7 +613,12 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
   // faces alone 1.3 ms).  With the tile plan of the offsets scan (binning.h: TilePlan) the ACTIVE workgroups issue those
   // stores instead, at the end of their own work (fire and forget: ~40 instructions per tile, fill_tile_full), and a
   // background workgroup returns at once.  Active row number r takes background rows [r q, (r + 1) q), q = ceil(B / A).
-  const bool piggy = BINNED && !SPLIT && EXACT && (KT & 3) == 0 && a.csr.plan.hdr != nullptr;
+  // Only when a bin is ONE tile (walk_plan: Ty == Tx == 1, images up to 512 pixels a side): with several tiles per bin a
+  // background bin's tile (ty, tx) would be dealt to workgroup (ty, tx) of an active bin, and the workgroups of an active
+  // bin in the partial last bin row / column whose own tile has no pixel return before they get here -- those tiles of
+  // the background bins dealt to them were never written (tests/test_gpu_meshes.py:
+  // test_large_images_background_is_written).  Larger images fill their background tiles with their own workgroups.
+  const bool piggy = BINNED && !SPLIT && EXACT && (KT & 3) == 0 && a.walk_plan != 0 && a.csr.plan.hdr != nullptr;
   int plan_a = 0, plan_b = 0;
   if (piggy) {
     plan_a = a.csr.plan.hdr[0];

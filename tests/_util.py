@@ -114,10 +114,17 @@ def split_counts(F, N):
     return first, count
 
 
+# SURVEY.md 8(d) config 3 as written: torus(r = 0.4 + 0.2 u, R = 1.0) UNSCALED (pytorch3d/utils/torus.py:24-73): the bench
+# headline and the full-size parity tests run on hetero_batch(64, seed=0, torus_div=CONFIG3_TORUS_DIV).  The default of the
+# helper stays 1.5 (the lighter batch rounds 1-3 quoted; the small tests and the committed fixtures were made with it).
+CONFIG3_TORUS_DIV = 1.0
+
+
 def hetero_batch(n_meshes, seed=0, fmin=1000, fmax=20000, torus_div=1.5):
     """BASELINE config 3 generator: tori / icospheres with log-uniform face counts, random rotation,
     seen from distance 2.7.  Returns (list of NDC verts, list of faces).  torus_div: the tori (ring radius 1) are scaled
-    by 1 / torus_div -- 1.5 is the bench workload (the batch covers ~31 % of the pixels), 1.0 fills the frame."""
+    by 1 / torus_div -- 1.0 is SURVEY.md 8(d) config 3 literally (the tori fill the frame and cross its edges, ~58 % of the
+    pixels covered: the bench headline), 1.5 the lighter batch of rounds 1-3 (~31 % covered)."""
     gen = torch.Generator().manual_seed(seed)
     verts, faces = [], []
     for _ in range(n_meshes):

@@ -1,6 +1,7 @@
 """The EXACT launch `bench.py` times, against the reference's own device kernels on the same MI355X.
 
-`bench.py` (BASELINE configs[2]) rasterizes `hetero_batch(64, seed=0)` at 512x512, K = 8, SoftRas blur, perspective-correct
+`bench.py` (BASELINE configs[2]) rasterizes `hetero_batch(64, seed=0, torus_div=1.0)` (SURVEY.md 8(d) config 3 as written;
+the lighter torus_div=1.5 batch of rounds 1-3 is the second parameter) at 512x512, K = 8, SoftRas blur, perspective-correct
 + clipped barycentrics: one `mesh_fine` launch of 65,536 workgroups over 64 images (41k background tiles, the XCD tile
 map over the full grid, output offsets past 2^31 bytes) and one `mesh_backward` launch.  The smaller parity tests
 (tests/test_gpu_baseline_sizes.py, test_gpu_vs_reference_device_kernels.py) rasterize four of the 64 meshes; this one
@@ -40,7 +41,8 @@ def _bits(t):
     return t.view(torch.int32)
 
 
-def test_full_bench_batch_forward_and_backward_vs_reference_device_kernels():
+@pytest.mark.parametrize("torus_div", [U.CONFIG3_TORUS_DIV, 1.5], ids=["config3_literal", "light_div1.5"])
+def test_full_bench_batch_forward_and_backward_vs_reference_device_kernels(torus_div):
     mod = orc.ref_hip_module(nofma=True)
     if mod is None:
         pytest.skip("oracle/_ref/p3d_ref_hip_nofma.so not built (oracle/build_ref_hip.py, build container only)")
@@ -48,7 +50,9 @@ def test_full_bench_batch_forward_and_backward_vs_reference_device_kernels():
     from pytorch3d_amd import _C
 
     d = torch.device("cuda:0")
-    verts, faces = U.hetero_batch(B, seed=0)  # bench.py: build_batch(B, seed=rank), rank 0
+    # bench.py: build_batch(B, seed=rank), rank 0 -- torus_div 1.0 is the headline workload (SURVEY.md 8(d) config 3 as written:
+    # tori unscaled, crossing the frame edge, ~58 % of the pixels covered), 1.5 the lighter batch rounds 1-3 quoted
+    verts, faces = U.hetero_batch(B, seed=0, torus_div=torus_div)
     m = p3d.PackedMeshes([v.to(d) for v in verts], [f.to(d) for f in faces])
     fv = m.verts_packed()[m.faces_packed()].contiguous()
     F = int(fv.shape[0])
@@ -74,12 +78,12 @@ def test_full_bench_batch_forward_and_backward_vs_reference_device_kernels():
     tie[..., K - 1] = True
     unexplained = int((~same & ~tie).sum())
     covered = float((ours[0][..., 0] >= 0).float().mean())
-    print(f"[bench launch: {B} meshes, {F} faces, {H}^2, K={K}] pix_to_face differences {n_idx} / {total} "
+    print(f"[bench launch torus_div={torus_div}: {B} meshes, {F} faces, {H}^2, K={K}] pix_to_face differences {n_idx} / {total} "
           f"({n_idx / total:.2e}), not at an exact depth tie: {unexplained}; bary / dists words differing where the index "
           f"agrees: {bad_b} / {bad_d}; covered pixels {covered:.3f}")
     assert bad_d == 0 and bad_b == 0
     assert unexplained == 0
-    assert n_idx <= 5e-4 * total
+    assert n_idx <= 1e-3 * total  # observed: 1.7e-4 (torus_div 1.5); all of them at exact depth ties (asserted above)
     del theirs, tie, same
     torch.cuda.empty_cache()
 

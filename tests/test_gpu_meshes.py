@@ -417,6 +417,44 @@ def test_images_larger_than_the_bin_grid_property_checks(size, K):
     assert (g1.cpu()[~hit] == 0).all()
 
 
+@pytest.mark.parametrize("size", [(1000, 1000), (720, 1280), (528, 528), (1000, 1400)])
+@pytest.mark.parametrize("K", [4, 8])
+def test_large_images_background_is_written(size, K, monkeypatch):
+    """above 512 pixels a side an internal bin holds several 16x16 tiles; when the image leaves a
+    partial last bin row / column (1000 -> 32-pixel bins, last one 8 pixels; 720x1280 -> 64-pixel bins, last row 16) and
+    the mesh reaches that border, the piggyback fill of round 3 left tiles of background bins unwritten (the outputs are
+    torch.empty).  The outputs are pre-filled with a sentinel here; the meshes overflow the frame on every side; binned
+    must equal naive and no sentinel may survive."""
+    from pytorch3d_amd import PackedMeshes, _C
+
+    verts, faces = U.hetero_batch(2, seed=11, fmin=600, fmax=2500, torus_div=0.7)
+    m = PackedMeshes(verts, faces)
+    fv = m.verts_packed()[m.faces_packed()]
+    first, count = m.mesh_to_faces_packed_first_idx(), m.num_faces_per_mesh()
+    nbr = torch.full((fv.shape[0],), -1, dtype=torch.int64)
+    real = _C._mesh_outputs
+
+    def sentinel_outputs(N, H, W, K_, device):
+        out = real(N, H, W, K_, device)
+        out[0].fill_(7777777)
+        for o in out[1:]:
+            o.fill_(123.0)
+        return out
+
+    monkeypatch.setattr(_C, "_mesh_outputs", sentinel_outputs)
+    from pytorch3d_amd.rasterize_meshes import default_bin_size
+
+    a = _run_ours(fv, first, count, nbr, size, 3e-4, K, default_bin_size(max(size)), 20000, True, True, False)
+    b = _run_ours(fv, first, count, nbr, size, 3e-4, K, 0, 0, True, True, False)
+    assert int((a[0] == 7777777).sum()) == 0, "pix_to_face entries never written by the binned kernel"
+    for o in a[1:]:
+        assert int((o == 123.0).sum()) == 0, "float outputs never written by the binned kernel"
+    _assert_fwd_equal(a, b, tag=f"naive==binned@{size}")
+    # the meshes reach all four borders of the output (what makes the partial last bins active)
+    hit = a[0][..., 0] >= 0
+    assert hit[:, 0, :].any() and hit[:, -1, :].any() and hit[:, :, 0].any() and hit[:, :, -1].any()
+
+
 def test_operators_are_reentrant_across_threads_and_streams():
     """The launchers keep no global mutable state and launch on the caller's current stream (nn.DataParallel calls them
     from several Python threads, tests/test_render_multigpu.py:171 in the reference): four threads, each on its own
