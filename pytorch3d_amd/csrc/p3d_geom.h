@@ -237,18 +237,22 @@ P3D_HD bool face_hit(f3 v0, f3 v1, f3 v2, f2 p, float blur_radius, bool perspect
 // to float lands on the same float as rounding q.  n = 0, d = inf and NaNs propagate as in IEEE division; for
 // results below 2^-126 (float denormals) the argument does not hold and the last denormal bit may differ.
 //
-// rd: a hardware reciprocal estimate refined by two Newton steps in double.  Per pixel the seed is v_rcp_f32 (1 ulp =
+// rd: a hardware reciprocal estimate refined in double (recip_newton).  Per pixel the seed is v_rcp_f32 (1 ulp =
 // 2^-23 -> 2^-46 -> below 2^-52), which needs 2^-126 <= d <= 2^126; that holds for the per-pixel denominators of every
 // face whose coordinates are of ordinary magnitude (`FaceRec::wide` false).  For the other faces, and for the per-face
 // reciprocals (computed once per face), the seed is v_rcp_f64, valid over the whole float range.  On the host 1.0 / d.
 // All of them give the same float quotients, by the argument above.
 // ---------------------------------------------------------------------------
+// One cubic step instead of two Newton steps (round 4: three v_fma_f64 instead of four, twice per (pixel, face)): with
+// e = 1 - d r the true reciprocal is r (1 + e + e^2 + e^3 + ...); r (1 + e + e^2) is off by e^3 <= 2^-69 for a seed of 23
+// bits (v_rcp_f32: 1 ulp; v_rcp_f64 on gfx950 measures 2^-24.4, profiles/microbench/rcp_accuracy_mi355x.txt).  Roundings:
+// e and t = e + e^2 are of magnitude 2^-23, their rounding errors (2^-53 relative to them) vanish; the last fma rounds
+// once, 2^-53 relative -- together below the 2^-52 the argument above needs.
 P3D_HD double recip_newton(double dd, double r) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  double e = __builtin_fma(-dd, r, 1.0);
-  r = __builtin_fma(e, r, r);
-  e = __builtin_fma(-dd, r, 1.0);
-  r = __builtin_fma(e, r, r);
+  const double e = __builtin_fma(-dd, r, 1.0);
+  const double t = __builtin_fma(e, e, e);
+  r = __builtin_fma(r, t, r);
 #endif
   return r;
 }
@@ -372,6 +376,24 @@ P3D_HD bool face_hit_rec(const FaceRec& r, f2 p, float blur_radius, bool perspec
                          FaceHit* out) {
   const f3 bp = face_depth_rec(r, p, perspective_correct, clip_bary, out);
   return face_dist_rec(r, p, blur_radius, bp, out);
+}
+
+// ---------------------------------------------------------------------------
+// Pixel masks of a bounding box (fine rasterizer).  The reference tests every pixel against the blur-expanded box of
+// every candidate face (rasterize_meshes.cu:94-97: outside if px > xhi || px < xlo || py > yhi || py < ylo, strict).
+// Pixel centres are strictly monotone in the pixel index, so along one axis the pixels inside are the index range
+// [#(centre < lo), n - 1 - #(centre > hi)] -- two counts per axis, taken once per (face, tile) instead of four compares per
+// (face, pixel).  A NaN edge compares false both ways: every pixel is inside, as in the reference's expression.
+// ---------------------------------------------------------------------------
+// bits [below, 15 - above] of a 16-pixel axis (below = centres under the low edge, above = centres over the high edge)
+P3D_HD unsigned range_mask16(int below, int above) { return (0xffffu >> above) & (0xffffu << below) & 0xffffu; }
+
+// An 8-column mask and an 8-row mask as the 64-bit mask of an 8x8 block, bit 8 * row + column, in two halves: the column
+// byte replicated into the bytes of the set rows.  A 4-bit row group times 0x00204081 puts bit i at position 8 i (the
+// shifted copies x, x << 7, x << 14, x << 21 do not overlap), times the column byte (< 256) fills those bytes.
+P3D_HD void block_mask_8x8(unsigned cols8, unsigned rows8, unsigned* lo, unsigned* hi) {
+  *lo = cols8 * (((rows8 & 15u) * 0x00204081u) & 0x01010101u);
+  *hi = cols8 * ((((rows8 >> 4) & 15u) * 0x00204081u) & 0x01010101u);
 }
 
 // ---------------------------------------------------------------------------

@@ -205,7 +205,9 @@ __device__ __forceinline__ void write_subtile_fill_patch(const MeshArgs& a, cons
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (!pix_ok || (lane >> 3) != r) continue;
     const int64_t base = (((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi)) * K;
-    if constexpr (IN_REGS) {
+    if constexpr (Queue::kPayload == 0) {
+      // queues without payload are written by write_pixel_long; they come here for background tiles only (patch == false)
+    } else if constexpr (IN_REGS) {
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
         if (k < K && q.valid(k)) {
@@ -286,6 +288,139 @@ __device__ __forceinline__ void fill_tile_full(const MeshArgs& a, int n, int ty0
   for (int i = 0; i < 2 * Q; ++i) store16(ib + i * 256, i1, i1, i1, i1);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Queues without payload (16 < K <= 48, round 4).  With SoftRas blur a covered pixel holds ~17 entries at K = 32..100, and a
+// queue in private memory (TopKMem, what K > 16 ran on until round 3) moves O(K) entries of 24 bytes through scratch for
+// every admitted face: K = 32 1.57 ms where K = 16 takes 0.44 (8 bench meshes, profiles/r04).  Here an entry is the ONE
+// register pair (z | index) of topk.h: TopKPairs<KT, ., 0> -- the insertion is one 64-bit compare and two v_pk_mov per
+// entry, as in the point rasterizer (raster_points.hip) -- and the signed distance and the barycentrics of the entries that
+// survive are recomputed when the pixel is written: the same inlined functions (p3d_geom.h) on the same operands give the
+// same bits.  The reference keeps everything in its 150-entry local array (rasterize_meshes.cu:216-237).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ FaceHit recompute_face(const MeshArgs& a, int f, f2 p, bool persp, bool clip) {
+  const float* g = a.face_verts + (int64_t)f * 9;
+  FaceRec fr;
+  face_rec_make(mk3(g[0], g[1], g[2]), mk3(g[3], g[4], g[5]), mk3(g[6], g[7], g[8]), &fr);
+  FaceHit h;
+  const f3 bp = face_depth_rec(fr, p, persp, clip, &h);
+  face_dist_rec(fr, p, a.blur, bp, &h);
+  return h;
+}
+
+// One pixel's rows from a queue without payload.  Stage 1: pix_to_face and zbuf straight from the registers (16-byte
+// stores when K % 4 == 0).  Stage 2: groups of four entries -- the lane reads its own four indices back (they were
+// acknowledged by the L2: s_waitcnt vmcnt(0); the queue registers are dead by then, and a runtime loop cannot index
+// registers), gathers the four faces' vertices in one round trip, recomputes (dist, bary) and writes the group with
+// 16-byte stores, -1 padding included; a group no lane has an entry in is four -1 stores.
+template <typename Queue, int KT, bool EXACT>
+__device__ __forceinline__ void write_pixel_long(const MeshArgs& a, const Queue& q, int64_t opix, f2 p, bool pix_ok, bool persp,
+                                                 bool clip) {
+  const int K = EXACT ? KT : a.K;
+  const int64_t base = opix * K;
+  int nvalid = 0;
+  if (pix_ok) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) nvalid += (k < K && q.valid(k)) ? 1 : 0;
+    if ((K & 3) == 0) {
+#pragma unroll
+      for (int k = 0; k < KT; k += 4) {
+        if (k < K) {
+          long long iv[4];
+          unsigned zv[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool ok = q.valid((k + j) % KT);
+            iv[j] = ok ? (long long)q.ix((k + j) % KT) : -1ll;
+            zv[j] = __float_as_uint(ok ? q.zf((k + j) % KT) : -1.0f);
+          }
+          store16(a.zbuf + base + k, zv[0], zv[1], zv[2], zv[3]);
+          store16(a.p2f + base + k, (unsigned)iv[0], (unsigned)(iv[0] >> 32), (unsigned)iv[1], (unsigned)(iv[1] >> 32));
+          store16(a.p2f + base + k + 2, (unsigned)iv[2], (unsigned)(iv[2] >> 32), (unsigned)iv[3], (unsigned)(iv[3] >> 32));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        if (k < K) {
+          const bool ok = q.valid(k);
+          a.p2f[base + k] = ok ? (int64_t)q.ix(k) : -1;
+          a.zbuf[base + k] = ok ? q.zf(k) : -1.0f;
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const bool vec = (K & 3) == 0;
+#pragma unroll 1
+  for (int k0 = 0; k0 < K; k0 += 4) {
+    if (__ballot(pix_ok && k0 < nvalid) == 0) {  // uniform: nobody holds an entry here (the rows' -1 tail)
+      if (pix_ok) {
+        if (vec) {
+          const unsigned m1 = 0xbf800000u;
+          store16(a.dists + base + k0, m1, m1, m1, m1);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) store16(a.bary + (base + k0) * 3 + 4 * c, m1, m1, m1, m1);
+        } else {
+          for (int j = 0; j < 4 && k0 + j < K; ++j) {
+            a.dists[base + k0 + j] = -1.0f;
+            for (int c = 0; c < 3; ++c) a.bary[(base + k0 + j) * 3 + c] = -1.0f;
+          }
+        }
+      }
+      continue;
+    }
+    int f[4];
+    float gv[4][9];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f[j] = -1;
+      if (pix_ok && k0 + j < nvalid)
+        f[j] = (int)__hip_atomic_load(a.p2f + base + k0 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // past the L1: this lane's own store
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float* g = a.face_verts + (int64_t)(f[j] < 0 ? 0 : f[j]) * 9;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) gv[j][c] = f[j] >= 0 ? g[c] : 0.0f;
+    }
+    float out[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      FaceHit h;
+      h.dist = -1.0f;
+      h.bary = mk3(-1.0f, -1.0f, -1.0f);
+      if (f[j] >= 0) {
+        FaceRec fr;
+        face_rec_make(mk3(gv[j][0], gv[j][1], gv[j][2]), mk3(gv[j][3], gv[j][4], gv[j][5]), mk3(gv[j][6], gv[j][7], gv[j][8]), &fr);
+        const f3 bp = face_depth_rec(fr, p, persp, clip, &h);
+        face_dist_rec(fr, p, a.blur, bp, &h);
+      }
+      out[j] = h.dist;
+      out[4 + 3 * j + 0] = h.bary.x;
+      out[4 + 3 * j + 1] = h.bary.y;
+      out[4 + 3 * j + 2] = h.bary.z;
+    }
+    if (pix_ok) {
+      if (vec) {
+        store16(a.dists + base + k0, __float_as_uint(out[0]), __float_as_uint(out[1]), __float_as_uint(out[2]), __float_as_uint(out[3]));
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          store16(a.bary + (base + k0) * 3 + 4 * c, __float_as_uint(out[4 + 4 * c]), __float_as_uint(out[5 + 4 * c]),
+                  __float_as_uint(out[6 + 4 * c]), __float_as_uint(out[7 + 4 * c]));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (k0 + j < K) {
+            a.dists[base + k0 + j] = out[j];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a.bary[(base + k0 + j) * 3 + c] = out[4 + 3 * j + c];
+          }
+        }
+      }
+    }
+  }
+}
+
 // Staged face in LDS: five 16-byte words, each read by a wave as one broadcast (all lanes, same address).
 //   [0] v0x v0y v1x v1y   [1] v2x v2y z0 z1   [2] z2 fid nb wide   [3] rd_area, rd_l01 (doubles)   [4] rd_l02, rd_l12
 constexpr int kRecWords = 5;
@@ -295,20 +430,47 @@ constexpr int kRecWords = 5;
 // clipped-neighbour rule (rasterize_meshes.cu:186-215).  Two instantiations, chosen per tile region (see the kernel):
 // with the rule in the common loop body the compiler copies the whole queue (48 moves) after every hit to feed the
 // rule's control flow.
+// Which pixels of the wave's 8x8 sub-tile lie inside the face's blur-expanded bounding box comes as a 64-bit LANE MASK
+// (lane = 8 * row + column), built once per (face, sub-tile) by the face's lane in wave_chunk from the column / row masks of
+// stage_chunk: a visit reads it with two v_readlane and uses it as the execution mask as it is -- no box in LDS, no four
+// compares per visit, and a candidate that no pixel can see costs no LDS round trip at all.
 template <bool GENERAL, typename Queue, bool PC = false>
-__device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue& q, unsigned long long cand, int oj, f2 p,
-                                                bool pix_ok, bool persp, bool clip, const float4* s_box,
-                                                const float4 (*s_rec)[kRecWords], const float* s_zc) {
+__device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue& q, unsigned long long cand, int oj, unsigned mlo,
+                                                unsigned mhi, float zcv, f2 p, bool pix_ok, bool persp, bool clip,
+                                                const float4 (*s_rec)[kRecWords]) {
   while (cand) {
-    const int jj = __builtin_amdgcn_readlane(oj, __builtin_ctzll(cand));
+    const int ci = __builtin_ctzll(cand);
     cand &= cand - 1;
-    // all LDS reads of this candidate are issued together (one round trip instead of dependent ones)
-    const float4 b = s_box[jj];
-    const float zc = s_zc[jj];
-    const float4 r0 = s_rec[jj][0], r1 = s_rec[jj][1], r2 = s_rec[jj][2];
-    const bool out = p.x > b.y || p.x < b.x || p.y > b.w || p.y < b.z;
+    int jj = __builtin_amdgcn_readlane(oj, ci);
+    const unsigned alo = (unsigned)__builtin_amdgcn_readlane((int)mlo, ci), ahi = (unsigned)__builtin_amdgcn_readlane((int)mhi, ci);
+    unsigned long long inside = ((unsigned long long)ahi << 32) | (unsigned long long)alo;
+    float zc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zcv), ci));
+    if constexpr (!GENERAL) {
+      // Disjoint pairs.  A face's box covers 40 of a sub-tile's 64 pixels on average, so an evaluation runs with a third
+      // of its lanes idle.  The next candidate whose pixel mask does not intersect this one's is evaluated in the SAME
+      // pass: its lanes read its record (the LDS reads become two-address gathers), everything after that is per lane
+      // anyway.  Any order of the candidates gives the same queues here (top-K under a total order; the neighbour rule,
+      // which is order-dependent, lives in the GENERAL nest), so taking a later candidate early changes nothing but the
+      // number of passes: 20 % fewer on the bench batch by bounding boxes alone (profiles/next/README.md).
+      const unsigned long long free_of_a = __ballot(((mlo & alo) | (mhi & ahi)) == 0u) & cand;  // lane = candidate face
+      if (free_of_a) {  // uniform
+        const int cb = __builtin_ctzll(free_of_a);
+        cand &= ~(1ull << cb);
+        const unsigned long long in_b = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mhi, cb) << 32) |
+                                        (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)mlo, cb);
+        const bool mine_is_b = __builtin_amdgcn_inverse_ballot_w64(in_b);
+        const int jb = __builtin_amdgcn_readlane(oj, cb);
+        const float zb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(zcv), cb));
+        jj = mine_is_b ? jb : jj;
+        zc = mine_is_b ? zb : zc;
+        inside |= in_b;
+      }
+    }
+    const bool in_box = __builtin_amdgcn_inverse_ballot_w64(inside);  // the mask IS the predicate: no VALU
     const bool too_deep = zc > q.kth_z(K);
-    if (pix_ok && !out && !too_deep) {
+    if (pix_ok && in_box && !too_deep) {
+      // all LDS reads of this candidate are issued together (one round trip instead of dependent ones)
+      const float4 r0 = s_rec[jj][0], r1 = s_rec[jj][1], r2 = s_rec[jj][2];
       const int f = __float_as_int(r2.y);
       FaceHit h;
       bool hit = false;
@@ -332,7 +494,6 @@ __device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue&
         if (GENERAL || (!(h.z < 0.0f) && q.admits(K, h.z, f))) hit = face_dist_rec(fr, p, a.blur, bp, &h);
       }
       if (hit) {
-        const float pl[kMeshPayload] = {h.dist, h.bary.x, h.bary.y, h.bary.z};
         bool ins = true;
         if constexpr (GENERAL) {
           const int nb = __float_as_int(r2.z);
@@ -341,7 +502,13 @@ __device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue&
             // the two halves of a split face stays in the queue -- the one closer to the pixel.
             const int at = q.find(nb);
             if (at >= 0) {
-              if (fabsf(h.dist) < fabsf(q.payload_at(0, at)))
+              float queued;
+              if constexpr (Queue::kPayload > 0) {
+                queued = q.payload_at(0, at);
+              } else {
+                queued = recompute_face(a, nb, p, persp, clip).dist;  // a queue without payload: the same function, the same bits
+              }
+              if (fabsf(h.dist) < fabsf(queued))
                 q.erase(at);
               else
                 ins = false;
@@ -350,7 +517,15 @@ __device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue&
         }
         // a candidate that sorts after the K-th entry of a full queue would fall straight off the end of the insertion
         // network: skip the network for it
-        if (ins && q.admits(K, h.z, f)) q.insert(K, h.z, f, pl);
+        if (ins && q.admits(K, h.z, f)) {
+          if constexpr (Queue::kPayload > 0) {
+            const float pl[kMeshPayload] = {h.dist, h.bary.x, h.bary.y, h.bary.z};
+            q.insert(K, h.z, f, pl);
+          } else {
+            const float none[1] = {0.0f};  // (z, index) only: distance and barycentrics are recomputed when the pixel is written
+            q.insert(K, h.z, f, none);
+          }
+        }
       }
     }
   }
@@ -377,7 +552,9 @@ __device__ __forceinline__ void cover_mark(const MeshArgs& a, int n, int sy0, bo
 __device__ __forceinline__ float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
 struct StageLds {
-  float4* box;
+  unsigned* pm;     // per staged face: column mask (bits 0..15) | row mask (bits 16..31) of the tile's pixels inside its box
+  float pxy;        // lane c < 16: NDC centre of the tile's pixel column c; lane 16 + r: of its pixel row r (every wave alike)
+  unsigned valid_c, valid_r;  // columns / rows of the tile that exist in the image
   float4 (*rec)[kRecWords];
   float* zc;
   int* order;
@@ -402,6 +579,7 @@ __device__ __forceinline__ int stage_chunk(const MeshArgs& a, const StageLds& l,
   f3 v0, v1, v2;
   FaceSetup fs;
   int fid = -1, nb = -1;
+  unsigned cm = 0, rm = 0;
   if (i < count) {
     fid = BINNED ? a.csr.list[src_base + i] : (int)(src_base + i);
     const float* g = a.face_verts + (int64_t)fid * 9;
@@ -410,8 +588,22 @@ __device__ __forceinline__ int stage_chunk(const MeshArgs& a, const StageLds& l,
     v1 = mk3(g[3], g[4], g[5]);
     v2 = mk3(g[6], g[7], g[8]);
     fs = face_setup(v0, v1, v2, a.sqrt_blur, cull);
-    const bool off_tile = tile.x0 > fs.xhi || tile.x1 < fs.xlo || tile.y0 > fs.yhi || tile.y1 < fs.ylo;
-    keep = !fs.reject && !off_tile;
+    // the tile's pixel columns / rows whose centres lie inside the blur-expanded box: the per-pixel bbox test of the
+    // reference (rasterize_meshes.cu:94-97, strict comparisons) done once per (face, column) and (face, row)
+    // (the centres are monotone in the pixel index, so the pixels inside form the range [#(centre < lo), 15 - #(centre > hi)])
+    int xb = 0, xa = 0, yb = 0, ya = 0;  // centres below the box's low edge / above its high edge
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const float xs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l.pxy), c));
+      const float ys = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l.pxy), 16 + c));
+      xb += xs < fs.xlo ? 1 : 0;
+      xa += xs > fs.xhi ? 1 : 0;
+      yb += ys < fs.ylo ? 1 : 0;
+      ya += ys > fs.yhi ? 1 : 0;
+    }
+    cm = range_mask16(xb, xa) & l.valid_c;
+    rm = range_mask16(yb, ya) & l.valid_r;
+    keep = !fs.reject && cm != 0 && rm != 0;  // some pixel centre of the tile is inside the box
     if (keep && prune)
       keep = !rect_cannot_hit(mk2(v0.x, v0.y), mk2(v1.x, v1.y), mk2(v2.x, v2.y), tile.x0, tile.x1, tile.y0, tile.y1, a.sqrt_blur);
   }
@@ -431,7 +623,7 @@ __device__ __forceinline__ int stage_chunk(const MeshArgs& a, const StageLds& l,
     FaceRec fr;
     face_rec_make(v0, v1, v2, &fr);
     gen = nb != -1 || (PC && fr.wide);
-    l.box[pos] = make_float4(fs.xlo, fs.xhi, fs.ylo, fs.yhi);
+    l.pm[pos] = cm | (rm << 16);
     l.rec[pos][0] = make_float4(v0.x, v0.y, v1.x, v1.y);
     l.rec[pos][1] = make_float4(v2.x, v2.y, v0.z, v1.z);
     l.rec[pos][2] = make_float4(v2.z, __int_as_float(fid), __int_as_float(nb), __int_as_float(fr.wide ? 1 : 0));
@@ -466,9 +658,9 @@ struct SubTile {
 // 16 so that every wave sees a front-to-back subsequence of about the same depth range.
 template <bool GENERAL, typename Queue, bool PC = false>
 __device__ __forceinline__ void wave_chunk(const MeshArgs& a, int K, Queue& q, int staged, bool sorted, const SubTile& st, f2 p,
-                                           bool pix_ok, int lane, bool persp, bool clip, bool prune, const float4* s_box,
+                                           bool pix_ok, int lane, bool persp, bool clip, bool prune, const unsigned* s_pm,
                                            const float4 (*s_rec)[kRecWords], const float* s_zc, const int* s_order,
-                                           const float* s_qlow, int deal = -1) {
+                                           const float* s_qlow, int cshift, int rshift, int deal = -1) {
   for (int jb = 0; jb < staged; jb += kWave) {
     const int jfirst = deal >= 0 ? deal * 16 : jb;  // this wave's first position
     if (jfirst >= staged) break;
@@ -477,17 +669,24 @@ __device__ __forceinline__ void wave_chunk(const MeshArgs& a, int K, Queue& q, i
     const int j = deal >= 0 ? (((lane >> 4) * 4 + deal) * 16 + (lane & 15)) : jb + lane;
     bool touch = false;
     int oj = 0;
+    unsigned mlo = 0, mhi = 0;
+    float zcv = 0.0f;
     if (j < staged) {
       oj = s_order[j];
-      const float4 b = s_box[oj];
-      touch = !(st.x0 > b.y || st.x1 < b.x || st.y0 > b.w || st.y1 < b.z);
+      const unsigned pm = s_pm[oj];
+      // this wave's 8 columns / 8 rows of the tile's masks; the sub-tile's pixels inside the box as a 64-bit lane mask
+      // (lane = 8 * row + column; p3d_geom.h: block_mask_8x8)
+      const unsigned cmask = (pm >> cshift) & 0xffu, rmask = (pm >> (16 + rshift)) & 0xffu;
+      touch = (cmask != 0) & (rmask != 0);
       if (touch && prune) {
         const float4 r0 = s_rec[oj][0], r1 = s_rec[oj][1];
         touch = !rect_cannot_hit(mk2(r0.x, r0.y), mk2(r0.z, r0.w), mk2(r1.x, r1.y), st.x0, st.x1, st.y0, st.y1, a.sqrt_blur);
       }
+      block_mask_8x8(cmask, rmask, &mlo, &mhi);
+      zcv = s_zc[oj];
     }
     const unsigned long long cand = __ballot(touch);
-    eval_candidates<GENERAL, Queue, PC>(a, K, q, cand, oj, p, pix_ok, persp, clip, s_box, s_rec, s_zc);
+    eval_candidates<GENERAL, Queue, PC>(a, K, q, cand, oj, mlo, mhi, zcv, p, pix_ok, persp, clip, s_rec);
     if (deal >= 0) break;  // a chunk holds at most 256 positions: one group per wave
   }
 }
@@ -537,7 +736,7 @@ template <typename Queue, int KT, bool IN_REGS, bool BINNED, bool EXACT, int WAV
           bool SPLIT = false>
 __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) {
   __shared__ float s_merge[SPLIT ? 3 * kMergeWords * KT * kWave : 1];
-  __shared__ float4 s_box[kStage];                  // xlo, xhi, ylo, yhi (blur-expanded)
+  __shared__ unsigned s_pm[kStage];                 // pixel column | row masks of the staged faces (StageLds::pm)
   __shared__ float4 s_rec[kStage][kRecWords];       // see kRecWords
   __shared__ __align__(16) float s_zc[kStage];      // depth-cull key: every sample of the face has z >= s_zc (or -inf)
   __shared__ int s_order[kStage];                   // visiting order of the staged faces: ascending s_zc (by bucket) when order is free
@@ -634,7 +833,7 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
       // the four waves cover the same pixels: wave 0 writes them
     } else if ((Kbg & 3) == 0) {
       fill_tile_background<kStage>(a, n, ty0, tx0, y_end, x_end, tid);
-    } else if constexpr (EXACT) {
+    } else if constexpr (EXACT && Queue::kPayload > 0) {
       Queue e;
       e.init();
       if (pix_ok) write_pixel<Queue, KT, IN_REGS>(a, e, ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi));
@@ -660,7 +859,16 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
   const bool persp = PC || a.persp != 0, clip = PC || a.clip != 0, cull = a.cull != 0;
   const bool prune = true;  // the conservative rectangle-vs-face reject of the tile / sub-tile culls
   StageLds lds;
-  lds.box = s_box;
+  lds.pm = s_pm;
+  {
+    // the tile the masks refer to: the workgroup's 16 x 16 tile, or (split mode) its one 8 x 8 sub-tile
+    const int ox = SPLIT ? sx0 : tx0, oy = SPLIT ? sy0 : ty0, side = SPLIT ? 8 : kTile;
+    const int cols = min(side, x_end - ox), rows = min(side, y_end - oy);
+    lds.valid_c = (1u << cols) - 1u;
+    lds.valid_r = (1u << rows) - 1u;
+    const int li = lane & 15;
+    lds.pxy = (lane & 16) ? pix_to_ndc(oy + li, H, W) : pix_to_ndc(ox + li, W, H);
+  }
   lds.rec = s_rec;
   lds.zc = s_zc;
   lds.order = s_order;
@@ -693,11 +901,11 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
     if (general) break;  // uniform
     chunk_bucket_order(s_zc, staged, s_order, s_qlow, s_ord, tid);
     if (run_waves)
-      wave_chunk<false, Queue, PC>(a, K, q, staged, true, st, p, pix_ok, lane, persp, clip, prune, s_box, s_rec, s_zc, s_order, s_qlow,
-                                   SPLIT ? w : -1);
+      wave_chunk<false, Queue, PC>(a, K, q, staged, true, st, p, pix_ok, lane, persp, clip, prune, s_pm, s_rec, s_zc, s_order, s_qlow,
+                                   SPLIT ? 0 : (sub & 1) * 8, SPLIT ? 0 : (sub >> 1) * 8, SPLIT ? w : -1);
     __syncthreads();
   }
-  if constexpr (SPLIT) {
+  if constexpr (SPLIT && Queue::kPayload > 0) {
     // the queues of waves 1..3 join wave 0's: before the general nest (its neighbour rule must see every entry queued so
     // far, and only wave 0 walks it), or before the pixels are written
     if (w != 0) merge_dump<Queue, KT>(q, s_merge + (w - 1) * kMergeWords * KT * kWave, lane);
@@ -713,7 +921,8 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
       if (tid < staged) s_order[tid] = tid;
       __syncthreads();
       if (run_waves && (!SPLIT || w == 0))
-        wave_chunk<true, Queue>(a, K, q, staged, false, st, p, pix_ok, lane, persp, clip, prune, s_box, s_rec, s_zc, s_order, s_qlow);
+        wave_chunk<true, Queue>(a, K, q, staged, false, st, p, pix_ok, lane, persp, clip, prune, s_pm, s_rec, s_zc, s_order, s_qlow,
+                                SPLIT ? 0 : (sub & 1) * 8, SPLIT ? 0 : (sub >> 1) * 8);
       __syncthreads();
       base += kStage;
       if (base >= count) break;
@@ -723,7 +932,11 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
   }
 
   {
-    if constexpr (EXACT) {
+    if constexpr (Queue::kPayload == 0) {
+      static_assert(!SPLIT, "queues without payload do not run in split mode");
+      if (wave_ok) write_pixel_long<Queue, KT, EXACT>(a, q, ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi), p, pix_ok, persp, clip);
+      if (a.cover != nullptr && wave_ok) cover_mark(a, n, sy0, pix_ok && q.valid(0), H - 1 - yi, W - 1 - xi, lane);
+    } else if constexpr (EXACT) {
       if (pix_ok && (!SPLIT || w == 0)) {
         // the pixel's coordinates are rebuilt from a fresh lane id: keeping yi / xi alive across the chunk loops costs the
         // two registers that separate this kernel from the 120-VGPR allocation step
@@ -787,6 +1000,17 @@ void launch_fine_variant(const MeshArgs& a, unsigned grid, bool split, size_t dy
   mesh_raster_kernel<Q, KT, REGS, BINNED, EXACT><<<grid, kStage, dyn_lds, stream>>>(a);
 }
 
+// Queues without payload (K <= KT live entries): the perspective + clip instantiation (64-bit key compares; depths are
+// >= +0 there: clipped barycentrics are >= +0 and faces with a vertex depth below 1e-8 never reach the queue, face_setup) when
+// both flags are set.
+template <int KT, bool BINNED, int WAVES>
+void launch_long_variant(const MeshArgs& a, unsigned grid, hipStream_t stream) {
+  if (a.persp && a.clip)
+    mesh_raster_kernel<TopKPairs<KT, true, 0>, KT, true, BINNED, false, WAVES, true><<<grid, kStage, 0, stream>>>(a);
+  else
+    mesh_raster_kernel<TopKPairs<KT, false, 0>, KT, true, BINNED, false, WAVES><<<grid, kStage, 0, stream>>>(a);
+}
+
 #define P3D_COMMA ,
 template <bool BINNED>
 int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
@@ -802,30 +1026,47 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
   const size_t dyn_lds = 0;
 #define P3D_LAUNCH_FINE(KT_, REGS_, EXACT_, Q_) launch_fine_variant<Q_, KT_, REGS_, BINNED, EXACT_>(a, grid, split, dyn_lds, stream)
 #define P3D_LAUNCH_FINE_W(KT_, WAVES_, Q_) mesh_raster_kernel<Q_, KT_, true, BINNED, false, WAVES_><<<grid, kStage, 0, stream>>>(a)
+#define P3D_LAUNCH_LONG(KT_, WAVES_) launch_long_variant<KT_, BINNED, WAVES_>(a, grid, stream)
+  // Up to 16: queues WITH payload in registers.  K = 1, 2, 4, 8, 16 have exact instantiations (vector-row epilogue, no
+  // test on K left); every other K runs the pair queue of the next capacity with K live entries (topk.h: TopKPairs::insert
+  // skips the steps of the dead entries with scalar branches).  Until round 3 those K ran TopKReg queues of 8 / 12 entries
+  // whose kernels sit at the register limit of their launch bounds; with round 4's pixel masks they spilled, and a kernel of
+  // this file that spills VGPRs next to its SGPR spills loses queue entries (profiles/r04/spill_miscompile.md) -- the
+  // build now refuses such kernels (pytorch3d_amd/build.py).
   if (K == 1)
     P3D_LAUNCH_FINE(1, true, true, TopKReg<1 P3D_COMMA kMeshPayload>);
   else if (K == 2)
     P3D_LAUNCH_FINE(2, true, true, TopKReg<2 P3D_COMMA kMeshPayload>);
   else if (K == 3)
-    P3D_LAUNCH_FINE(4, true, false, TopKReg<4 P3D_COMMA kMeshPayload>);
+    P3D_LAUNCH_FINE_W(4, kFineWaves, TopKPairs<4>);
   else if (K == 4)  // K = 4, 8, 16: the queue in register pairs (topk.h: TopKPairs; one 64-bit key compare per entry in the
     P3D_LAUNCH_FINE(4, true, true, TopKPairs<4>);  // perspective + clip kernels): measured -3 % / -11 % / -10 % (profiles/r03)
-  else if (K < 8)
-    P3D_LAUNCH_FINE(8, true, false, TopKReg<8 P3D_COMMA kMeshPayload>);
+  else if (K < 8)  // (2 VGPRs short of four waves per SIMD with the fill + patch epilogue: three)
+    P3D_LAUNCH_FINE_W(8, 3, TopKPairs<8>);
   else if (K == 8)
     P3D_LAUNCH_FINE(8, true, true, TopKPairs<8>);
-  // 9..12: the queue (6 registers per entry: 72) still fits the register file at 3 waves per SIMD; from 16 entries on
-  // the allocator spills hundreds of registers, and the queue in private memory is the better choice
-  else if (K == 16)  // (12 entries in pairs spill 52 B/lane at three waves per SIMD: not offered)
+  else if (K <= 16)  // 16 entries x 3 pairs = 96 registers: two waves per SIMD
     P3D_LAUNCH_FINE_W(16, 2, TopKPairs<16>);
-  else if (K <= 12)
-    P3D_LAUNCH_FINE_W(12, 3, TopKReg<12 P3D_COMMA kMeshPayload>);
-  else if (K <= 16)
-    P3D_LAUNCH_FINE_W(16, 2, TopKReg<16 P3D_COMMA kMeshPayload>);
+  // 17..48: queues without payload in register pairs (write_pixel_long recomputes distance and barycentrics of the survivors).
+  // Four capacities; a queue serves every K up to its capacity at the cost of K entries (topk.h: TopKPairs::insert skips the
+  // steps of the dead entries with scalar branches), so no exact-K instantiations here.  (A TopKReg of 32+ entries keeps its
+  // 32+ comparison masks in SGPRs: they spill, and the build with spills lost candidates -- measured in round 4, not pursued.)
+  else if (K <= 24)
+    P3D_LAUNCH_LONG(24, 3);
+  else if (K <= 32)
+    P3D_LAUNCH_LONG(32, 3);
+  else if (K <= 40)
+    P3D_LAUNCH_LONG(40, 2);
+  else if (K <= 48)
+    P3D_LAUNCH_LONG(48, 2);
+  // (49..64: a 64-entry pair queue needs 128 + ~130 registers -- 70 VGPRs spilled at two waves per SIMD, refused by the build;
+  // at one wave per SIMD the compiler parks 32 of them in AGPRs and that kernel lost entries on the GPU, run to run
+  // differently, whatever was tried in round 4 (profiles/r04/spill_miscompile.md): the private-memory queue keeps K > 48.)
   else
     P3D_LAUNCH_FINE(P3D_MAX_K, false, false, TopKMem<P3D_MAX_K P3D_COMMA kMeshPayload>);
 #undef P3D_LAUNCH_FINE
 #undef P3D_LAUNCH_FINE_W
+#undef P3D_LAUNCH_LONG
   return launch_status();
 }
 

@@ -40,7 +40,8 @@ struct PointArgs {
 // distance is recomputed from the point's coordinates when the pixel is written -- the same two subtractions, two
 // products and one sum as in the test (rasterize_points.cu:55-60), so the same bits.
 // WAVES: minimum waves per SIMD the register allocation has to leave room for (512 / WAVES VGPRs per lane).
-template <typename Queue, int KT, bool IN_REGS, bool BINNED, bool PAYLOAD = true, int WAVES = 2>
+// EXACTK: K == KT is known at compile time (the pair queues' insertion then has no test on K left).
+template <typename Queue, int KT, bool IN_REGS, bool BINNED, bool PAYLOAD = true, int WAVES = 2, bool EXACTK = false>
 __global__ __launch_bounds__(kStage, WAVES) void point_raster_kernel(PointArgs a) {
   __shared__ float4 s_box[kStage];  // x-r, x+r, y-r, y+r
   __shared__ float4 s_pt[kStage];   // x, y, z, r*r
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(kStage, WAVES) void point_raster_kernel(PointArgs a
 
   Queue q;
   q.init();
-  const int K = a.K;
+  const int K = EXACTK ? KT : a.K;
 
   for (int base = 0; base < count; base += kStage) {
     const int i = base + tid;
@@ -211,7 +212,7 @@ int launch_point_raster(const PointArgs& a, hipStream_t stream) {
   // below (1M points, 512^2): K = 10 0.27 -> 0.18 ms, K = 32 1.55 -> 0.73, K = 50 2.34 -> 1.54, K = 100 9.1 -> 3.0 ms
   // (two waves per SIMD instead of one with 241 AGPRs).  Other K take the queue of the next capacity below.
 #define P3D_PQ(KT_, WAVES_) \
-  point_raster_kernel<TopKPairs<KT_ P3D_COMMA true P3D_COMMA 0>, KT_, true, BINNED, false, WAVES_><<<grid, kStage, 0, stream>>>(a)
+  point_raster_kernel<TopKPairs<KT_ P3D_COMMA true P3D_COMMA 0>, KT_, true, BINNED, false, WAVES_, true><<<grid, kStage, 0, stream>>>(a)
   switch (K) {
     case 8: P3D_PQ(8, 2); return launch_status();
     case 10: P3D_PQ(10, 2); return launch_status();
@@ -251,8 +252,8 @@ int launch_point_raster(const PointArgs& a, hipStream_t stream) {
     point_raster_kernel<TopKReg<50, 0>, 50, true, BINNED, false, 2><<<grid, kStage, 0, stream>>>(a);
   else if (K <= 64)
     point_raster_kernel<TopKReg<64, 0>, 64, true, BINNED, false, 2><<<grid, kStage, 0, stream>>>(a);
-  else if (K <= 100)  // one wave per SIMD: 200 queue registers, the upper ones in AGPRs
-    point_raster_kernel<TopKReg<100, 0>, 100, true, BINNED, false, 1><<<grid, kStage, 0, stream>>>(a);
+  else if (K <= 100)  // 65..99: the pair queue of 100 entries with K live ones (TopKReg<100, 0> spilled 465 VGPRs: refused by the build)
+    point_raster_kernel<TopKPairs<100, true, 0>, 100, true, BINNED, false, 1><<<grid, kStage, 0, stream>>>(a);
   else  // 101..150: 300 queue registers do not fit the 256 VGPRs + 256 AGPRs of a lane without scratch
     point_raster_kernel<TopKMem<P3D_MAX_K, 1>, P3D_MAX_K, false, BINNED><<<grid, kStage, 0, stream>>>(a);
   return launch_status();

@@ -211,7 +211,9 @@ struct SoftTable {
 
 constexpr int kSoftPhongBwdWaves = 3;  // measured (D = 9, K = 8): 146 VGPRs at 3 waves 3.84 ms; capped at 128 (72 B of scratch) 4.80 ms
 template <int D, bool POINT, bool PG, int KT>
-__global__ __launch_bounds__(256, kSoftPhongBwdWaves) void soft_phong_bwd_kernel(SoftPhongArgs a) {
+// PG (gradients to lights / materials / camera: 25 more per-lane sums) needs more than the 168 registers of three waves per
+// SIMD: it spilled 2..19 VGPRs there, and kernels with VGPR spills are refused by the build since round 4 (build.py).
+__global__ __launch_bounds__(256, PG ? 2 : kSoftPhongBwdWaves) void soft_phong_bwd_kernel(SoftPhongArgs a) {
 #pragma clang fp contract(fast)  // gradient-only arithmetic (tolerance-gated): let mul+add fuse into FMA
   using Tab = typename SoftTable<D>::T;
   constexpr int NV = 3 * D;

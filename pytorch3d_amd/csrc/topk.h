@@ -26,6 +26,7 @@ constexpr int kEmptyIdx = 0x7fffffff;
 template <int KT, int NP>
 struct TopKReg {
   static constexpr bool kKeyOrder = false;  // entries are ordered by float compares: -0.0 == +0.0
+  static constexpr int kPayload = NP;       // payload words an entry carries (0: the consumer recomputes them from the index)
   static constexpr int NPS = NP > 0 ? NP : 1;  // storage rows; NP = 0: no payload (the one row is never touched and costs no register)
   float z[KT];
   int idx[KT];
@@ -155,6 +156,7 @@ struct TopKReg {
 template <int KMAX, int NP>
 struct TopKMem {
   static constexpr bool kKeyOrder = false;
+  static constexpr int kPayload = NP;
   float z[KMAX];
   int idx[KMAX];
   float pl[NP][KMAX];
@@ -245,6 +247,14 @@ P3D_HDM float bits_f32(unsigned v) {
   c.u = v;
   return c.f;
 }
+// A wave-uniform integer the optimizer may not reason about (no instruction is emitted for it).
+P3D_HDM int opaque_uniform(int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (!__builtin_constant_p(v)) asm volatile("" : "+s"(v));
+#endif
+  return v;
+}
+
 P3D_HDM u32x2 mk_pair(unsigned lo, unsigned hi) {
   u32x2 r;
   r[0] = lo;
@@ -261,6 +271,7 @@ template <int KT, bool KEY64 = false, int NP = 4>
 struct TopKPairs {
   static_assert(NP == 4 || NP == 0, "payload pairs: two or none");
   static constexpr bool kKeyOrder = KEY64;  // ordered by the bit pattern of z: the caller supplies depths >= +0
+  static constexpr int kPayload = NP;
   static constexpr int KP = NP == 4 ? KT : 1;
   static constexpr int NPS = NP > 0 ? NP : 1;
   u32x2 zi[KT];  // z bits, idx (KEY64: idx, z bits)
@@ -301,6 +312,8 @@ struct TopKPairs {
 
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef unsigned long long LaneMask;
+  // (the masked-move blocks below change SCC -- s_and_saveexec / s_and write it -- and say so: since round 4 scalar compares
+  // on a runtime K sit right next to them, and a compare result the compiler kept in SCC across a block came back wrong)
   // three compares straight into lane masks, combined on the scalar unit (a ballot of the combined bool goes through
   // a v_cndmask + v_cmp pair)
   __device__ __forceinline__ LaneMask sorts_before(float cz, int cidx, int k) const {
@@ -321,7 +334,8 @@ struct TopKPairs {
           "v_pk_mov_b32 %[z], %[pz], %[pz] op_sel:[0,1]\n\t"
           "s_mov_b64 exec, %[sv]"
           : [z] "+v"(zi[k]), [sv] "=&s"(saved)
-          : [m] "s"(m), [m1] "s"(m1), [cz] "v"(czi), [pz] "v"(zi[k - 1]));
+          : [m] "s"(m), [m1] "s"(m1), [cz] "v"(czi), [pz] "v"(zi[k - 1])
+          : "scc");
       return;
     }
     asm volatile(
@@ -336,7 +350,8 @@ struct TopKPairs {
         "s_mov_b64 exec, %[sv]"
         : [z] "+v"(zi[k]), [a] "+v"(pa[k % KP]), [b] "+v"(pb[k % KP]), [sv] "=&s"(saved)
         : [m] "s"(m), [m1] "s"(m1), [cz] "v"(czi), [ca] "v"(cpa), [cb] "v"(cpb), [pz] "v"(zi[k - 1]), [pa_] "v"(pa[(k - 1) % KP]),
-          [pb_] "v"(pb[(k - 1) % KP]));
+          [pb_] "v"(pb[(k - 1) % KP])
+          : "scc");
   }
   __device__ __forceinline__ void place(int k, LaneMask m, u32x2 czi, u32x2 cpa, u32x2 cpb) {
     LaneMask saved;
@@ -346,7 +361,8 @@ struct TopKPairs {
           "v_pk_mov_b32 %[z], %[cz], %[cz] op_sel:[0,1]\n\t"
           "s_mov_b64 exec, %[sv]"
           : [z] "+v"(zi[k]), [sv] "=&s"(saved)
-          : [m] "s"(m), [cz] "v"(czi));
+          : [m] "s"(m), [cz] "v"(czi)
+          : "scc");
       return;
     }
     asm volatile(
@@ -356,7 +372,8 @@ struct TopKPairs {
         "v_pk_mov_b32 %[b], %[cb], %[cb] op_sel:[0,1]\n\t"
         "s_mov_b64 exec, %[sv]"
         : [z] "+v"(zi[k]), [a] "+v"(pa[k % KP]), [b] "+v"(pb[k % KP]), [sv] "=&s"(saved)
-        : [m] "s"(m), [cz] "v"(czi), [ca] "v"(cpa), [cb] "v"(cpb));
+        : [m] "s"(m), [cz] "v"(czi), [ca] "v"(cpa), [cb] "v"(cpb)
+          : "scc");
   }
 #else
   typedef bool LaneMask;
@@ -391,21 +408,37 @@ struct TopKPairs {
   }
 #endif
 
-  // K == KT only (exact-K kernels)
-  P3D_HDM void insert(int /*K*/, float cz, int cidx, const float (&cpl)[NPS]) {
+  // K <= KT live entries, K uniform over the wave (the exact-K kernels pass the constant KT and every test on K folds away).
+  // Entries K .. KT-1 are never written: their steps of the network are skipped by scalar branches, so a queue of
+  // capacity KT serves every K below it at the cost of K entries -- the live capacity must be exactly K, not KT, because
+  // the clipped-neighbour rule looks the other half of a split face up in the CURRENT K nearest (rasterize_meshes.cu:186-215).
+  P3D_HDM void insert(int K, float cz, int cidx, const float (&cpl)[NPS]) {
     const u32x2 czi = mk_entry(cz, cidx);
     const u32x2 cpa = NP == 4 ? mk_pair(f32_bits(cpl[0]), f32_bits(cpl[1 % NPS])) : czi;
     const u32x2 cpb = NP == 4 ? mk_pair(f32_bits(cpl[2 % NPS]), f32_bits(cpl[3 % NPS])) : czi;
-    LaneMask mk = sorts_before(cz, cidx, KT - 1);
+    LaneMask mk = 0;
 #pragma unroll
     for (int k = KT - 1; k >= 1; --k) {
-      const LaneMask mk1 = sorts_before(cz, cidx, k - 1);  // reads entry k-1 before it can change
-      place_and_shift(k, mk, mk1, czi, cpa, cpb);
-      mk = mk1;
+      // (a runtime K is re-read through an empty asm per step: left alone, the compiler evaluates all 2 KT tests on K ahead of
+      // the loop nest as 64-bit masks, spills them into VGPR lanes and fetches them back with two v_readlane per step)
+      const int Kq = opaque_uniform(K);
+      if (k < Kq) {  // uniform
+        if (k == Kq - 1) mk = sorts_before(cz, cidx, k);     // the first live step has no predecessor that computed its mask
+        const LaneMask mk1 = sorts_before(cz, cidx, k - 1);  // reads entry k-1 before it can change
+        place_and_shift(k, mk, mk1, czi, cpa, cpb);
+        mk = mk1;
+        if (k == Kq - 1) {
+          kz = zf(k);
+          ki = ix(k);
+        }
+      }
     }
+    if (K == 1) mk = sorts_before(cz, cidx, 0);
     place(0, mk, czi, cpa, cpb);
-    kz = zf(KT - 1);
-    ki = ix(KT - 1);
+    if (K == 1) {
+      kz = zf(0);
+      ki = ix(0);
+    }
   }
 
   P3D_HDM int find(int want) const {
@@ -452,6 +485,10 @@ struct PcQueue {
 template <int KT>
 struct PcQueue<TopKPairs<KT, false, 4>> {
   typedef TopKPairs<KT, true> type;
+};
+template <int KT>
+struct PcQueue<TopKPairs<KT, false, 0>> {
+  typedef TopKPairs<KT, true, 0> type;
 };
 
 }  // namespace p3d

@@ -181,6 +181,57 @@ extern "C" int64_t hg_exact_div_check(int64_t trials, uint64_t seed) {
   return bad;
 }
 
+// Pixel masks of a bounding box (p3d_geom.h: range_mask16, block_mask_8x8 -- what the fine rasterizer's staging and sub-tile
+// cull build) against the reference's per-pixel test px > xhi || px < xlo || py > yhi || py < ylo, on random tiles of random
+// image sizes (partial tiles at the image edge included) and boxes whose edges sit between, exactly on and far from pixel
+// centres, NaN edges included.  Returns the number of (pixel, box) pairs whose mask bit differs from the per-pixel test.
+extern "C" int64_t hg_pixel_mask_check(int64_t trials, uint64_t seed) {
+  uint64_t s = seed * 0x9E3779B97F4A7C15ull + 1;
+  auto next = [&]() {
+    s ^= s << 13;
+    s ^= s >> 7;
+    s ^= s << 17;
+    return s;
+  };
+  auto uni = [&]() { return (float)((double)(next() >> 11) * (1.0 / 9007199254740992.0)); };
+  int64_t bad = 0;
+  for (int64_t t = 0; t < trials; ++t) {
+    const int W = 16 + (int)(next() % 1000), H = 16 + (int)(next() % 1000);
+    const int ox = (int)(next() % (unsigned)W) & ~15, oy = (int)(next() % (unsigned)H) & ~15;
+    const int cols = (W - ox) < 16 ? (W - ox) : 16, rows = (H - oy) < 16 ? (H - oy) : 16;
+    const float cx = pix_to_ndc(ox + (int)(next() % 16), W, H), cy = pix_to_ndc(oy + (int)(next() % 16), H, W);
+    const float ex = exp2f(-12.0f + 11.0f * uni()), ey = exp2f(-12.0f + 11.0f * uni());
+    float xlo = cx - ex * uni(), xhi = cx + ex * uni(), ylo = cy - ey * uni(), yhi = cy + ey * uni();
+    if (t % 7 == 0) xlo = pix_to_ndc(ox + (int)(next() % 16), W, H);  // exactly a centre: the comparisons are strict
+    if (t % 11 == 0) xhi = pix_to_ndc(ox + (int)(next() % 16), W, H);
+    if (t % 13 == 0) ylo = pix_to_ndc(oy + (int)(next() % 16), H, W);
+    if (t % 17 == 0) yhi = pix_to_ndc(oy + (int)(next() % 16), H, W);
+    if (t % 1009 == 0) xlo = NAN;
+    if (t % 1013 == 0) yhi = NAN;
+    int xb = 0, xa = 0, yb = 0, ya = 0;
+    for (int c = 0; c < 16; ++c) {
+      const float xs = pix_to_ndc(ox + c, W, H), ys = pix_to_ndc(oy + c, H, W);
+      xb += xs < xlo ? 1 : 0;
+      xa += xs > xhi ? 1 : 0;
+      yb += ys < ylo ? 1 : 0;
+      ya += ys > yhi ? 1 : 0;
+    }
+    const unsigned cm = range_mask16(xb, xa) & ((1u << cols) - 1u), rm = range_mask16(yb, ya) & ((1u << rows) - 1u);
+    for (int sub = 0; sub < 4; ++sub) {
+      unsigned lo, hi;
+      block_mask_8x8((cm >> ((sub & 1) * 8)) & 0xffu, (rm >> ((sub >> 1) * 8)) & 0xffu, &lo, &hi);
+      const uint64_t m = ((uint64_t)hi << 32) | lo;
+      for (int lane = 0; lane < 64; ++lane) {
+        const int xi = ox + (sub & 1) * 8 + (lane & 7), yi = oy + (sub >> 1) * 8 + (lane >> 3);
+        const float px = pix_to_ndc(xi, W, H), py = pix_to_ndc(yi, H, W);
+        const bool want = xi < W && yi < H && !(px > xhi || px < xlo || py > yhi || py < ylo);
+        if (want != (bool)((m >> lane) & 1ull)) ++bad;
+      }
+    }
+  }
+  return bad;
+}
+
 // the atlas cell (atlas_cell.h) of P barycentric samples: cells[p] = row * R + col, or -1 where not addressable
 extern "C" void hg_atlas_cells(const float* bary, int64_t P, int R, int64_t* cells) {
   for (int64_t p = 0; p < P; ++p) {
@@ -305,7 +356,9 @@ extern "C" int64_t hg_queue_pairs_check(int64_t sequences, uint64_t seed) {
   return bad;
 }
 
-// The payload-free form (long point queues): TopKPairs<12, *, 0> against TopKReg<12, 0>, inserts gated by admits().
+// The payload-free form (long point queues; mesh queues for 16 < K <= 64): TopKPairs<12, *, 0> against TopKReg<12, 0>, inserts
+// gated by admits(), with a live capacity K <= 12 drawn per sequence (entries K.. must stay empty, the K-th entry is the
+// admission threshold) and occasional erasures (the clipped-neighbour rule: the queue has room again afterwards).
 extern "C" int64_t hg_queue_pairs0_check(int64_t sequences, uint64_t seed) {
   uint64_t s = seed * 0x9E3779B97F4A7C15ull + 11;
   auto next = [&]() {
@@ -324,19 +377,30 @@ extern "C" int64_t hg_queue_pairs0_check(int64_t sequences, uint64_t seed) {
     c.init();
     const int ops = 4 + (int)(next() % 60);
     const int zlevels = 1 + (int)(next() % 9);
+    const int K = (next() % 3 == 0) ? 12 : 1 + (int)(next() % 12);
     for (int o = 0; o < ops; ++o) {
       const uint64_t r = next();
       const float z = (float)(r % zlevels) * 0.5f + ((r >> 8) % 4 == 0 ? 0.0f : 1e-4f * (float)((r >> 12) % 3));
       const int idx = (int)((r >> 20) % 97);
       const float pl[1] = {0.0f};
-      const bool ad = a.admits(12, z, idx);
-      if (ad != b.admits(12, z, idx) || ad != c.admits(12, z, idx)) ++bad;
-      if (ad) {
-        a.insert(12, z, idx, pl);
-        b.insert(12, z, idx, pl);
-        c.insert(12, z, idx, pl);
+      if ((r >> 40) % 11 == 0) {  // erase a queued primitive, if this one is queued
+        const int at = a.find(idx);
+        if (at != b.find(idx) || at != c.find(idx)) ++bad;
+        if (at >= 0) {
+          a.erase(at);
+          b.erase(at);
+          c.erase(at);
+        }
+        continue;
       }
-      if ((a.kth_z(12) != b.kth_z(12) || a.kth_z(12) != c.kth_z(12))) ++bad;
+      const bool ad = a.admits(K, z, idx);
+      if (ad != b.admits(K, z, idx) || ad != c.admits(K, z, idx)) ++bad;
+      if (ad) {
+        a.insert(K, z, idx, pl);
+        b.insert(K, z, idx, pl);
+        c.insert(K, z, idx, pl);
+      }
+      if ((a.kth_z(K) != b.kth_z(K) || a.kth_z(K) != c.kth_z(K))) ++bad;
       for (int k = 0; k < 12; ++k) {
         if (a.valid(k) != b.valid(k) || a.valid(k) != c.valid(k) || a.ix(k) != b.ix(k) || a.ix(k) != c.ix(k)) ++bad;
         if (a.valid(k) && (a.zf(k) != b.zf(k) || a.zf(k) != c.zf(k))) ++bad;

@@ -271,6 +271,21 @@ def test_shared_reciprocal_division_is_exact_and_fast_path_equals_plain_path():
                 assert torch.equal(a, b), (case, size)
 
 
+def test_pixel_masks_equal_the_per_pixel_bbox_test():
+    """csrc/p3d_geom.h: range_mask16 / block_mask_8x8 -- the fine rasterizer takes a face's bounding-box test once per
+    (face, tile column) and (face, tile row) and hands the pixels inside to a visit as a 64-bit lane mask; the reference
+    tests every pixel (rasterize_meshes.cu:94-97, strict comparisons).  Host build of the header: 128M (pixel, box) pairs on
+    random image sizes, partial tiles, edges exactly on pixel centres, NaN edges -- the mask bit equals the per-pixel test."""
+    import ctypes
+
+    import _util as U
+
+    hg = U.hostgeom()
+    hg.hg_pixel_mask_check.restype = ctypes.c_int64
+    hg.hg_pixel_mask_check.argtypes = [ctypes.c_int64, ctypes.c_uint64]
+    assert hg.hg_pixel_mask_check(500_000, 3) == 0
+
+
 def test_point_rasterizer_host_logic():
     """pytorch3d_amd/rasterize_points.py: radius forms, the reference's bin-size heuristic (rasterize_points.py:104-113, no
     "<= 64 -> 8" special case as meshes have) and its error; the kernels themselves refuse CPU tensors."""
@@ -355,3 +370,22 @@ def test_pair_register_queue_scheme_matches_the_register_queue():
     hg.hg_queue_pairs0_check.restype = ctypes.c_int64
     hg.hg_queue_pairs0_check.argtypes = [ctypes.c_int64, ctypes.c_uint64]
     assert hg.hg_queue_pairs0_check(200_000, 7) == 0
+
+
+def test_no_kernel_of_the_library_spills_vgprs():
+    """pytorch3d_amd/build.py records the compiler's per-kernel resource usage next to the library and refuses a build in which
+    a kernel spills VGPRs: in round 4 every kernel of raster_mesh.hip that did lost queue entries on the GPU, bit-exact again as
+    soon as it fitted its registers (profiles/r04/spill_miscompile.md).  Scratch itself is fine where it is the design (the
+    private-memory queue TopKMem for K > 64 / > 100)."""
+    import json
+
+    from pytorch3d_amd import build as B
+
+    path = B.LIB + ".resources.json"
+    assert os.path.exists(path), "build the library with `python -m pytorch3d_amd.build` (conftest does)"
+    res = json.load(open(path))
+    assert len(res) > 150
+    spilled = {B.demangle(k): v["vgpr_spill"] for k, v in res.items() if v["vgpr_spill"] != 0}
+    assert not spilled, spilled
+    scratch = sorted(B.demangle(k) for k, v in res.items() if v["scratch"] > 0)
+    assert all("TopKMem" in k for k in scratch), scratch

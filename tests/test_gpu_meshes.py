@@ -57,16 +57,33 @@ def test_naive_and_binned_vs_oracle(size, blur, persp, clip, cull):
         _assert_fwd_equal(binned, ref, tag=f"bin_size={bin_size}")
 
 
-@pytest.mark.parametrize("K", [1, 2, 3, 5, 8, 9, 12, 14, 16, 40, 150])
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 15, 16, 17, 20, 23, 24, 25, 31, 32, 33, 40, 41, 47, 48, 49, 50, 56, 63, 64, 65, 100, 150])
 def test_all_queue_capacities(K):
+    """Every queue of the launcher (raster_mesh.hip: launch_mesh_raster): register queues with payload up to 16, queues
+    without payload (distance / barycentrics recomputed at the store) for 17..64 at their exact capacities and at the
+    next one above K, the private-memory queue beyond -- with and without the perspective + clip instantiation
+    (64-bit key compares), binned and naive."""
     gen = torch.Generator().manual_seed(K)
     F = 300
     fv = U.triangle_soup(F, gen, size=1.0)
     first, count = U.split_counts(F, 2)
     nbr = torch.full((F,), -1, dtype=torch.int64)
-    ref = orc.rasterize_meshes_naive(fv, first, count, nbr, (24, 24), 0.005, K, True, True, False)
-    ours = _run_ours(fv, first, count, nbr, (24, 24), 0.005, K, 8, 300, True, True, False)
-    _assert_fwd_equal(ours, ref, tag=f"K={K}")
+    for persp, clip in ((True, True), (True, False), (False, False)):
+        ref = orc.rasterize_meshes_naive(fv, first, count, nbr, (24, 24), 0.005, K, persp, clip, False)
+        ours = _run_ours(fv, first, count, nbr, (24, 24), 0.005, K, 8, 300, persp, clip, False)
+        _assert_fwd_equal(ours, ref, tag=f"K={K} persp={persp} clip={clip}")
+    # A soup of frame-sized triangles: ~100 faces over every pixel, so every queue up to 64 entries OVERFLOWS (asserted) -- the
+    # regime in which round 4's kernels with VGPR spills lost entries while the sparse soup above still passed
+    # (profiles/r04/spill_miscompile.md); two chunks of faces in the naive path; a non-square image with partial tiles.
+    big = U.triangle_soup(260, gen, size=4.0)
+    bfirst, bcount = U.split_counts(260, 1)
+    bnbr = torch.full((260,), -1, dtype=torch.int64)
+    for persp, clip in ((True, True), (False, False)):
+        ref = orc.rasterize_meshes_naive(big, bfirst, bcount, bnbr, (20, 37), 0.02, K, persp, clip, False)
+        assert K > 64 or int((ref[0][..., K - 1] >= 0).sum()) > 0, "the soup does not fill a queue of this length"
+        for bin_size in (0, 8):
+            ours = _run_ours(big, bfirst, bcount, bnbr, (20, 37), 0.02, K, bin_size, 300, persp, clip, False)
+            _assert_fwd_equal(ours, ref, tag=f"K={K} persp={persp} clip={clip} 20x37 bin={bin_size}")
 
 
 def test_k_too_large_raises():
@@ -115,7 +132,7 @@ def test_clipped_neighbor_rule():
         nbr[a], nbr[a + 1] = a + 1, a
         fv[a + 1] = fv[a] + torch.randn(3, 3, generator=gen) * 0.05
     first, count = U.split_counts(F, 1)
-    for K in (2, 5, 30):
+    for K in (2, 5, 17, 20, 30, 32, 64):  # 17..64: queues without payload -- the rule's distance test recomputes the queued half
         ref = orc.rasterize_meshes_naive(fv, first, count, nbr, (24, 24), 0.01, K, True, True, False)
         for bin_size in (0, 8):
             ours = _run_ours(fv, first, count, nbr, (24, 24), 0.01, K, bin_size, 100, True, True, False)

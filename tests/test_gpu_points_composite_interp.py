@@ -42,6 +42,30 @@ def test_points_naive_and_binned_vs_oracle(size, K):
         assert all(torch.equal(a, b) for a, b in zip(ours, r))
 
 
+@pytest.mark.parametrize("K", [1, 2, 4, 5, 8, 10, 12, 16, 24, 32, 33, 40, 50, 64, 65, 80, 99, 100, 101, 150])
+def test_points_queues_overflow_vs_oracle(K):
+    """A cloud dense enough that EVERY queue overflows (~200 splats over each pixel; the sparse cloud above never fills a
+    queue beyond 8 entries): all capacities of the launcher, the pair queue of 100 entries with 65..99 live ones
+    (round 4: TopKReg<100, 0> spilled 465 VGPRs and is gone), the private-memory queue beyond 100."""
+    from pytorch3d_amd import _C
+
+    d = _dev()
+    gen = torch.Generator().manual_seed(1000 + K)
+    P = 1500
+    pts = _cloud(P, gen)
+    first = torch.tensor([0, 700])
+    count = torch.tensor([700, 800])
+    radius = torch.rand(P, generator=gen) * 0.3 + 0.45
+    size = (20, 37)
+    ref = orc.rasterize_points_naive(pts, first, count, size, radius, K)
+    assert int((ref[0][..., K - 1] >= 0).sum()) > 0, "the cloud does not fill a queue of this length"
+    for bin_size in (0, 8):
+        ours = _C.rasterize_points(pts.to(d), first.to(d), count.to(d), size, radius.to(d), K, bin_size, 1000)
+        ours = [o.cpu() for o in ours]
+        assert torch.equal(ours[0], ref[0]), f"idx differs K={K} bin={bin_size}: {(ours[0] != ref[0]).sum().item()}"
+        assert torch.equal(ours[1], ref[1]) and torch.equal(ours[2], ref[2])
+
+
 @pytest.mark.parametrize("size,K", [((1100, 900), 6), ((640, 2048), 10)])
 def test_points_on_images_larger_than_the_bin_grid(size, K):
     """Above 512 pixels the internal bins grow beyond one tile: naive == binned (bit-exact), sorted K-prefixes, -1 padding."""
