@@ -289,7 +289,7 @@ __device__ __forceinline__ void fill_tile_full(const MeshArgs& a, int n, int ty0
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Queues without payload (16 < K <= 48, round 4).  With SoftRas blur a covered pixel holds ~17 entries at K = 32..100, and a
+// Queues without payload (8 < K <= 48, round 4).  With SoftRas blur a covered pixel holds ~17 entries at K = 32..100, and a
 // queue in private memory (TopKMem, what K > 16 ran on until round 3) moves O(K) entries of 24 bytes through scratch for
 // every admitted face: K = 32 1.57 ms where K = 16 takes 0.44 (8 bench meshes, profiles/r04).  Here an entry is the ONE
 // register pair (z | index) of topk.h: TopKPairs<KT, ., 0> -- the insertion is one 64-bit compare and two v_pk_mov per
@@ -1027,8 +1027,8 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
 #define P3D_LAUNCH_FINE(KT_, REGS_, EXACT_, Q_) launch_fine_variant<Q_, KT_, REGS_, BINNED, EXACT_>(a, grid, split, dyn_lds, stream)
 #define P3D_LAUNCH_FINE_W(KT_, WAVES_, Q_) mesh_raster_kernel<Q_, KT_, true, BINNED, false, WAVES_><<<grid, kStage, 0, stream>>>(a)
 #define P3D_LAUNCH_LONG(KT_, WAVES_) launch_long_variant<KT_, BINNED, WAVES_>(a, grid, stream)
-  // Up to 16: queues WITH payload in registers.  K = 1, 2, 4, 8, 16 have exact instantiations (vector-row epilogue, no
-  // test on K left); every other K runs the pair queue of the next capacity with K live entries (topk.h: TopKPairs::insert
+  // Up to 8: queues WITH payload in registers.  K = 1, 2, 4, 8 have exact instantiations (vector-row epilogue, no
+  // test on K left); 3 and 5..7 run the pair queue of the next capacity with K live entries (topk.h: TopKPairs::insert
   // skips the steps of the dead entries with scalar branches).  Until round 3 those K ran TopKReg queues of 8 / 12 entries
   // whose kernels sit at the register limit of their launch bounds; with round 4's pixel masks they spilled, and a kernel of
   // this file that spills VGPRs next to its SGPR spills loses queue entries (profiles/r04/spill_miscompile.md) -- the
@@ -1039,18 +1039,20 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
     P3D_LAUNCH_FINE(2, true, true, TopKReg<2 P3D_COMMA kMeshPayload>);
   else if (K == 3)
     P3D_LAUNCH_FINE_W(4, kFineWaves, TopKPairs<4>);
-  else if (K == 4)  // K = 4, 8, 16: the queue in register pairs (topk.h: TopKPairs; one 64-bit key compare per entry in the
+  else if (K == 4)  // K = 4, 8: the queue in register pairs (topk.h: TopKPairs; one 64-bit key compare per entry in the
     P3D_LAUNCH_FINE(4, true, true, TopKPairs<4>);  // perspective + clip kernels): measured -3 % / -11 % / -10 % (profiles/r03)
   else if (K < 8)  // (2 VGPRs short of four waves per SIMD with the fill + patch epilogue: three)
     P3D_LAUNCH_FINE_W(8, 3, TopKPairs<8>);
   else if (K == 8)
     P3D_LAUNCH_FINE(8, true, true, TopKPairs<8>);
-  else if (K <= 16)  // 16 entries x 3 pairs = 96 registers: two waves per SIMD
-    P3D_LAUNCH_FINE_W(16, 2, TopKPairs<16>);
-  // 17..48: queues without payload in register pairs (write_pixel_long recomputes distance and barycentrics of the survivors).
-  // Four capacities; a queue serves every K up to its capacity at the cost of K entries (topk.h: TopKPairs::insert skips the
+  // 9..48: queues without payload in register pairs (write_pixel_long recomputes distance and barycentrics of the survivors).
+  // Five capacities; a queue serves every K up to its capacity at the cost of K entries (topk.h: TopKPairs::insert skips the
   // steps of the dead entries with scalar branches), so no exact-K instantiations here.  (A TopKReg of 32+ entries keeps its
   // 32+ comparison masks in SGPRs: they spill, and the build with spills lost candidates -- measured in round 4, not pursued.)
+  // Measured against the payload queue of 16 entries at two waves per SIMD (8 / 64 bench meshes, profiles/r04/k_long16*.txt):
+  // K = 12 0.40 -> 0.28 ms / 3.44 -> 2.33, K = 16 0.49 -> 0.39 / 4.41 -> 3.05 -- 100 registers, four waves per SIMD.
+  else if (K <= 16)
+    P3D_LAUNCH_LONG(16, 4);
   else if (K <= 24)
     P3D_LAUNCH_LONG(24, 3);
   else if (K <= 32)
