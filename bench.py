@@ -261,9 +261,25 @@ def other_configs(lib, _lib, device):
             return img, gf, ga, gp
 
         wall, kern = _timed(lib, _lib, c4)
+        # algorithmic bytes per launch: points fwd N*H*W*K*12 + P*16; bwd N*H*W*K*12 + P*12 read + P*12 written;
+        # compositor fwd N*H*W*K*(8+4) + min(N*H*W*K, P)*C*4 + N*C*H*W*4; bwd the same reads + N*C*H*W*4 + N*K*H*W*4 + C*P*4
+        px = H * H
+        alg4 = {
+            "points_fine": px * K * 12 + P * 16,
+            "points_backward": px * K * 12 + P * 12 + P * 12,
+            "alpha_composite_fwd": px * K * 12 + min(px * K, P) * C * 4 + C * px * 4,
+            "alpha_composite_bwd": px * K * 12 + min(px * K, P) * C * 4 + C * px * 4 + C * px * 4 + px * K * 4 + C * P * 4,
+        }
+        per_kernel = {k: {"avg_ms": kern[k], "algorithmic_bytes": b, "algorithmic_gbps": b / (kern[k] * 1e-3) / 1e9,
+                          "frac_of_peak": b / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBPS} for k, b in alg4.items() if kern.get(k)}
+        total = sum(alg4.values())
         out["config4_points_1m_512_k10_fwd_bwd"] = {"wall_ms": round(wall, 4), "kernels_ms": kern,
                                                     "kernel_sum_ms": round(sum(kern.values()), 4),
-                                                    "note": "wall includes the torch glue between the operators (alphas, permutes)"}
+                                                    "algorithmic_bytes": total, "per_kernel": per_kernel,
+                                                    "gbps_of_kernel_sum": total / (sum(kern.values()) * 1e-3) / 1e9,
+                                                    "frac_of_peak_kernel_sum": total / (sum(kern.values()) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                                    "note": "wall includes the torch glue between the operators (alphas, permutes); 219 MB "
+                                                            "on one image: latency / binning bound, not bandwidth bound (SURVEY 8(d))"}
     except Exception as e:
         out["config4_points_1m_512_k10_fwd_bwd"] = {"error": repr(e)}
     return out
@@ -298,14 +314,15 @@ def dropin_timing(batch, image_size):
     import subprocess
 
     out = {}
-    for mode in ("c_only", "patched"):
+    for mode, div in (("c_only", TORUS_DIV), ("patched", TORUS_DIV), ("c_only", 1.5), ("patched", 1.5)):
+        key = mode if div == TORUS_DIV else f"{mode}_torus_div_{div}"
         try:
             res = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "dropin_timing.py"), "--mode", mode, "--batch", str(batch),
-                                  "--image-size", str(image_size)], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                                  "--image-size", str(image_size), "--torus-div", str(div)], capture_output=True, text=True, timeout=600, cwd=ROOT)
             lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
-            out[mode] = json.loads(lines[-1]) if lines else {"value": None, "reason": (res.stderr or res.stdout)[-400:]}
+            out[key] = json.loads(lines[-1]) if lines else {"value": None, "reason": (res.stderr or res.stdout)[-400:]}
         except Exception as e:  # never sink the measurement
-            out[mode] = {"value": None, "reason": repr(e)}
+            out[key] = {"value": None, "reason": repr(e)}
     return out
 
 

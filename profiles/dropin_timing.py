@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--image-size", type=int, default=512)
+    ap.add_argument("--torus-div", type=float, default=1.0, help="1.0: SURVEY 8(d) config 3 as written (the bench headline); 1.5: the lighter batch of rounds 1-3")
     args = ap.parse_args()
     stage = os.path.join(ROOT, "oracle", "_ref", "reference_py")
     ref_root = None
@@ -70,7 +71,7 @@ def main():
     d = torch.device("cuda:0")
     B, H, K = args.batch, args.image_size, 8
     blur = math.log(1.0 / 1e-4 - 1.0) * 1e-4
-    verts, faces = U.hetero_batch(B, seed=0)
+    verts, faces = U.hetero_batch(B, seed=0, torus_div=args.torus_div)
     mesh0 = Meshes(verts=[v.to(d) for v in verts], faces=[f.to(d) for f in faces])
     V = int(mesh0.verts_packed().shape[0])
     deform = torch.zeros((V, 3), device=d, requires_grad=True)
@@ -102,7 +103,9 @@ def main():
     wall = (time.perf_counter() - t0) / args.steps * 1e3
     lib.p3d_profile_enable(0)
     kern = {k: round(ms / n * (n / args.steps), 4) for k, (n, ms) in sorted(_lib.profile_snapshot().items())}
-    out = {"mode": args.mode, "ms_per_step": wall, "Mpix_s": B * H * H / (wall * 1e-3) / 1e6, "steps": args.steps,
+    from pytorch3d_amd import _C as ours_C
+
+    out = {"mode": args.mode, "torus_div": args.torus_div, "cover_recalls_hit_miss": list(ours_C.COVER_RECALLS), "ms_per_step": wall, "Mpix_s": B * H * H / (wall * 1e-3) / 1e6, "steps": args.steps,
            "our_kernels_ms_per_step": kern, "our_kernels_sum_ms": round(sum(kern.values()), 4),
            "covered": float((frag.pix_to_face[..., 0] >= 0).float().mean()),
            "grad_finite": bool(torch.isfinite(deform.grad).all()),

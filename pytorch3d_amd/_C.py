@@ -111,10 +111,57 @@ def _mesh_outputs(N, H, W, K, device):
 def rasterize_meshes(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, image_size,
                      blur_radius, faces_per_pixel, bin_size, max_faces_per_bin, perspective_correct,
                      clip_barycentric_coords, cull_backfaces):
-    """RasterizeMeshes, rasterize_meshes.h:513-562.  Returns (pix_to_face, zbuf, bary, dists)."""
-    return _rasterize_meshes_covered(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx,
-                                     image_size, blur_radius, faces_per_pixel, bin_size, max_faces_per_bin, perspective_correct,
-                                     clip_barycentric_coords, cull_backfaces, want_cover=False)[0]
+    """RasterizeMeshes, rasterize_meshes.h:513-562.  Returns (pix_to_face, zbuf, bary, dists).
+
+    The row cover of the output (include/p3d_amd.h: p3d_rasterize_meshes_with_cover) is written as well and remembered for the
+    pix_to_face tensor returned here (_remember_cover): the reference's autograd node hands that very tensor to
+    `rasterize_meshes_backward` (renderer/mesh/rasterize_meshes.py:312-357), which then walks only the rows that hold a face --
+    the operator signatures stay the reference's."""
+    out, cover = _rasterize_meshes_covered(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx,
+                                           image_size, blur_radius, faces_per_pixel, bin_size, max_faces_per_bin, perspective_correct,
+                                           clip_barycentric_coords, cull_backfaces, want_cover=True)
+    if cover is not None:
+        _remember_cover(out[0], cover)
+    return out
+
+
+# pix_to_face tensors returned by rasterize_meshes -> their row covers, for as long as the tensor OBJECT lives.  Keyed by the
+# memory the tensor occupies; an entry is used only if the tensor that was returned is still alive (so the memory cannot have
+# been handed to anybody else), has not been written in place since (version counter), and the argument of the backward is a
+# contiguous tensor of the same shape at the same address.  Anything else: no cover, the backward reads every row.
+_COVERS = {}
+_COVERS_MAX = 64
+COVER_RECALLS = [0, 0]  # backward calls without an explicit cover: [found the forward's, found none] (read by tests / profiles)
+
+
+def _cover_key(t):
+    return (t.device.index, t.data_ptr(), tuple(t.shape))
+
+
+def _remember_cover(p2f, cover):
+    import weakref
+
+    key = _cover_key(p2f)
+
+    def drop(_ref, key=key):
+        e = _COVERS.get(key)
+        if e is not None and e[0] is _ref:
+            del _COVERS[key]
+
+    if len(_COVERS) >= _COVERS_MAX:
+        for k in list(_COVERS)[: _COVERS_MAX // 2]:
+            _COVERS.pop(k, None)
+    _COVERS[key] = (weakref.ref(p2f, drop), p2f._version, cover)
+
+
+def _recall_cover(p2f):
+    e = _COVERS.get(_cover_key(p2f)) if p2f.dtype == torch.int64 and p2f.is_contiguous() else None
+    alive = e[0]() if e is not None else None
+    if alive is None or p2f._version != e[1] or alive._version != e[1]:
+        COVER_RECALLS[1] += 1
+        return None
+    COVER_RECALLS[0] += 1
+    return e[2]
 
 
 def _rasterize_meshes_covered(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, image_size,
@@ -248,6 +295,8 @@ def rasterize_meshes_backward(face_verts, pix_to_face, grad_zbuf, grad_bary, gra
     if torch.are_deterministic_algorithms_enabled() and not torch.is_deterministic_algorithms_warn_only_enabled():
         raise RuntimeError("RasterizeMeshesBackwardCuda does not have a deterministic implementation")
     fv = _c(face_verts, torch.float32)
+    if _cover is None:
+        _cover = _recall_cover(pix_to_face)  # the forward of this very tensor left its row cover (see rasterize_meshes)
     p2f = _c(pix_to_face, torch.int64)
     gz, gb, gd = _c(grad_zbuf, torch.float32), _c(grad_bary, torch.float32), _c(grad_dists, torch.float32)
     N, H, W, K = p2f.shape

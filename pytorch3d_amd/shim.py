@@ -26,6 +26,8 @@ reference classes runs on them end to end:
     renderer.blending.softmax_rgb_blend / hard_rgb_blend      -> csrc/blend.hip
     renderer.mesh.shading.phong_shading / flat_shading / gouraud_shading -> csrc/shade.hip (+ interp.hip)
     renderer.mesh.textures.TexturesUV / TexturesAtlas .sample_textures   -> csrc/texture*.hip, atlas.hip
+    structures.meshes.Meshes.offset_verts / offset_verts_     -> one add on the packed vertices, topology shared, no host sync
+                                                                 (the reference re-runs Meshes.__init__: ~70 syncs per call)
 
 Every replacement falls back to the reference's own function for inputs the fused kernels do not cover (CPU tensors,
 colour widths other than 3, light classes other than Point / Directional / Ambient, padding modes grid_sample has and
@@ -261,6 +263,44 @@ def patch_reference_python():
 
     _patch_mesh_rasterizer(our_rm)
     _patch_soft_phong_shader(our_shade)
+    _patch_meshes_offset_verts()
+
+
+def camera_matrices(cameras, kwargs):
+    """(world -> view, view -> NDC, is_perspective, min znear or None) of `cameras`, or None when they have no matrix form.
+    Building them is ~25 small torch launches plus a host sync for znear (`.min().item()`): cached on the camera object
+    under a fingerprint of its parameters -- (name, object, in-place version counter) of every tensor attribute, the value of
+    every plain one -- whenever the call overrides none of them (kwargs holds nothing but the two objects themselves).
+    A new tensor assigned to an attribute, an in-place edit of one, or a different scalar all change the fingerprint."""
+    import importlib
+
+    import torch
+
+    cam_utils = importlib.import_module("pytorch3d.renderer.cameras")
+    cacheable = all(k in ("cameras", "raster_settings") for k in kwargs)
+    fp = None
+    if cacheable:
+        # (the fingerprint holds the tensor OBJECTS, compared by identity: an id() alone could be reused by a new tensor)
+        fp = tuple((k, v, v._version) if torch.is_tensor(v) else (k, v, None) for k, v in vars(cameras).items()
+                   if not k.startswith("_p3d_amd") and (torch.is_tensor(v) or isinstance(v, (bool, int, float, str, tuple, type(None)))))
+        hit = cameras.__dict__.get("_p3d_amd_matrices")
+        if hit is not None and len(hit[0]) == len(fp) and all(
+                a[0] == b[0] and a[2] == b[2] and (a[1] is b[1] if torch.is_tensor(a[1]) or torch.is_tensor(b[1]) else a[1] == b[1])
+                for a, b in zip(hit[0], fp)):
+            return hit[1]
+    w2v = cameras.get_world_to_view_transform(**kwargs).get_matrix()
+    proj = cam_utils.try_get_projection_transform(cameras, kwargs)
+    out = None
+    if proj is not None:
+        v2n = proj.compose(cameras.get_ndc_camera_transform(**kwargs)).get_matrix()
+        znear = cameras.get_znear()
+        if isinstance(znear, torch.Tensor):
+            znear = znear.min().item()
+        out = (w2v, v2n, bool(cameras.is_perspective()), znear)
+    if cacheable and not (out is not None and (out[0].requires_grad or out[1].requires_grad)):
+        cameras.__dict__["_p3d_amd_matrices"] = (fp, out)
+    return out
+
 
 
 def _patch_mesh_rasterizer(our_rm):
@@ -286,11 +326,10 @@ def _patch_mesh_rasterizer(our_rm):
                 verts = meshes_world.verts_packed()
                 ok = _is_hip_f32(verts) and meshes_world.faces_packed().is_cuda and len(cameras) in (1, len(meshes_world))
                 if ok:
-                    w2v = cameras.get_world_to_view_transform(**kwargs).get_matrix()
-                    proj = cam_utils.try_get_projection_transform(cameras, kwargs)
-                    ok = proj is not None
+                    cm = camera_matrices(cameras, kwargs)
+                    ok = cm is not None
                     if ok:
-                        v2n = proj.compose(cameras.get_ndc_camera_transform(**kwargs)).get_matrix()
+                        w2v, v2n, cam_persp, znear = cm
                         ok = not (w2v.requires_grad or v2n.requires_grad) and w2v.device == verts.device
             except Exception:
                 ok = False
@@ -301,13 +340,10 @@ def _patch_mesh_rasterizer(our_rm):
         clip_bary = rs.clip_barycentric_coords
         if clip_bary is None:
             clip_bary = rs.blur_radius > 0.0
-        persp = rs.perspective_correct if rs.perspective_correct is not None else cameras.is_perspective()
+        persp = rs.perspective_correct if rs.perspective_correct is not None else cam_persp
         if rs.z_clip_value is not None:
             z_clip = rs.z_clip_value
         else:
-            znear = cameras.get_znear()
-            if isinstance(znear, torch.Tensor):
-                znear = znear.min().item()
             z_clip = None if not persp or znear is None else znear / 2
         ndc = our_rm.transform_verts_to_ndc(meshes_world, w2v, v2n)
         p2f, zbuf, bary, dists = our_rm.rasterize_meshes(
@@ -363,6 +399,86 @@ def _patch_soft_phong_shader(our_shade):
     forward.__wrapped__ = orig
     shader.SoftPhongShader.forward = forward
     _PATCHED.append((shader.SoftPhongShader, "forward", orig, forward))
+
+
+def _patch_meshes_offset_verts():
+    """Meshes.offset_verts / offset_verts_ (structures/meshes.py:1295-1360), what every mesh-fitting loop of the reference's
+    tutorials calls once per step.  The reference clones the whole object -- `clone()` re-runs `Meshes.__init__` on lists
+    (per mesh a boolean-mask index of the faces = one host sync each, `int(max())` and `unique()` syncs) and clones ~20
+    internal tensors -- and then reads `num_verts_per_mesh().tolist()` from the device: ~4.5 ms of CPU and ~70 syncs per
+    call on the 64-mesh bench batch, twice the rasterizer's forward + backward, and the syncs keep the CPU from ever running
+    ahead of the GPU (profiles/r03/dropin_breakdown.py).  Here: one elementwise add on the packed vertices; the new object
+    SHARES every topology tensor and cache of the old one (faces, packed / padded indices, edges, Laplacian -- none of them
+    depends on the vertex positions and the Meshes API has no in-place edit of them; the reference would hand out clones),
+    its vertex list is 64 views of the new packed tensor split by sizes kept on the host, the padded vertices are dropped
+    (recomputed lazily by `verts_padded()`), face areas / normals and vertex normals are recomputed if and only if the
+    original had them, as the reference does, and textures are cloned as `clone()` clones them.  Falls back to the
+    reference's method for empty meshes and offsets of another dtype / device / shape."""
+    import importlib
+
+    import torch
+
+    meshes_mod = importlib.import_module("pytorch3d.structures.meshes")
+    Meshes = meshes_mod.Meshes
+    orig = Meshes.offset_verts
+    orig_ = Meshes.offset_verts_
+
+    def usable(self, off):
+        v = self.verts_packed()
+        return (torch.is_tensor(off) and self._N > 0 and not self.isempty() and v.dtype == torch.float32 and off.device == v.device
+                and off.dtype == torch.float32 and (off.shape == v.shape or tuple(off.shape) == (3,)))
+
+    def host_sizes(self):
+        sizes = self.__dict__.get("_p3d_amd_num_verts")
+        if sizes is None:
+            sizes = self.num_verts_per_mesh().tolist()  # once per topology: the copies made below inherit it
+            self.__dict__["_p3d_amd_num_verts"] = sizes
+        return sizes
+
+    def apply(dst, src, off):
+        update_normals = tuple(off.shape) != (3,)
+        dst._verts_packed = src.verts_packed() + off
+        dst._verts_list = list(dst._verts_packed.split(host_sizes(src), 0))
+        dst._verts_padded = None
+        if update_normals and (src._faces_areas_packed is not None or src._faces_normals_packed is not None):
+            dst._compute_face_areas_normals(refresh=True)
+        if update_normals and src._verts_normals_packed is not None:
+            dst._compute_vertex_normals(refresh=True)
+        return dst
+
+    def offset_verts(self, vert_offsets_packed):
+        ok = False
+        try:
+            ok = usable(self, vert_offsets_packed)
+        except Exception:
+            ok = False
+        _count("Meshes.offset_verts", ok)
+        if not ok:
+            return orig(self, vert_offsets_packed)
+        self.verts_list(), self.faces_list()  # the lists exist before they are shared (meshes built from padded tensors)
+        new = object.__new__(type(self))
+        new.__dict__.update(self.__dict__)
+        if self.textures is not None:
+            new.textures = self.textures.clone()
+        return apply(new, self, vert_offsets_packed)
+
+    def offset_verts_(self, vert_offsets_packed):
+        ok = False
+        try:
+            ok = usable(self, vert_offsets_packed)
+        except Exception:
+            ok = False
+        _count("Meshes.offset_verts_", ok)
+        if not ok:
+            return orig_(self, vert_offsets_packed)
+        return apply(self, self, vert_offsets_packed)
+
+    offset_verts.__wrapped__ = orig
+    offset_verts_.__wrapped__ = orig_
+    Meshes.offset_verts = offset_verts
+    Meshes.offset_verts_ = offset_verts_
+    _PATCHED.append((Meshes, "offset_verts", orig, offset_verts))
+    _PATCHED.append((Meshes, "offset_verts_", orig_, offset_verts_))
 
 
 def uninstall_python_patches():

@@ -112,9 +112,11 @@ def _stub_missing_packages():
                 setattr(sys.modules[parent], child, m)
 
 
-def _device_routed_C():
+def _device_routed_C(hip_from_reference=None):
     """`pytorch3d._C` for the reference's tests: HIP tensors -> pytorch3d_amd, CPU tensors -> the reference's own CPU
-    build (oracle/_ref/p3d_ref_cpu.so)."""
+    build (oracle/_ref/p3d_ref_cpu.so).  hip_from_reference ("fma" | "nofma"): HIP tensors go to the reference's OWN device
+    kernels instead (oracle/_ref/p3d_ref_hip[_nofma].so, the hipified .cu files: oracle/build_ref_hip.py) wherever that
+    build has the operator -- the control run that says what the reference's tests do on the reference's code on this GPU."""
     import torch
 
     import pytorch3d_amd.shim as shim
@@ -145,8 +147,29 @@ def _device_routed_C():
 
     from pytorch3d_amd import _C as ours_C
 
+    ref_hip = None
+    if hip_from_reference:
+        so = os.path.join(ROOT, "oracle", "_ref", "p3d_ref_hip_nofma.so" if hip_from_reference == "nofma" else "p3d_ref_hip.so")
+        if not os.path.exists(so):
+            raise SystemExit(f"{so}: the reference's device build is missing (oracle/build_ref_hip.py, build container)")
+        spec = importlib.util.spec_from_file_location(os.path.basename(so)[:-3], so)
+        ref_hip = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref_hip)
+        counts["ref_hip"] = {}
+
+    def route_hip(name, ours):
+        theirs = getattr(ref_hip, name, None) if ref_hip is not None else None
+        if theirs is None:
+            return ours
+
+        def call(*args, **kwargs):
+            counts["ref_hip"][name] = counts["ref_hip"].get(name, 0) + 1
+            return theirs(*args, **kwargs)
+
+        return call
+
     for name in ours_C.HOT_PATH_EXPORTS:
-        setattr(mod, name, route(name, getattr(ours_C, name)))
+        setattr(mod, name, route(name, route_hip(name, getattr(ours_C, name))))
 
     # The four small operators above the boundary (face areas / normals, packed <-> padded; pytorch3d_amd/_aux_ops.py):
     # HIP tensors -> our torch formulations, CPU tensors -> the reference's CPU kernels, like everything else.
@@ -205,6 +228,8 @@ def main():
                     help="also replace the reference's torch formulations around the operators (clip_faces, softmax_rgb_blend, "
                          "phong_shading, TexturesUV.sample_textures, the face gather ...) with the fused HIP versions "
                          "(pytorch3d_amd.shim.patch_reference_python)")
+    ap.add_argument("--hip-from-reference", choices=["fma", "nofma"], default=None,
+                    help="control run: HIP tensors go to the reference's own device kernels (oracle/_ref/p3d_ref_hip[_nofma].so)")
     args = ap.parse_args()
     if not os.path.isdir(os.path.join(args.stage, "pytorch3d")):
         raise SystemExit(f"{args.stage}: the reference is not staged (run oracle/stage_reference.py in the build container)")
@@ -214,7 +239,7 @@ def main():
             sys.path.insert(0, p)
     _stub_missing_packages()
     warnings.filterwarnings("ignore")
-    mod, counts = _device_routed_C()
+    mod, counts = _device_routed_C(args.hip_from_reference)
     sys.modules["pytorch3d._C"] = mod
     import pytorch3d
 

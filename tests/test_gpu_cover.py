@@ -140,3 +140,52 @@ def test_autograd_function_carries_the_cover():
                                                                        accumulate=True)
     got = torch.cat([v.grad for v in vg])
     assert torch.allclose(got, want, rtol=1e-3, atol=1e-5 * want.abs().max().item())
+
+
+def test_the_reference_style_backward_call_finds_the_cover_of_its_pix_to_face():
+    """`_C.rasterize_meshes` remembers the row cover of the pix_to_face tensor it returns; `_C.rasterize_meshes_backward` called
+    the way the reference's autograd node calls it (no cover argument, renderer/mesh/rasterize_meshes.py:334-357) finds it as
+    long as that tensor object lives and was not written to -- and never for a copy, a written tensor, or another shape."""
+    from pytorch3d_amd import _C
+
+    d = torch.device("cuda:0")
+    _, fv, first, cnt = _batch(3, 5)
+    nbr = torch.full((fv.shape[0],), -1, dtype=torch.int64, device=d)
+    size, K = (96, 80), 8
+    out = _C.rasterize_meshes(fv, first, cnt, nbr, size, 1e-3, K, 32, 5000, True, True, False)
+    gen = torch.Generator().manual_seed(3)
+    gz, gd = (torch.randn(out[1].shape, generator=gen).to(d) for _ in range(2))
+    gb = torch.randn(out[2].shape, generator=gen).to(d)
+    _, cover = _C._rasterize_meshes_covered(fv, first, cnt, nbr, size, 1e-3, K, 32, 5000, True, True, False)
+    want = _C.rasterize_meshes_backward(fv, out[0].clone(), gz, gb, gd, True, True)  # a copy: no cover (counted as a miss)
+    hits, misses = _C.COVER_RECALLS
+    got = _C.rasterize_meshes_backward(fv, out[0], gz, gb, gd, True, True)
+    assert _C.COVER_RECALLS == [hits + 1, misses]
+    assert torch.equal(_C._recall_cover(out[0]), cover)
+    scale = want.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1e-6)
+    assert float(((got - want).abs() / scale).max()) < 5e-3  # (atomics: the accumulation order differs)
+    # saved-for-backward round trip, as the reference's node does it
+    class Node(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            o = _C.rasterize_meshes(x, first, cnt, nbr, size, 1e-3, K, 32, 5000, True, True, False)
+            ctx.save_for_backward(x, o[0])
+            ctx.mark_non_differentiable(o[0])
+            return o
+
+        @staticmethod
+        def backward(ctx, g0, g1, g2, g3):
+            x, p2f = ctx.saved_tensors
+            return _C.rasterize_meshes_backward(x, p2f, g1, g2, g3, True, True)
+
+    x = fv.clone().requires_grad_(True)
+    o = Node.apply(x)
+    hits, misses = _C.COVER_RECALLS
+    torch.autograd.backward([o[1], o[2], o[3]], [gz, gb, gd])
+    assert _C.COVER_RECALLS == [hits + 1, misses], "the autograd round trip lost the cover"
+    assert float(((x.grad - want).abs() / scale).max()) < 5e-3
+    # written in place -> the cover is no longer trusted
+    out[0][0, 0, 0, 0] = out[0][0, 0, 0, 0]
+    hits, misses = _C.COVER_RECALLS
+    _C.rasterize_meshes_backward(fv, out[0], gz, gb, gd, True, True)
+    assert _C.COVER_RECALLS == [hits, misses + 1]

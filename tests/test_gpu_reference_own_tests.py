@@ -118,3 +118,31 @@ def test_reference_renderer_test_modules_on_the_hip_kernels(report):
         print("   known:", k)
     assert not unexpected, unexpected
     assert passed >= 30
+
+
+def test_known_rectangle_cases_on_the_references_own_device_build():
+    """the two `test_gpu` cases of test_rasterize_rectangle_images.py (:380, :729) listed in KNOWN, run with
+    `pytorch3d._C` = the reference's OWN device kernels (oracle/_ref/p3d_ref_hip.so, hipcc defaults = what a user of the
+    reference on this GPU would have; and the -ffp-contract=off build) next to ours.  A KNOWN entry is only legitimate if the
+    reference's own code fails the case on this GPU too: `ours fails while the reference passes` is an error here."""
+    if not os.path.isdir(os.path.join(STAGE, "pytorch3d", "renderer")):
+        pytest.skip("oracle/_ref/reference_py is not staged")
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "p3d_ref_hip.so")):
+        pytest.skip("oracle/_ref/p3d_ref_hip.so not built (oracle/build_ref_hip.py, build container only)")
+    table = {}
+    for who, extra in (("ours", []), ("reference_fma", ["--hip-from-reference", "fma"]), ("reference_nofma", ["--hip-from-reference", "nofma"])):
+        out = os.path.join(ROOT, "gpurun_out", f"ref_suite_rectangle_{who}.json")
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "run_reference_suite.py"), "--out", out, "-k", "test_gpu"] + extra +
+                             ["test_rasterize_rectangle_images"], capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stderr[-3000:]
+        rep = json.load(open(out))["test_rasterize_rectangle_images"]
+        for tid, r in rep.items():
+            last = r["msg"].strip().splitlines()[-1][:160] if r["msg"].strip() else ""
+            table.setdefault(tid.split(".", 2)[-1], {})[who] = (r["outcome"], last)
+    bad = []
+    for tid, row in sorted(table.items()):
+        print(f"[rectangle control] {tid}: " + "; ".join(f"{w}: {o}" + (f" ({m})" if o != "pass" else "") for w, (o, m) in sorted(row.items())))
+        if row["ours"][0] != "pass" and row["reference_fma"][0] == "pass" and row["reference_nofma"][0] == "pass":
+            bad.append(tid)
+    assert len(table) >= 2
+    assert not bad, f"cases the reference's own device code passes on this GPU and ours does not: {bad}"
