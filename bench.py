@@ -58,9 +58,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the timing of the unmodified reference MeshRasterizer through the shim")
-    ap.add_argument("--cpu-budget-s", type=float, default=45.0,
+    ap.add_argument("--cpu-budget-s", type=float, default=110.0,
                     help="wall-clock bound for the CPU baseline legs (the Python reference takes ~31 s of it; the C++ kernels then "
-                         "run at least two meshes of the subset: ~20 s of CPU work each, the backward single-threaded)")
+                         "run as many meshes of the seeded 8-mesh subset as fit, smallest / largest / middle first, at least "
+                         "two: ~10-30 s of CPU work each, the backward single-threaded)")
     return ap.parse_args()
 
 
@@ -102,7 +103,15 @@ def cpu_baseline(verts, faces, H, W, K, blur, budget_s):
     py = python_reference_baseline(orc)
     ref = orc.ref_module()
     kind = "reference" if ref is not None else "port"
-    order = torch.randperm(len(faces), generator=torch.Generator().manual_seed(0)).tolist()[:8]
+    subset = torch.randperm(len(faces), generator=torch.Generator().manual_seed(0)).tolist()[:8]
+    # visiting order inside the subset: smallest, largest, then towards the middle -- whatever part of it the budget admits
+    # spans the 1k-20k range instead of sitting on two mid-sized meshes
+    by_size = sorted(subset, key=lambda j: faces[j].shape[0])
+    order = []
+    while by_size:
+        order.append(by_size.pop(0))
+        if by_size:
+            order.append(by_size.pop(-1))
     gen = torch.Generator().manual_seed(231)
     done, px, t_fwd, t_bwd, nf = 0, 0, 0.0, 0.0, []
     for j in order:
@@ -138,7 +147,7 @@ def cpu_baseline(verts, faces, H, W, K, blur, budget_s):
         "unit": "Mpix/s",
         "cores": cores,
         "kind": kind,
-        "sample": f"{done} of the seeded 8-mesh subset (randperm seed 0) of the batch, faces {nf}, {H}x{W}, K={K}, "
+        "sample": f"{done} of the seeded 8-mesh subset (randperm seed 0; visited smallest / largest / inwards) of the batch, faces {nf}, {H}x{W}, K={K}, "
                   f"naive fwd {t_fwd:.1f} s (multi-threaded over rows, {cores} threads) + bwd {t_bwd:.1f} s (single-threaded, "
                   "as the reference CPU path is); batch of 64 = this x 8",
         "python_reference": py,
@@ -294,7 +303,7 @@ def spawn_ranks(args):
 
     n = args.gpus
     have = torch.cuda.device_count()
-    if have < n and not os.environ.get("P3D_BENCH_TEST_BACKEND"):
+    if have < n and not (os.environ.get("P3D_BENCH_TEST_BACKEND") or os.environ.get("P3D_BENCH_SHARED_GPU")):
         raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -378,19 +387,41 @@ def main():
     # P3D_BENCH_TEST_BACKEND=gloo maps every rank to cuda:0 and uses gloo: lets the multi-rank code path (barriers,
     # max-over-ranks timing, final gather) be exercised on a single-GPU box.  Never set by the driver.
     test_backend = os.environ.get("P3D_BENCH_TEST_BACKEND")
-    if test_backend:
+    # P3D_BENCH_SHARED_GPU=1 (tests only): every rank on cuda:0 but the REAL backend choice -- RCCL refuses two ranks on one
+    # device, which is how the single-GPU box exercises the "nccl failed -> gloo" fallback below.
+    if test_backend or os.environ.get("P3D_BENCH_SHARED_GPU"):
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist_on = world > 1
+    backend, backend_note = None, None
     if dist_on:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if test_backend:
-            dist.init_process_group(test_backend, rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = test_backend or "nccl"
+        try:
+            if test_backend:
+                dist.init_process_group(test_backend, rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+                probe = torch.ones(1, device=device)
+                dist.all_reduce(probe)  # RCCL opens its communicator lazily: fail HERE, where every rank can still fall back alike
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"all_reduce over RCCL returned {probe.item()} for {world} ranks")
+        except Exception as e:  # RCCL unusable on this node (IPC mode, xGMI topology ...): keep the measurement, say so in the line
+            backend_note = f"nccl failed ({type(e).__name__}: {str(e)[:300]}); barriers, timing and the final gather run over gloo (host memory)"
+            print(f"[bench rank {rank}] {backend_note}", file=sys.stderr, flush=True)
+            try:
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+            except Exception:
+                pass
+            port = int(os.environ.get("MASTER_PORT", "29500")) + 1
+            dist.init_process_group("gloo", init_method=f"tcp://{os.environ['MASTER_ADDR']}:{port}", rank=rank, world_size=world)
+            backend = "gloo"
+    comm_dev = device if backend == "nccl" else torch.device("cpu")  # where tensors of a collective have to live
 
     import pytorch3d_amd as p3d
     from pytorch3d_amd import _lib
@@ -432,13 +463,20 @@ def main():
 
     own = [B] * world if not jobs_mode else [B * steps] * world
 
+    gather_state = {"ok": True, "how": "gather to rank 0", "error": None}
+
     def final_gather(depths):
         # the one collective of the job: the final depth images of every rank are gathered on rank 0
-        shard = torch.cat([z[..., 0].detach() for z in depths], 0).contiguous()
+        shard = torch.cat([z[..., 0].detach() for z in depths], 0).contiguous().to(comm_dev)
         try:
             return sharding.gather_batch(shard, own, dst=0)
-        except (RuntimeError, NotImplementedError):  # a backend without gather: every rank raises alike
-            return sharding.gather_batch(shard, own)
+        except (RuntimeError, NotImplementedError) as e:  # a backend without gather: every rank raises alike
+            gather_state.update(how="all_gather (gather raised: %s)" % str(e)[:120])
+            try:
+                return sharding.gather_batch(shard, own)
+            except Exception as e2:  # reported, never fatal: the per-rank numbers are still worth having
+                gather_state.update(ok=False, how="none", error=f"{type(e2).__name__}: {str(e2)[:300]}")
+                return None
 
     for i in range(args.warmup):
         p2f, zbuf = step(i)
@@ -474,11 +512,22 @@ def main():
         dist.barrier()
     t1 = time.perf_counter()
     lib.p3d_profile_enable(0)
-    elapsed = torch.tensor([t1 - t0, gather_ms], dtype=torch.float64, device=device)
-    if dist_on:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed, gather_ms = float(elapsed[0].item()), float(elapsed[1].item())
     prof = _lib.profile_snapshot()
+    mine = torch.tensor([t1 - t0, gather_ms, (tg0 - t0) * 1e3 / max(steps, 1),
+                         prof.get("mesh_fine", (1, 0.0))[1] / max(prof.get("mesh_fine", (1, 0.0))[0], 1),
+                         prof.get("mesh_backward", (1, 0.0))[1] / max(prof.get("mesh_backward", (1, 0.0))[0], 1)],
+                        dtype=torch.float64, device=comm_dev)
+    per_rank = None
+    if dist_on:
+        # every rank's own clock: [seconds incl. gather, gather ms, compute ms per step, mesh_fine ms, mesh_backward ms]
+        rows = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(rows, mine)
+        per_rank = [{"rank": r, "seconds": float(x[0]), "gather_ms": float(x[1]), "compute_ms_per_step": float(x[2]),
+                     "mesh_fine_ms": float(x[3]), "mesh_backward_ms": float(x[4])} for r, x in enumerate(rows)]
+        elapsed = max(p["seconds"] for p in per_rank)  # MAX over ranks, as the contract asks
+        gather_ms = max(p["gather_ms"] for p in per_rank)
+    else:
+        elapsed, gather_ms = float(mine[0]), float(mine[1])
     per_step = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
     median_ms = per_step[len(per_step) // 2]
     valid = p2f >= 0
@@ -555,6 +604,8 @@ def main():
             "ms_per_step": elapsed / steps * 1e3,
             "ms_per_step_median": median_ms,
             "gather_ms": gather_ms,
+            "gather": dict(gather_state, backend=backend, backend_note=backend_note) if dist_on else None,
+            "per_rank": per_rank,
             "higher_is_better": True,
             "scaling": "strong" if jobs_mode else "weak",
             "vs_baseline": None,

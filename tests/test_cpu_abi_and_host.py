@@ -389,3 +389,24 @@ def test_no_kernel_of_the_library_spills_vgprs():
     assert not spilled, spilled
     scratch = sorted(B.demangle(k) for k, v in res.items() if v["scratch"] > 0)
     assert all("TopKMem" in k for k in scratch), scratch
+
+
+def test_bench_jobs_mode_deals_every_sub_batch_to_exactly_one_rank():
+    """BASELINE configs[4]: 512 jobs = 8 sub-batches of 64 (generator seeds 0..7); on G in
+    {1, 2, 4, 8} GPUs rank r runs sub-batches r, r + G, ...: every seed exactly once, the same number per rank (what the
+    padded gather of `own` sizes relies on), and a G that does not divide is refused rather than silently unbalanced."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(U.ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for world in (1, 2, 4, 8):
+        dealt = [bench.sub_batches_of_rank(512, 64, r, world) for r in range(world)]
+        assert sorted(s for d in dealt for s in d) == list(range(8))
+        assert len({len(d) for d in dealt}) == 1 and len(dealt[0]) == 8 // world
+        assert all(d == sorted(d) and d[0] == r for r, d in enumerate(dealt))
+    for world in (3, 5, 16):
+        with pytest.raises(SystemExit):
+            bench.sub_batches_of_rank(512, 64, 0, world)
+    with pytest.raises(SystemExit):
+        bench.sub_batches_of_rank(500, 64, 0, 2)
