@@ -387,8 +387,9 @@ def main():
     # P3D_BENCH_TEST_BACKEND=gloo maps every rank to cuda:0 and uses gloo: lets the multi-rank code path (barriers,
     # max-over-ranks timing, final gather) be exercised on a single-GPU box.  Never set by the driver.
     test_backend = os.environ.get("P3D_BENCH_TEST_BACKEND")
-    # P3D_BENCH_SHARED_GPU=1 (tests only): every rank on cuda:0 but the REAL backend choice -- RCCL refuses two ranks on one
-    # device, which is how the single-GPU box exercises the "nccl failed -> gloo" fallback below.
+    # P3D_BENCH_SHARED_GPU=1 (tests only, with P3D_BENCH_FAIL_NCCL=1): every rank on cuda:0 but the REAL backend choice, so that
+    # a single-GPU box exercises the "nccl failed -> gloo" fallback below.  (RCCL itself HANGS with two ranks on one device --
+    # measured in round 4, 900 s -- so the failure is injected, not provoked.)
     if test_backend or os.environ.get("P3D_BENCH_SHARED_GPU"):
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -404,6 +405,8 @@ def main():
             if test_backend:
                 dist.init_process_group(test_backend, rank=rank, world_size=world)
             else:
+                if os.environ.get("P3D_BENCH_FAIL_NCCL"):  # tests only: stands in for an RCCL that cannot be brought up
+                    raise RuntimeError("P3D_BENCH_FAIL_NCCL is set")
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
                 probe = torch.ones(1, device=device)
                 dist.all_reduce(probe)  # RCCL opens its communicator lazily: fail HERE, where every rank can still fall back alike
