@@ -26,6 +26,9 @@ reference classes runs on them end to end:
     renderer.blending.softmax_rgb_blend / hard_rgb_blend      -> csrc/blend.hip
     renderer.mesh.shading.phong_shading / flat_shading / gouraud_shading -> csrc/shade.hip (+ interp.hip)
     renderer.mesh.textures.TexturesUV / TexturesAtlas .sample_textures   -> csrc/texture*.hip, atlas.hip
+    renderer.mesh.shader.Hard{Phong,Gouraud,Flat}Shader.forward -> the shader sees the nearest slot only (hard_rgb_blend keeps
+                                                                 nothing else): 1 / K of the shading and texture work
+    renderer.mesh.shader.SoftSilhouetteShader.forward         -> no ones_like(bary_coords) (1.6 GB at the bench batch)
     structures.meshes.Meshes.offset_verts / offset_verts_     -> one add on the packed vertices, topology shared, no host sync
                                                                  (the reference re-runs Meshes.__init__: ~70 syncs per call)
 
@@ -264,6 +267,7 @@ def patch_reference_python():
     _patch_mesh_rasterizer(our_rm)
     _patch_soft_phong_shader(our_shade)
     _patch_meshes_offset_verts()
+    _patch_hard_and_silhouette_shaders()
 
 
 def camera_matrices(cameras, kwargs):
@@ -399,6 +403,72 @@ def _patch_soft_phong_shader(our_shade):
     forward.__wrapped__ = orig
     shader.SoftPhongShader.forward = forward
     _PATCHED.append((shader.SoftPhongShader, "forward", orig, forward))
+
+
+def _patch_hard_and_silhouette_shaders():
+    """HardPhongShader / HardGouraudShader / HardFlatShader (shader.py:81-112, 150-185, 245-275) shade and texture ALL K slots of
+    every pixel and then `hard_rgb_blend` keeps slot 0 (blending.py:54-88: `pix_to_face[..., 0]`, `colors[..., 0, :]`): K - 1 of K
+    samples are computed, stored and differentiated for nothing.  Here the shader sees the fragments cut to their nearest slot
+    (contiguous copies of 1 / K of the data; autograd routes the gradient back into slot 0 of the originals, the other slots
+    get the zeros the reference's blend gives them) -- same image, same gradients, 1 / K of the shading and texture work.
+    SoftSilhouetteShader (shader.py:277-300) materialises `torch.ones_like(bary_coords)` -- 1.6 GB at the bench batch -- to
+    read one constant pixel of it: a stride-0 view of a single 1 serves the reference's `sigmoid_alpha_blend` as well."""
+    import importlib
+
+    import torch
+
+    shader = importlib.import_module("pytorch3d.renderer.mesh.shader")
+    rz = importlib.import_module("pytorch3d.renderer.mesh.rasterizer")
+    blend = importlib.import_module("pytorch3d.renderer.blending")
+
+    def nearest_slot(orig, name):
+        def forward(self, fragments, meshes, **kwargs):
+            ok = False
+            try:
+                p2f = fragments.pix_to_face
+                ok = torch.is_tensor(p2f) and p2f.dim() == 4 and p2f.shape[3] > 1 and torch.is_tensor(fragments.bary_coords)
+            except Exception:
+                ok = False
+            _count(name + ".forward", ok)
+            if not ok:
+                return orig(self, fragments, meshes, **kwargs)
+            first = rz.Fragments(pix_to_face=fragments.pix_to_face[..., :1].contiguous(), zbuf=fragments.zbuf[..., :1].contiguous(),
+                                 bary_coords=fragments.bary_coords[..., :1, :].contiguous(), dists=fragments.dists[..., :1].contiguous())
+            return orig(self, first, meshes, **kwargs)
+
+        forward.__wrapped__ = orig
+        return forward
+
+    for cls_name in ("HardPhongShader", "HardGouraudShader", "HardFlatShader"):
+        cls = getattr(shader, cls_name, None)
+        if cls is None:
+            continue
+        orig = cls.forward
+        new = nearest_slot(orig, cls_name)
+        cls.forward = new
+        _PATCHED.append((cls, "forward", orig, new))
+
+    sil = getattr(shader, "SoftSilhouetteShader", None)
+    if sil is not None:
+        sil_orig = sil.forward
+
+        def sil_forward(self, fragments, meshes, **kwargs):
+            ok = False
+            try:
+                ok = torch.is_tensor(fragments.bary_coords) and fragments.bary_coords.dim() == 5
+            except Exception:
+                ok = False
+            _count("SoftSilhouetteShader.forward", ok)
+            if not ok:
+                return sil_orig(self, fragments, meshes, **kwargs)
+            b = fragments.bary_coords
+            colors = torch.ones((1, 1, 1, 1, 1), dtype=b.dtype, device=b.device).expand(b.shape)  # shader.py:154 without the 12 K bytes per pixel
+            blend_params = kwargs.get("blend_params", self.blend_params)
+            return blend.sigmoid_alpha_blend(colors, fragments, blend_params)
+
+        sil_forward.__wrapped__ = sil_orig
+        sil.forward = sil_forward
+        _PATCHED.append((sil, "forward", sil_orig, sil_forward))
 
 
 def _patch_meshes_offset_verts():

@@ -141,8 +141,41 @@ SCRIPT = textwrap.dedent("""
     cg = FoVPerspectiveCameras(R=R, T=Tg)
     g1 = shim.camera_matrices(cg, {})
     assert g1[0].requires_grad and shim.camera_matrices(cg, {}) is not g1
+    # ---- hard shaders on the nearest slot only: same image, same gradients as the reference's all-K evaluation ----
+    from pytorch3d.renderer import HardPhongShader, HardGouraudShader, HardFlatShader, PointLights
+    from pytorch3d.renderer.mesh.rasterizer import Fragments
+    import pytorch3d.renderer.mesh.shader as shader_mod
+    originals = {n: getattr(shader_mod, n).forward for n in ("HardPhongShader", "HardGouraudShader", "HardFlatShader")}
+    shim._patch_hard_and_silhouette_shaders()
+    m = batch()
+    Fn = m.faces_packed().shape[0]
+    g2 = torch.Generator().manual_seed(5)
+    N, H, W, K = len(m), 9, 11, 4
+    p2f = torch.randint(-1, Fn, (N, H, W, K), generator=g2)
+    p2f[:, :2] = -1  # background rows
+    bary = torch.rand(N, H, W, K, 3, generator=g2)
+    bary = bary / bary.sum(-1, keepdim=True)
+    zbuf, dists = torch.rand(N, H, W, K, generator=g2) + 1.0, torch.rand(N, H, W, K, generator=g2) * 1e-3
+    cams1 = FoVPerspectiveCameras(R=R[:1], T=T[:1])
+    lights = PointLights(location=[[0.0, 1.0, -2.0]])
+    gout = torch.randn(N, H, W, 4, generator=g2)
+    for name, cls in (("HardPhongShader", HardPhongShader), ("HardGouraudShader", HardGouraudShader), ("HardFlatShader", HardFlatShader)):
+        res = []
+        for fwd in (cls.forward, originals[name]):
+            b = bary.clone().requires_grad_(True)
+            vcol = m.textures.verts_features_packed().clone().requires_grad_(True)
+            mm = Meshes(verts=m.verts_list(), faces=m.faces_list(), textures=TexturesVertex(list(vcol.split(m.num_verts_per_mesh().tolist()))))
+            sh = cls(cameras=cams1, lights=lights)
+            img = fwd(sh, Fragments(pix_to_face=p2f, zbuf=zbuf, bary_coords=b, dists=dists), mm)
+            (img * gout).sum().backward()
+            res.append((img.detach(), b.grad.clone(), vcol.grad.clone()))
+        for x, y in zip(res[0], res[1]):
+            assert torch.equal(x, y) or torch.allclose(x, y, atol=1e-6, rtol=1e-5), (name, float((x - y).abs().max()))
+        assert float(res[0][1][..., 1:, :].abs().max()) == 0.0  # slots behind the nearest get no gradient, as in the reference
+        assert shim.PATCH_CALLS[name + ".forward"][0] >= 1
     shim.uninstall_python_patches()
     assert Meshes.offset_verts is ref_offset and Meshes.offset_verts_ is ref_offset_
+    assert all(getattr(shader_mod, n).forward is f for n, f in originals.items())
     print("HOST-PATCHES-OK")
 """)
 
