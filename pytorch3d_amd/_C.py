@@ -89,7 +89,20 @@ def _num_bins(H, W, bin_size, who):
 
 
 def _workspace(nbytes, device):
-    return torch.empty((max(int(nbytes), 256),), dtype=torch.uint8, device=device)
+    """Scratch for the coarse stage.  The C ABI sizes it for the worst case (every primitive in every bin, capped by
+    max_faces_per_bin: include/p3d_amd.h) because sizing it exactly would need a host sync; only the used prefix is touched.
+    1.3 GB at the bench batch, 42 GB for 512 meshes in one call: a request the allocator cannot serve is reported with what to
+    do about it instead of as a bare out-of-memory error."""
+    n = max(int(nbytes), 256)
+    try:
+        return torch.empty((n,), dtype=torch.uint8, device=device)
+    except RuntimeError as e:  # torch.OutOfMemoryError is a RuntimeError
+        if "out of memory" not in str(e).lower():
+            raise
+        raise RuntimeError(f"the coarse stage's worst-case workspace of {n / 2**30:.1f} GiB does not fit on {device}: rasterize the "
+                           "batch in smaller pieces (pytorch3d_amd.sharding.partition, or bench.py --jobs style sub-batches of 64 "
+                           "meshes) or pass a smaller max_faces_per_bin (the workspace is capped by N * bins * max_faces_per_bin * 4 "
+                           "bytes)") from e
 
 
 # ----------------------------------------------------------------------------------------------

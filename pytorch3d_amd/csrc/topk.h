@@ -477,7 +477,13 @@ struct TopKPairs {
   }
 };
 
-// the queue a kernel with compile-time perspective-correct + clipped barycentrics may use in place of Q
+// the queue a kernel with compile-time perspective-correct + clipped barycentrics may use in place of Q.
+// Why the 64-bit key order is safe there without canonicalising -0.0: the depth of a sample is
+// bc.x * z0 + bc.y * z1 + bc.z * z2 with clipped barycentrics bc >= +0 (max(b, 0) / s, s >= 1e-5 > 0) and vertex depths
+// z >= 1e-8: a face with a vertex depth below 1e-8 -- zero and negative zero included -- never reaches a queue
+// (p3d_geom.h: face_setup, `z_invalid`, the reference's rasterize_meshes.cu:147 `zmin < kEpsilon`).  Products of a value
+// >= +0 with a positive one are >= +0, and so is their sum in round-to-nearest: the bit pattern of z orders like z.
+// (The point rasterizer, whose depths may be exactly zero of either sign, adds +0.0f when it stages them.)
 template <typename Q>
 struct PcQueue {
   typedef Q type;

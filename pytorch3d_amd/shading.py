@@ -113,6 +113,7 @@ class _PhongShade(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_colors):
+        _refuse_when_deterministic("phong_shading backward")
         p2f, b, fa, tx, params = ctx.saved_tensors
         N, H, W, K = p2f.shape
         F, _, D = fa.shape
@@ -218,6 +219,15 @@ def gouraud_shading(meshes, fragments, lights, cameras, materials, verts_colors_
 # ---------------------------------------------------------------------------------------------------------------------
 # SoftPhongShader in one kernel each way (csrc/soft_phong.hip): phong_shading + softmax_rgb_blend, the colours never in HBM
 # ---------------------------------------------------------------------------------------------------------------------
+def _refuse_when_deterministic(what):
+    """The shading backward kernels scatter to the face records (and light / material parameters) with float atomics: run to
+    run the sums differ in the last bits.  Under torch.use_deterministic_algorithms(True) that has to be said, as the
+    rasterizer's backward says it (rasterize_meshes.cu:587 alertNotDeterministic)."""
+    if torch.are_deterministic_algorithms_enabled() and not torch.is_deterministic_algorithms_warn_only_enabled():
+        raise RuntimeError(f"{what} does not have a deterministic implementation (float atomics); use the unfused torch "
+                           "formulation of the reference or torch.use_deterministic_algorithms(True, warn_only=True)")
+
+
 class _SoftPhong(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pix_to_face, bary, dists, zbuf, face_attrs, texels, params, kind, sigma, gamma, bg, znear, zfar):
@@ -248,6 +258,7 @@ class _SoftPhong(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        _refuse_when_deterministic("soft_phong_shading backward")
         p2f, b, d, z, fa, tx, params, zn_t, zf_t = ctx.saved_tensors
         kind, sigma, gamma, bg, zn, zf, has_tx, has_zn, has_zf = ctx.meta
         N, H, W, K = p2f.shape

@@ -370,6 +370,8 @@ def _patch_soft_phong_shader(our_shade):
     import importlib
 
     shader = importlib.import_module("pytorch3d.renderer.mesh.shader")
+    shading_mod = importlib.import_module("pytorch3d.renderer.mesh.shading")
+    blend_mod = importlib.import_module("pytorch3d.renderer.blending")
     orig = shader.SoftPhongShader.forward
 
     def forward(self, fragments, meshes, **kwargs):
@@ -383,9 +385,9 @@ def _patch_soft_phong_shader(our_shade):
                   and not getattr(blend_params.background_color, "requires_grad", False))
         except Exception:
             ok = False
+        vcol = texels = None
         if ok:
             tex = getattr(meshes, "textures", None)
-            vcol = texels = None
             if type(tex).__name__ == "TexturesVertex" and tex.verts_features_packed().shape[-1] == 3:
                 vcol = tex.verts_features_packed()
                 ok = _is_hip_f32(vcol)
@@ -394,6 +396,13 @@ def _patch_soft_phong_shader(our_shade):
                 ok = _is_hip_f32(texels) and texels.dim() == 5 and texels.shape[-1] == 3
         _count("SoftPhongShader.forward", ok)
         if not ok:
+            if texels is not None:
+                # the textures were sampled for the probe and turned out not to fit the fused kernel (channels, dtype): finish the
+                # reference's own forward with them (shader.py:131-146) instead of letting it sample them a second time
+                colors = shading_mod.phong_shading(meshes=meshes, fragments=fragments, texels=texels, lights=lights, cameras=cameras,
+                                                   materials=materials)
+                return blend_mod.softmax_rgb_blend(colors, fragments, blend_params, znear=kwargs.get("znear", getattr(cameras, "znear", 1.0)),
+                                                   zfar=kwargs.get("zfar", getattr(cameras, "zfar", 100.0)))
             return orig(self, fragments, meshes, **kwargs)
         znear = kwargs.get("znear", getattr(cameras, "znear", 1.0))
         zfar = kwargs.get("zfar", getattr(cameras, "zfar", 100.0))
