@@ -421,8 +421,13 @@ def main():
                     dist.destroy_process_group()
             except Exception:
                 pass
+            # an explicit store on the next port, hosted by rank 0: under torchrun an `init_method` URL makes every rank a CLIENT of
+            # the agent's store (TORCHELASTIC_USE_AGENT_STORE), which nobody hosts on a second port -- measured: it hangs
+            import datetime
+
             port = int(os.environ.get("MASTER_PORT", "29500")) + 1
-            dist.init_process_group("gloo", init_method=f"tcp://{os.environ['MASTER_ADDR']}:{port}", rank=rank, world_size=world)
+            store = dist.TCPStore(os.environ["MASTER_ADDR"], port, world, is_master=(rank == 0), timeout=datetime.timedelta(seconds=120))
+            dist.init_process_group("gloo", store=store, rank=rank, world_size=world)
             backend = "gloo"
     comm_dev = device if backend == "nccl" else torch.device("cpu")  # where tensors of a collective have to live
 
