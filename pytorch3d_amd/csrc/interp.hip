@@ -120,8 +120,8 @@ __global__ __launch_bounds__(256) void interp_bwd_kernel(const int64_t* __restri
 template <int D>
 struct InterpTable {
   static constexpr int NV = 3 * D;
-  static constexpr int kSlots = NV == 3 ? 426 : NV == 6 ? 256 : 182;  // 4 waves x slots x (8 + 4 * stride) B <= 40 KB
-  using T = WaveTable<NV, kSlots>;
+  static constexpr int kSlots = NV == 3 ? 424 : NV == 6 ? 256 : 180;  // 4 waves x slots x (8 + 4 * stride) B <= 40 KB; multiples of 4 (bucket probing)
+  using T = WaveTable<NV, kSlots, kRows, false, true>;
 };
 
 template <int D>
@@ -187,7 +187,7 @@ void launch_interp_bwd_table(const int64_t* p2f, const float* bary, const float*
 // fit a table slot, and per-sample atomics (the reference's design) run at ~70 GB/s of algorithmic traffic (D = 8:
 // 28 ms on 34 M samples); per chunk the kernel is the small-D one: p2f and bary are re-read (20 B), the chunk of
 // grad_pix_attrs is read once (16 B), grad_bary is written by the first chunk and accumulated by the others.
-using ChunkTable = WaveTable<12, 182, kChunk>;  // 4 waves x 182 x 56 B = 40 KB
+using ChunkTable = WaveTable<12, 180, kChunk, false, true>;  // 4 waves x 180 x 56 B = 40 KB; bucket probing
 
 __global__ __launch_bounds__(256) void interp_bwd_chunk_kernel(const int64_t* __restrict__ p2f, const float* __restrict__ bary,
                                                                const float* __restrict__ attrs,

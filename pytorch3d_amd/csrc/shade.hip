@@ -94,8 +94,8 @@ struct ShadeTable {
   // for 5 / 4 workgroups per CU (D = 6: 32 KB, D = 9: 40 KB) rather than for the worst case of a step (64 consecutive
   // samples can name 64 faces): they run in SPILL mode (wave_table.h).  Measured on the config-3 fragments, D = 6:
   // 182 slots (2 WG/CU) 4.3 ms, 144 (3 WG/CU) 3.3 ms, 106 (4 WG/CU) 2.9 ms, 90 (5 WG/CU) 2.6 ms, 75 (6 WG/CU) 2.65 ms; D = 9: 110 slots (3 WG/CU) 3.6 ms, 83 (4 WG/CU) 3.2 ms.
-  static constexpr int kSlots = D == 6 ? 90 : 83;
-  using T = WaveTable<NV, kSlots, false, true>;
+  static constexpr int kSlots = D == 6 ? 88 : 80;  // multiples of 4: the keys are probed a bucket of four at a time
+  using T = WaveTable<NV, kSlots, false, true, true>;
 };
 
 // PG: also accumulate the gradient of the per-image parameters (lights, materials, camera centre): 25 per-lane sums over

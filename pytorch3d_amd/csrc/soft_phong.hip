@@ -205,8 +205,8 @@ __global__ __launch_bounds__(256) void soft_phong_fwd_kernel(SoftPhongArgs a) {
 template <int D>
 struct SoftTable {
   static constexpr int NV = 3 * D;
-  static constexpr int kSlots = D == 6 ? 90 : 83;  // shade.hip: ShadeTable (5 / 4 workgroups per CU, spill mode)
-  using T = WaveTable<NV, kSlots, false, true>;
+  static constexpr int kSlots = D == 6 ? 88 : 80;  // shade.hip: ShadeTable (5 / 4 workgroups per CU, spill mode, bucket probing)
+  using T = WaveTable<NV, kSlots, false, true, true>;
 };
 
 constexpr int kSoftPhongBwdWaves = 3;  // measured (D = 9, K = 8): 146 VGPRs at 3 waves 3.84 ms; capped at 128 (72 B of scratch) 4.80 ms
