@@ -151,6 +151,10 @@ P3D_HD float seg_dist2(f2 p, f2 a, f2 b) {
   const float dx = (a.x + t * bax) - p.x;
   const float dy = (a.y + t * bay) - p.y;
   const float d_seg = dx * dx + dy * dy;
+  // FAST (backward): the same predicate on floats -- 1e-8 lies between the floats 9.99999994e-9 (= 1e-8f, the nearer one) and
+  // 1.00000008e-8, so `l2 <= 1e-8` in double and `l2 <= 1e-8f` in float select the same floats -- without the v_cvt_f64_f32 +
+  // v_cmp_f64 per edge and sample
+  if (FAST) return (l2 <= 1e-8f) ? d_point : d_seg;
   return ((double)l2 <= P3D_KEPS) ? d_point : d_seg;
 }
 

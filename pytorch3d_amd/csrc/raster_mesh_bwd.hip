@@ -395,9 +395,18 @@ __global__ __launch_bounds__(256, RowsCfg<KT>::kWaves) void mesh_backward_rows_k
 
   const int seg = min(16, W - ax) * KT;               // samples of a row segment inside the image
   const int e = (lane & (PIX - 1)) * KT + lane / PIX;  // this lane's sample within a step's 64
-  float px[SPR];                                       // NDC x of this lane's pixel in step s of a row (rasterize_meshes.cu:458-462)
+  // Pixel centres, once per wave.  px[s]: NDC x of this lane's pixel in step s of a row (rasterize_meshes.cu:458-462); py_rows:
+  // lane r holds the NDC y of row r of the area, a step fetches its row's with one v_readlane.  Both pass through an empty asm:
+  // left to itself the compiler recomputed them inside the step loop -- two IEEE divisions (v_div_scale / v_rcp / 5 fma /
+  // v_div_fmas / v_div_fixup each) per step, ~45 of the ~530 VALU instructions of a step (round 4, seen in the ISA).
+  float px[SPR];
 #pragma unroll
-  for (int s = 0; s < SPR; ++s) px[s] = pix_to_ndc(W - 1 - (ax + s * PIX + (lane & (PIX - 1))), W, H);
+  for (int s = 0; s < SPR; ++s) {
+    px[s] = pix_to_ndc(W - 1 - (ax + s * PIX + (lane & (PIX - 1))), W, H);
+    asm volatile("" : "+v"(px[s]));
+  }
+  float py_rows = pix_to_ndc(H - 1 - (ay + (lane & 15)), H, W);
+  asm volatile("" : "+v"(py_rows));
   const int64_t area_base = (((int64_t)n * H + ay) * W + ax) * KT;
   const int64_t row_pitch = (int64_t)W * KT;
 
@@ -429,7 +438,7 @@ __global__ __launch_bounds__(256, RowsCfg<KT>::kWaves) void mesh_backward_rows_k
       float pxs = px[0];
 #pragma unroll
       for (int c = 1; c < SPR; ++c) pxs = s == c ? px[c] : pxs;
-      const f2 p = mk2(pxs, pix_to_ndc(H - 1 - (ay + r), H, W));
+      const f2 p = mk2(pxs, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py_rows), r)));
       g = face_sample_bwd(mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), mk3(q[6], q[7], q[8]), p, gz, gb, gd, persp, clip, false);
     } else {
 #pragma unroll

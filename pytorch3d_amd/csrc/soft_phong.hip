@@ -248,29 +248,70 @@ __global__ __launch_bounds__(256, PG ? 2 : kSoftPhongBwdWaves) void soft_phong_b
   for (int j = 0; j < (PG ? P3D_SHADE_PARAM_FLOATS : 1); ++j) pg[j] = 0.0f;
   const float pw0 = c.shin == 0.0f ? 1.0f : 0.0f;  // pow(0, shininess)
   const int k = lane & (KT - 1);
+  // Streams two steps deep (round 4).  The kernel is bound by latency, not by issue: 11,400 VALU instructions per wave in
+  // ~200 us, 52 % of the wave cycles waiting with three waves per SIMD (profiles/r04/soft_phong_pmc.md) -- every step was the
+  // chain pix_to_face -> (face record gather, per-sample operands) -> arithmetic -> table, each link a memory round trip.
+  // Now pix_to_face of step t + 2 and the per-sample operands of step t + 1 (distance, depth, barycentrics, the pixel's
+  // upstream gradient -- still only for samples / pixels that hold a face) are requested before step t is computed: 12
+  // registers, and the only load a step still waits for is its face-record gather.
+  auto sample_pos = [&](int e0, bool* ok) -> int64_t {
+    const int e = e0 + lane;
+    *ok = e < total;  // (run is a multiple of KT and 64 is too: a pixel's lanes are ok together)
+    const int r = (int)(((float)e + 0.5f) * inv_run);  // exact for these small operands (shade.hip)
+    return (((int64_t)n * H + y0 + r) * W + x0) * KT + (e - r * run);
+  };
+  struct Ops {
+    float d, z, b[3];
+    float4 go;
+  };
+  auto load_ops = [&](bool ok, int64_t p, int f, Ops* o) {
+    const bool valid = f >= 0;
+    const bool any = grp_ior<KT>(valid ? 1 : 0) != 0;
+    o->d = o->z = 0.0f;
+    o->b[0] = o->b[1] = o->b[2] = 0.0f;
+    o->go = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok && (any || zf == zn)) {
+      o->d = a.dists[p];
+      o->z = a.zbuf[p];
+      o->go = *reinterpret_cast<const float4*>(a.grad_out + (p / KT) * 4);
+    }
+    if (valid) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) o->b[j] = a.bary[p * 3 + j];
+    }
+  };
+  bool ok_c, ok_n = false, ok_nn = false;
+  int64_t p_c = sample_pos(0, &ok_c), p_n = 0, p_nn = 0;
+  int f_c = ok_c ? (int)a.p2f[p_c] : -1, f_n = -1, f_nn = -1;
+  if (64 < total) {
+    p_n = sample_pos(64, &ok_n);
+    f_n = ok_n ? (int)a.p2f[p_n] : -1;
+  }
+  Ops cur, nxt;
+  load_ops(ok_c, p_c, f_c, &cur);
 #pragma unroll 1
   for (int e0 = 0; e0 < total; e0 += 64) {
-    const int e = e0 + lane;
-    const bool ok = e < total;  // (run is a multiple of KT and 64 is too: a pixel's lanes are ok together)
-    const int r = (int)(((float)e + 0.5f) * inv_run);  // exact for these small operands (shade.hip)
-    const int64_t p = (((int64_t)n * H + y0 + r) * W + x0) * KT + (e - r * run);
-    const int f = ok ? (int)a.p2f[p] : -1;
+    // requests for the steps ahead
+    f_nn = -1;
+    ok_nn = false;
+    if (e0 + 128 < total) {
+      p_nn = sample_pos(e0 + 128, &ok_nn);
+      f_nn = ok_nn ? (int)a.p2f[p_nn] : -1;
+    }
+    if (e0 + 64 < total) load_ops(ok_n, p_n, f_n, &nxt);
+    const bool ok = ok_c;
+    const int64_t p = p_c;
+    const int f = f_c;
     const bool valid = f >= 0;
     const bool any = grp_ior<KT>(valid ? 1 : 0) != 0;
     float gb[3] = {0.f, 0.f, 0.f};
     float gdist = 0.0f, gz = 0.0f;
     float g[NV];
     if (any || (ok && zf == zn)) {
-      float d = 0.0f, z = 0.0f;
-      if (ok) {
-        d = a.dists[p];
-        z = a.zbuf[p];
-      }
-      float b[3] = {0.f, 0.f, 0.f}, col[3] = {0.f, 0.f, 0.f}, tex_in[3] = {0.f, 0.f, 0.f};
+      const float d = cur.d, z = cur.z;
+      float b[3] = {cur.b[0], cur.b[1], cur.b[2]}, col[3] = {0.f, 0.f, 0.f}, tex_in[3] = {0.f, 0.f, 0.f};
       ShadeState<D> st;
       if (valid) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) b[j] = a.bary[p * 3 + j];
         if (D == 6) {
 #pragma unroll
           for (int j = 0; j < 3; ++j) tex_in[j] = a.texels[p * 3 + j];
@@ -280,7 +321,7 @@ __global__ __launch_bounds__(256, PG ? 2 : kSoftPhongBwdWaves) void soft_phong_b
       }
       // ---- softmax blend backward (blend.hip: softmax_blend_bwd_kernel), the pixel's K slots side by side in the wave
       const SoftLane q = soft_lane<KT>(valid, d, z, k, a.sigma, a.gamma, zn, zf);
-      const float4 go4 = ok ? *reinterpret_cast<const float4*>(a.grad_out + (p / KT) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 go4 = cur.go;
       const float inv_denom = 1.0f / q.denom;
       const float r0 = (grp_sum<KT>(q.w * col[0]) + q.delta * a.bg[0]) * inv_denom;
       const float r1 = (grp_sum<KT>(q.w * col[1]) + q.delta * a.bg[1]) * inv_denom;
@@ -319,6 +360,14 @@ __global__ __launch_bounds__(256, PG ? 2 : kSoftPhongBwdWaves) void soft_phong_b
       a.gdists[p] = gdist;
       a.gzbuf[p] = gz;
     }
+    // rotate the pipeline (every path below this point continues with the next step)
+    ok_c = ok_n;
+    p_c = p_n;
+    f_c = f_n;
+    cur = nxt;
+    ok_n = ok_nn;
+    p_n = p_nn;
+    f_n = f_nn;
     if (__ballot(valid) == 0) continue;  // wave-uniform
     tab.add(a.gattrs, lane, f, g);
   }
