@@ -845,13 +845,24 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
     return;
   }
 
-  const f2 p = mk2(pix_to_ndc(xi, W, H), pix_to_ndc(yi, H, W));
-  // pixel-centre extents (pix_to_ndc is monotone in the pixel index)
-  // wave-uniform values: keep them in SGPRs (the divisions inside pix_to_ndc leave them in VGPRs otherwise)
-  const float tile_x0 = uniform_f(pix_to_ndc(tx0, W, H)), tile_x1 = uniform_f(pix_to_ndc(min(tx0 + kTile, x_end) - 1, W, H));
-  const float tile_y0 = uniform_f(pix_to_ndc(ty0, H, W)), tile_y1 = uniform_f(pix_to_ndc(min(ty0 + kTile, y_end) - 1, H, W));
-  const float sub_x0 = uniform_f(pix_to_ndc(sx0, W, H)), sub_x1 = uniform_f(pix_to_ndc(min(sx0 + 8, x_end) - 1, W, H));
-  const float sub_y0 = uniform_f(pix_to_ndc(sy0, H, W)), sub_y1 = uniform_f(pix_to_ndc(min(sy0 + 8, y_end) - 1, H, W));
+  // Pixel centres: ONE pix_to_ndc per lane for the whole set-up (round 4).  Lane l < 16 evaluates pixel column ox + l of the
+  // tile, lane 16 + l pixel row oy + l (ox, oy: the workgroup's 16 x 16 tile, or in split mode its one 8 x 8 sub-tile; lanes
+  // 32..63 repeat); the lane's own pixel centre and the eight pixel-centre extents of the tile and the sub-tile are then
+  // FETCHED from those lanes (two ds_bpermute, eight v_readlane) -- same function, same integer argument, same bits.  Before,
+  // every wave evaluated pix_to_ndc eleven times: ~24 IEEE divisions (11 instructions each), ~400 of the ~5000 VALU
+  // instructions of a wave that holds faces.
+  const int ox = SPLIT ? sx0 : tx0, oy = SPLIT ? sy0 : ty0;
+  const float pxy = (lane & 16) ? pix_to_ndc(oy + (lane & 15), H, W) : pix_to_ndc(ox + (lane & 15), W, H);
+  auto col_centre = [&](int x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pxy), x - ox)); };        // uniform x
+  auto row_centre = [&](int y) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pxy), 16 + y - oy)); };  // uniform y
+  const f2 p = mk2(__int_as_float(__builtin_amdgcn_ds_bpermute((xi - ox) << 2, __float_as_int(pxy))),
+                   __int_as_float(__builtin_amdgcn_ds_bpermute((16 + yi - oy) << 2, __float_as_int(pxy))));
+  // pixel-centre extents (pix_to_ndc is monotone in the pixel index); wave-uniform: SGPRs.  (Split mode stages against its one
+  // sub-tile: the tile extents are not used there.)
+  const float tile_x0 = SPLIT ? 0.0f : col_centre(tx0), tile_x1 = SPLIT ? 0.0f : col_centre(min(tx0 + kTile, x_end) - 1);
+  const float tile_y0 = SPLIT ? 0.0f : row_centre(ty0), tile_y1 = SPLIT ? 0.0f : row_centre(min(ty0 + kTile, y_end) - 1);
+  const float sub_x0 = col_centre(sx0), sub_x1 = col_centre(min(sx0 + 8, x_end) - 1);
+  const float sub_y0 = row_centre(sy0), sub_y1 = row_centre(min(sy0 + 8, y_end) - 1);
 
   Queue q;
   q.init();
@@ -862,12 +873,11 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
   lds.pm = s_pm;
   {
     // the tile the masks refer to: the workgroup's 16 x 16 tile, or (split mode) its one 8 x 8 sub-tile
-    const int ox = SPLIT ? sx0 : tx0, oy = SPLIT ? sy0 : ty0, side = SPLIT ? 8 : kTile;
+    const int side = SPLIT ? 8 : kTile;
     const int cols = min(side, x_end - ox), rows = min(side, y_end - oy);
     lds.valid_c = (1u << cols) - 1u;
     lds.valid_r = (1u << rows) - 1u;
-    const int li = lane & 15;
-    lds.pxy = (lane & 16) ? pix_to_ndc(oy + li, H, W) : pix_to_ndc(ox + li, W, H);
+    lds.pxy = pxy;
   }
   lds.rec = s_rec;
   lds.zc = s_zc;
