@@ -165,24 +165,39 @@ __global__ __launch_bounds__(256) void composite_bwd_tile_kernel(CompArgs a, int
   }
 
   // grad_alphas: registers only
+  float inv[MODE == P3D_COMPOSITE_ALPHA ? KT : 1];
+  if (MODE == P3D_COMPOSITE_ALPHA) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) inv[k] = 1.0f / (1 - al[k] + kEpsAlpha);
+  }
   if (ok) {
     for (int c = 0; c < C; ++c) {
       const float* f = a.features + (int64_t)c * a.P;
       const float go = go_p[(int64_t)c * HW];
       if (MODE == P3D_COMPOSITE_ALPHA) {
+        // alpha_composite.cu:120-139: entry k adds -go f_k cum_k alpha_k / (1 - alpha_t + eps) to grad_alpha[t] for every valid
+        // t < k.  The reference (and this kernel until round 4) forms each of those K (K - 1) / 2 quotients per channel with an
+        // IEEE division -- 135 divisions of 11 instructions per pixel at K = 10, C = 3, a dependent chain that made the
+        // kernel latency-bound (0.113 ms for 69 MB).  The divisor depends on t alone: grad_alpha[t] += inv_t * (sum of the
+        // `back` terms of the valid entries behind t), one reciprocal per entry (outside the channel loop) and one running sum.
+        // The sums are re-associated (tolerance-gated: 1e-6 absolute in the reference's own test, tests/test_compositing.py:207).
         float cum = 1.0f;
+        float back[KT];
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
+          back[k] = 0.0f;
           if (id[k] >= 0) {
             const float fv = f[id[k]];
             ga[k] += cum * fv * go;
-            const float back = -go * fv * cum * al[k];
-#pragma unroll
-            for (int tt = 0; tt < KT; ++tt) {
-              if (tt < k && id[tt] >= 0) ga[tt] += back / (1 - al[tt] + kEpsAlpha);
-            }
+            back[k] = -go * fv * cum * al[k];
             cum = cum * (1 - al[k]);
           }
+        }
+        float behind = 0.0f;
+#pragma unroll
+        for (int k = KT - 1; k >= 0; --k) {
+          if (id[k] >= 0) ga[k] += behind * inv[k];
+          behind += back[k];
         }
       } else if (MODE == P3D_COMPOSITE_NORM_SUM) {
         float sum_af = 0.0f;

@@ -287,21 +287,28 @@ __global__ __launch_bounds__(256) void point_backward_kernel(const float* __rest
   const float inv_run = 1.0f / (float)run, inv_k = 1.0f / (float)K;
   PointTable tab;
   tab.init(s_table[w], lane);
+  // lane l < 8: NDC x of the tile's pixel column x0 + l; lane 8 + l: NDC y of its row y0 + l (rasterize_points.cu:389-393:
+  // the backward un-flips the stored indices); once per wave
+  float centres = (lane & 8) ? pix_to_ndc(H - 1 - (y0 + (lane & 7)), H, W) : pix_to_ndc(W - 1 - (x0 + (lane & 7)), W, H);
+  asm volatile("" : "+v"(centres));
   for (int base = 0; base < total; base += 64) {
     const int e = base + lane;
     int p = -1;
     float g[3] = {0.f, 0.f, 0.f};
+    // exact for these small operands: (e + 0.5) / d is at least 0.5 / d away from an integer
+    const int r = (int)(((float)e + 0.5f) * inv_run);
+    const int ee = e - r * run;
+    const int xo = x0 + (int)(((float)ee + 0.5f) * inv_k);
+    const int yo = y0 + r;
+    // the pixel's centre from the lanes that hold the tile's eight column / row centres (two ds_bpermute instead of two
+    // pix_to_ndc with an IEEE division each per entry); outside the branch: every lane takes part in the exchange, lanes
+    // past the end of the tile read some lane of the table and never use it
+    const float xf = __int_as_float(__builtin_amdgcn_ds_bpermute(((xo - x0) & 7) << 2, __float_as_int(centres)));
+    const float yf = __int_as_float(__builtin_amdgcn_ds_bpermute((8 + ((yo - y0) & 7)) << 2, __float_as_int(centres)));
     if (e < total) {
-      // exact for these small operands: (e + 0.5) / d is at least 0.5 / d away from an integer
-      const int r = (int)(((float)e + 0.5f) * inv_run);
-      const int ee = e - r * run;
-      const int xo = x0 + (int)(((float)ee + 0.5f) * inv_k);
-      const int yo = y0 + r;
       const int64_t i = (((int64_t)n * H + yo) * W + x0) * K + ee;
       p = idxs[i];
       if (p >= 0) {
-        const float xf = pix_to_ndc(W - 1 - xo, W, H);  // rasterize_points.cu:389-393
-        const float yf = pix_to_ndc(H - 1 - yo, H, W);
         const float gd = grad_dists[i];
         const float dx = points[(int64_t)p * 3 + 0] - xf;
         const float dy = points[(int64_t)p * 3 + 1] - yf;
