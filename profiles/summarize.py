@@ -67,8 +67,8 @@ def main():
                 pmc[k][c] = sum(v) / len(v)
     if pmc:
         lines += ["## PMC passes (per-launch averages; each `--pmc` set collected in its own run)", "",
-                  "rocprofv3's `VGPR_Count` column reads HALF the wave64 allocation on gfx950 (mesh_fine: 64 <-> `.vgpr_count` 121, "
-                  "allocated 128; mesh_backward: 40 <-> 75, allocated 80); the ISA figures are in `profiles/r03/static_counts.txt`.", ""]
+                  "rocprofv3's `VGPR_Count` column reads HALF the wave64 allocation on gfx950; the compiler's figures per kernel (VGPRs, "
+                  "AGPRs, scratch, spills, occupancy) are recorded at build time in `pytorch3d_amd/libp3d_amd.so.resources.json`.", ""]
         for k in sorted(pmc, key=lambda k: -pmc[k].get("SQ_WAVE_CYCLES", 0)):
             m = meta[k]
             lines += [f"### {k}", "",
