@@ -470,13 +470,16 @@ __device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue&
     const bool too_deep = zc > q.kth_z(K);
     if (pix_ok && in_box && !too_deep) {
       // all LDS reads of this candidate are issued together (one round trip instead of dependent ones)
-      const float4 r0 = s_rec[jj][0], r1 = s_rec[jj][1], r2 = s_rec[jj][2];
+      // (jj differs per lane when two candidates share the pass: the record address is a per-lane product -- a 24-bit multiply,
+      // v_mul_u32_u24, instead of the quarter-rate v_mul_lo_u32 the plain index compiled to)
+      const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_rec) + __umul24((unsigned)jj, (unsigned)(kRecWords * sizeof(float4))));
+      const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
       const int f = __float_as_int(r2.y);
       FaceHit h;
       bool hit = false;
       {
-        const double2 d0 = *reinterpret_cast<const double2*>(&s_rec[jj][3]);
-        const double2 d1 = *reinterpret_cast<const double2*>(&s_rec[jj][4]);
+        const double2 d0 = *reinterpret_cast<const double2*>(&rec[3]);
+        const double2 d1 = *reinterpret_cast<const double2*>(&rec[4]);
         FaceRec fr;
         fr.v0 = mk3(r0.x, r0.y, r1.z);
         fr.v1 = mk3(r0.z, r0.w, r1.w);

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, 4) void mesh_backward_kernel(BwdArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Sample-major form for K = 4, 8, 16 (round 3).  The kernel above gives a lane a PIXEL and walks its K slots: 56 row
+// Sample-major form for K = 4, 8, 16 (round 3) and 32 (round 4: two pixels per 64-sample step; K = 32 on 8 bench meshes 0.95 -> 0.45 ms).  The kernel above gives a lane a PIXEL and walks its K slots: 56 row
 // registers per lane (127 VGPRs, four waves per SIMD) and, per slot, a face-vertex gather whose latency nothing hides --
 // the wave sits in s_waitcnt 47 % of its time (profiles/r02_fine_v2_rocprof.md) while VALU and LDS are each under half
 // busy.  Here a lane owns one SAMPLE per step: a 16-pixel row segment of the four operands is 16 K contiguous samples,
@@ -356,7 +356,7 @@ template <int KT, bool TO_VERTS>
 __global__ __launch_bounds__(256, RowsCfg<KT>::kWaves) void mesh_backward_rows_kernel(BwdArgs a) {
   constexpr int SPR = KT / 4;  // steps per 16-pixel row segment
   constexpr int PIX = RowsCfg<KT>::kPix;
-  static_assert(KT == 4 || KT == 8 || KT == 16, "16 K samples per row segment, 64 per step");
+  static_assert(KT == 4 || KT == 8 || KT == 16 || KT == 32, "16 K samples per row segment, 64 per step");
   using Table = WaveTable<9, RowsCfg<KT>::kSlots, TO_VERTS ? kCorners : kRows, true, true>;
   __shared__ __align__(16) int s_table[4][Table::kLdsInts];
 
@@ -499,7 +499,7 @@ int launch_mesh_backward(const float* face_verts, const int64_t* faces, int64_t 
   a.CX = (W + 15) / 16;
   a.area_list = nullptr;
   a.area_count = nullptr;
-  const bool rows_kernel = K == 4 || K == 8 || K == 16;
+  const bool rows_kernel = K == 4 || K == 8 || K == 16 || K == 32;  // (32: round 4, with the on-chip forward queues for K > 16)
   // Work items in scattered order: workgroups reach XCDs and CUs round robin by index, and in (image, row, column) order
   // the index says where in the image the item is -- the CUs that drew the borders ran empty while the ones with the image
   // centres queued work.  b -> (b * scatter) mod items, odd multiplier near items / golden ratio, coprime: a bijection.
@@ -526,6 +526,7 @@ int launch_mesh_backward(const float* face_verts, const int64_t* faces, int64_t 
     case 4: mesh_backward_rows_kernel<4, TV><<<grid, 256, 0, s>>>(a); break;     \
     case 8: mesh_backward_rows_kernel<8, TV><<<grid, 256, 0, s>>>(a); break;     \
     case 16: mesh_backward_rows_kernel<16, TV><<<grid, 256, 0, s>>>(a); break;   \
+    case 32: mesh_backward_rows_kernel<32, TV><<<grid, 256, 0, s>>>(a); break;   \
     default: mesh_backward_kernel<0, TV><<<grid, 256, 0, s>>>(a); break;         \
   }
   if (faces) {

@@ -236,6 +236,31 @@ def test_backward_vs_oracle(persp, clip):
                                  reference=ref)
 
 
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 5, 8, 12, 16, 20, 32, 40])
+def test_backward_every_kernel_vs_oracle(K):
+    """Every backward kernel of the launcher (raster_mesh_bwd.hip: the sample-major rows kernel for K = 4, 8, 16 and -- round 4 --
+    32, the pixel-major one for every other K) on the fragments of a dense soup, with and without the forward's row cover,
+    against the float64 restatement of the reference's formulas; an image whose sides are no multiple of the 16-pixel areas."""
+    from pytorch3d_amd import _C
+
+    d = _dev()
+    gen = torch.Generator().manual_seed(100 + K)
+    fv = U.smooth_soup(600, gen, size=4.0)  # frame-sized triangles: rows of 40 slots fill up
+    first, count = U.split_counts(600, 2)
+    nbr = torch.full((600,), -1, dtype=torch.int64)
+    size, blur = (40, 56), 2e-3
+    (p2f, zbuf, bary, dists), cover = _C._rasterize_meshes_covered(fv.to(d), first.to(d), count.to(d), nbr.to(d), size, blur, K, 8, 1000,
+                                                                    True, True, False)
+    assert int((p2f[..., K - 1] >= 0).sum()) > 0, "the soup does not fill a row of this length"
+    gz = torch.randn(zbuf.shape, generator=gen).to(d)
+    gb = torch.randn(bary.shape, generator=gen).to(d)
+    gd = torch.randn(dists.shape, generator=gen).to(d)
+    plain = _C.rasterize_meshes_backward(fv.to(d), p2f.clone(), gz, gb, gd, True, True)
+    covered = _C.rasterize_meshes_backward(fv.to(d), p2f, gz, gb, gd, True, True, _cover=cover)
+    for tag, got in (("no cover", plain), ("row cover", covered)):
+        U.assert_face_grads_vs_truth(f"backward K={K} {tag}", got.cpu(), fv, p2f.cpu(), gz.cpu(), gb.cpu(), gd.cpu(), True, True, rtol=2e-3)
+
+
 def test_autograd_mirror_and_reference_cpu_build():
     """The L2 mirror end to end (verts -> loss -> grad), against the reference's own CPU kernels when
     oracle/_ref is present (idx exact, floats 1e-5, grads rtol 5e-3 as tests/test_rasterize_meshes.py:317-319)."""
