@@ -438,11 +438,17 @@ def _patch_hard_and_silhouette_shaders():
                 ok = torch.is_tensor(p2f) and p2f.dim() == 4 and p2f.shape[3] > 1 and torch.is_tensor(fragments.bary_coords)
             except Exception:
                 ok = False
-            _count(name + ".forward", ok)
-            if not ok:
+            first = None
+            if ok:
+                try:  # fragments of another shape than the rasterizer's (a subclass, missing fields): the reference's own path
+                    first = rz.Fragments(pix_to_face=fragments.pix_to_face[..., :1].contiguous(), zbuf=fragments.zbuf[..., :1].contiguous(),
+                                         bary_coords=fragments.bary_coords[..., :1, :].contiguous(),
+                                         dists=fragments.dists[..., :1].contiguous())
+                except Exception:
+                    first = None
+            _count(name + ".forward", first is not None)
+            if first is None:
                 return orig(self, fragments, meshes, **kwargs)
-            first = rz.Fragments(pix_to_face=fragments.pix_to_face[..., :1].contiguous(), zbuf=fragments.zbuf[..., :1].contiguous(),
-                                 bary_coords=fragments.bary_coords[..., :1, :].contiguous(), dists=fragments.dists[..., :1].contiguous())
             return orig(self, first, meshes, **kwargs)
 
         forward.__wrapped__ = orig
