@@ -72,13 +72,18 @@ __global__ __launch_bounds__(kStage, WAVES) void point_raster_kernel(PointArgs a
   const int xi = sx0 + (lane & 7);
   const bool pix_ok = yi < y_end && xi < x_end;
   const bool wave_ok = sy0 < y_end && sx0 < x_end;
-  const float xf = pix_to_ndc(xi, W, H);
-  const float yf = pix_to_ndc(yi, H, W);
+  // one pix_to_ndc per lane: lane l < 16 evaluates the tile's pixel column tx0 + l, lane 16 + l its row ty0 + l; the lane's own
+  // centre and the eight extents are fetched from those lanes -- same function, same argument, same bits (raster_mesh.hip, round 4)
+  const float pxy = (lane & 16) ? pix_to_ndc(ty0 + (lane & 15), H, W) : pix_to_ndc(tx0 + (lane & 15), W, H);
+  auto col_centre = [&](int x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pxy), x - tx0)); };
+  auto row_centre = [&](int y) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pxy), 16 + y - ty0)); };
+  const float xf = __int_as_float(__builtin_amdgcn_ds_bpermute((xi - tx0) << 2, __float_as_int(pxy)));
+  const float yf = __int_as_float(__builtin_amdgcn_ds_bpermute((16 + yi - ty0) << 2, __float_as_int(pxy)));
 
-  const float tile_x0 = pix_to_ndc(tx0, W, H), tile_x1 = pix_to_ndc(min(tx0 + kTile, x_end) - 1, W, H);
-  const float tile_y0 = pix_to_ndc(ty0, H, W), tile_y1 = pix_to_ndc(min(ty0 + kTile, y_end) - 1, H, W);
-  const float sub_x0 = pix_to_ndc(sx0, W, H), sub_x1 = pix_to_ndc(min(sx0 + 8, x_end) - 1, W, H);
-  const float sub_y0 = pix_to_ndc(sy0, H, W), sub_y1 = pix_to_ndc(min(sy0 + 8, y_end) - 1, H, W);
+  const float tile_x0 = col_centre(tx0), tile_x1 = col_centre(min(tx0 + kTile, x_end) - 1);
+  const float tile_y0 = row_centre(ty0), tile_y1 = row_centre(min(ty0 + kTile, y_end) - 1);
+  const float sub_x0 = col_centre(min(sx0, x_end - 1)), sub_x1 = col_centre(max(min(sx0 + 8, x_end) - 1, tx0));
+  const float sub_y0 = row_centre(min(sy0, y_end - 1)), sub_y1 = row_centre(max(min(sy0 + 8, y_end) - 1, ty0));
 
   int64_t src_base;
   int count;
