@@ -452,6 +452,8 @@ __device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue&
       // anyway.  Any order of the candidates gives the same queues here (top-K under a total order; the neighbour rule,
       // which is order-dependent, lives in the GENERAL nest), so taking a later candidate early changes nothing but the
       // number of passes: 20 % fewer on the bench batch by bounding boxes alone (profiles/next/README.md).
+      // (Measured and dropped in round 4: pairing against the lanes that really EVALUATE the candidate -- inside its box and not
+      // behind the lane's K-th entry -- instead of its whole box: more pairs, +2 % time, profiles/r04/exp_active_pairs.txt.)
       const unsigned long long free_of_a = __ballot(((mlo & alo) | (mhi & ahi)) == 0u) & cand;  // lane = candidate face
       if (free_of_a) {  // uniform
         const int cb = __builtin_ctzll(free_of_a);
