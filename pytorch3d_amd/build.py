@@ -95,7 +95,10 @@ def build(force=False, verbose=False):
         for k, v in r.items():
             resources[k] = dict(v, source=src)
     spilled = sorted(k for k, v in resources.items() if v["vgpr_spill"] > 0)
-    if spilled:
+    if spilled and os.environ.get("P3D_ALLOW_SPILLS") and os.environ.get("P3D_LIB_PATH"):
+        # experiment variants only (never the product library): measure the kernels that fit, do not trust the others
+        print("[build] VARIANT with spilled kernels:", ", ".join(demangle(k) for k in spilled), file=sys.stderr)
+    elif spilled:
         # Round 4: every kernel of this library that spilled VGPRs next to SGPR spills LOST queue entries on the GPU (the
         # generic K = 5..7 kernel, TopKReg<32+, 0>, TopKPairs<64, ., 0>: profiles/r04/spill_miscompile.md), bit-exact
         # against the oracle as soon as the same code fitted its registers.  A spill is therefore a build error here, not a
