@@ -56,7 +56,7 @@ def _stamp_path():
 
 
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(LIB + ".resources.json"):  # the library and its resource record go together
         return True
     # a library built with other flags (ablation -D switches, table sizes) must never be reused as the product build
     try:
