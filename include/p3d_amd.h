@@ -52,9 +52,26 @@ const char* p3d_error_string(int code);
  * per-(mesh, bin) counters, offsets and the tile plan (~20 B per bin) and per-(1024-face chunk, bin) partial counts.
  * Only the used prefix is ever touched.  Examples at 512 x 512 (1024 internal bins per image), max_faces_per_bin =
  * max(10000, F / 5) as the reference's wrapper picks it: one 5.8k-face mesh 24 MB; the bench batch (N = 64, F = 321k)
- * 1.3 GB; an un-sharded batch of 512 such meshes 42 GB -- shard the batch (pytorch3d_amd/sharding.py) or lower
- * max_faces_per_bin when that matters.  Reuse the workspace across calls; it carries no state between them. */
+ * 1.3 GB; an un-sharded batch of 512 such meshes 42 GB -- hand over a short workspace (below), shard the batch
+ * (pytorch3d_amd/sharding.py) or lower max_faces_per_bin when that matters.  Reuse the workspace across calls; it carries no
+ * state between them. */
 size_t p3d_rasterize_meshes_workspace_bytes(int64_t F, int N, int H, int W, int bin_size, int max_faces_per_bin);
+
+/* Short workspaces (p3d_rasterize_meshes and p3d_rasterize_meshes_with_cover only; the reference has no counterpart: its
+ * coarse stage allocates the padded (N, BH, BW, max_faces_per_bin) tensor, rasterize_coarse.cu:353-354).
+ * Those two calls accept ANY workspace of at least p3d_rasterize_meshes_short_workspace_bytes(..., list_entries = 0) bytes:
+ * the bin lists get whatever room is left after the fixed arrays.  Whether the lists fit is decided on the device, after
+ * the scan, with no host sync: when they do, the binned kernel runs as usual and a second, naive launch returns at once;
+ * when they do not, the binned kernel returns at once and the naive kernel (every tile tests every face of its mesh)
+ * writes the same outputs -- slower, bit-identical.  The int64 at byte p3d_rasterize_meshes_workspace_need_offset(...) of
+ * the workspace holds, once the call has run, the number of list entries it needed: read it back whenever convenient and
+ * size the next workspace with p3d_rasterize_meshes_short_workspace_bytes(..., that number plus headroom).  Bench batch:
+ * 2.1 M entries = 8.4 MB of lists against the 1.3 GB worst case.  The cost of a short workspace is the second launch
+ * (its workgroups exit on a scalar load): 0.026 ms for the 65 536 tiles of the bench batch, whose lists that do not fit cost
+ * 6.7 ms instead of 1.5 (profiles/r04/r04c8/). */
+size_t p3d_rasterize_meshes_short_workspace_bytes(int64_t F, int N, int H, int W, int bin_size, int max_faces_per_bin,
+                                                  int64_t list_entries);
+size_t p3d_rasterize_meshes_workspace_need_offset(int64_t F, int N, int H, int W, int bin_size, int max_faces_per_bin);
 
 /* replaces RasterizeMeshes, pytorch3d/csrc/rasterize_meshes/rasterize_meshes.h:513-562
  * (_C.rasterize_meshes).  bin_size == 0 or max_faces_per_bin == 0 -> naive path, else

@@ -36,6 +36,10 @@ def open_lib(path):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    for name in ("p3d_rasterize_meshes_short_workspace_bytes", "p3d_rasterize_meshes_workspace_need_offset"):  # round 4+
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = _lib._SIGNATURES[name]
     return lib
 
 
@@ -104,8 +108,12 @@ def main():
 
     product = _lib.load()
     libs = [("product", _lib.LIB_PATH, product)]
+    short = {}  # variant -> list entries of a SHORT workspace (include/p3d_amd.h): name=path@entries; 0 = 1.25 x what the batch needs
     for spec in args.variants:
         name, path = spec.split("=", 1)
+        if "@" in path:
+            path, entries = path.split("@", 1)
+            short[name] = int(entries)
         if not os.path.exists(path):
             print(f"[exp_measure] {name}: {path} missing, skipped", file=sys.stderr)
             continue
@@ -116,6 +124,18 @@ def main():
     for name, path, lib in libs:
         ws = torch.empty((int(lib.p3d_rasterize_meshes_workspace_bytes(F, B, H, H, bin_size, M)),), dtype=torch.uint8, device=d)
         out, gv = outputs(), torch.empty((V, 3), device=d)
+        ws_note = None
+        if name in short:
+            run(lib, out, gv, ws)
+            torch.cuda.synchronize()
+            at = int(lib.p3d_rasterize_meshes_workspace_need_offset(F, B, H, H, bin_size, M))
+            need = int(ws[at:at + 8].view(torch.int64)[0])
+            entries = short[name] or need + need // 4
+            worst = ws.numel()
+            del ws
+            ws = torch.empty((int(lib.p3d_rasterize_meshes_short_workspace_bytes(F, B, H, H, bin_size, M, entries)),), dtype=torch.uint8,
+                             device=d)
+            ws_note = {"needed_entries": need, "list_entries": entries, "bytes": ws.numel(), "worst_case_bytes": worst}
         for _ in range(3):
             run(lib, out, gv, ws)
         torch.cuda.synchronize()
@@ -131,6 +151,8 @@ def main():
         kern = snapshot(lib)
         rec = {"variant": name, "lib": os.path.basename(path), "ms_per_step": e0.elapsed_time(e1) / args.iters,
                "kernels_ms": {k: round(v, 4) for k, v in sorted(kern.items())}}
+        if ws_note is not None:
+            rec["short_workspace"] = ws_note
         if ref_out is None:
             ref_out, ref_gv = out, gv
         else:

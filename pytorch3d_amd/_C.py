@@ -8,6 +8,7 @@ every element), and calls the C ABI of libp3d_amd.so on torch's current HIP stre
 GPU tensors only: there is no CPU implementation and no fallback in this package.
 """
 import ctypes
+import os
 
 import torch
 
@@ -89,20 +90,83 @@ def _num_bins(H, W, bin_size, who):
 
 
 def _workspace(nbytes, device):
-    """Scratch for the coarse stage.  The C ABI sizes it for the worst case (every primitive in every bin, capped by
-    max_faces_per_bin: include/p3d_amd.h) because sizing it exactly would need a host sync; only the used prefix is touched.
-    1.3 GB at the bench batch, 42 GB for 512 meshes in one call: a request the allocator cannot serve is reported with what to
-    do about it instead of as a bare out-of-memory error."""
+    """Scratch for the coarse stage, sized by the C ABI (include/p3d_amd.h).  A request the allocator cannot serve is reported
+    with what to do about it instead of as a bare out-of-memory error."""
     n = max(int(nbytes), 256)
     try:
         return torch.empty((n,), dtype=torch.uint8, device=device)
     except RuntimeError as e:  # torch.OutOfMemoryError is a RuntimeError
         if "out of memory" not in str(e).lower():
             raise
-        raise RuntimeError(f"the coarse stage's worst-case workspace of {n / 2**30:.1f} GiB does not fit on {device}: rasterize the "
+        raise RuntimeError(f"the coarse stage's workspace of {n / 2**30:.1f} GiB does not fit on {device}: rasterize the "
                            "batch in smaller pieces (pytorch3d_amd.sharding.partition, or bench.py --jobs style sub-batches of 64 "
-                           "meshes) or pass a smaller max_faces_per_bin (the workspace is capped by N * bins * max_faces_per_bin * 4 "
-                           "bytes)") from e
+                           "meshes), pass a smaller max_faces_per_bin (the worst case is capped by N * bins * max_faces_per_bin * 4 "
+                           "bytes) or set pytorch3d_amd._C.SHORT_WORKSPACE = 'always'") from e
+
+
+# Short workspaces for rasterize_meshes (include/p3d_amd.h "Short workspaces"; csrc/binning.h).  The worst case of the bin
+# lists is 100-1000 x what a batch needs (bench batch: 1.3 GB against 8.4 MB; 512 such meshes in one call: 42 GB), and
+# what it needs is only known on the device.  With a short workspace the call sizes the lists from what the SAME call shape
+# needed before (read back asynchronously: no host sync anywhere) plus a quarter of headroom, and the library decides on
+# the device whether they fit (if not, its naive kernel writes the same bits, once; the next call has the new size).
+#   'auto'    short when the worst case is above SHORT_WORKSPACE_ABOVE bytes (the stand-by launch costs 0.026 ms on the 65 536
+#             tiles of the bench batch, 1 % of its step: profiles/r04/r04c8/measure.json)
+#   'always'  every binned call        'never'  always the worst case
+SHORT_WORKSPACE = os.environ.get("P3D_SHORT_WORKSPACE", "auto")
+SHORT_WORKSPACE_ABOVE = 2 << 30
+SHORT_WORKSPACE_FIRST_GUESS = None  # tests: list entries of a shape's first call (default 32 per face + 256k)
+WORKSPACE_STATS = {"short_calls": 0, "last_bytes": 0, "last_entries": None}
+_NEEDS = {}  # call shape -> _Need
+
+
+class _Need:
+    """What one call shape needed, refreshed from the device without ever waiting for it."""
+
+    def __init__(self):
+        self.entries = None  # list entries the last call that reported back needed
+        self.calls = 0
+        self.pinned = None
+        self.event = None
+
+    def collect(self):
+        if self.event is not None and self.event.query():
+            self.entries = int(self.pinned[0])
+            self.event = None
+
+    def report_later(self, ws, offset):
+        # the first calls of a shape report every time, later ones every 8th: an 8-byte copy is still a copy on the stream
+        self.calls += 1
+        if self.event is not None or not (self.calls <= 4 or self.calls % 8 == 0) or torch.cuda.is_current_stream_capturing():
+            return
+        if self.pinned is None:
+            self.pinned = torch.empty((1,), dtype=torch.int64, pin_memory=True)
+        self.pinned.copy_(ws[offset:offset + 8].view(torch.int64), non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+
+def _mesh_workspace(lib, F, N, H, W, bin_size, M, dev):
+    """(workspace, _Need or None, byte offset of the call's needed-entries word)."""
+    worst = lib.p3d_rasterize_meshes_workspace_bytes(F, N, H, W, bin_size, M)
+    if SHORT_WORKSPACE == "never" or (SHORT_WORKSPACE != "always" and worst <= SHORT_WORKSPACE_ABOVE):
+        WORKSPACE_STATS["last_bytes"], WORKSPACE_STATS["last_entries"] = worst, None
+        return _workspace(worst, dev), None, 0
+    key = (dev.index, F, N, H, W, bin_size, M)
+    need = _NEEDS.get(key)
+    if need is None:
+        if len(_NEEDS) >= 64:
+            _NEEDS.pop(next(iter(_NEEDS)))
+        need = _NEEDS[key] = _Need()
+    if not torch.cuda.is_current_stream_capturing():
+        need.collect()
+    if need.entries is not None:
+        entries = need.entries + need.entries // 4 + 4096
+    else:
+        entries = SHORT_WORKSPACE_FIRST_GUESS if SHORT_WORKSPACE_FIRST_GUESS is not None else 32 * F + (1 << 18)
+    nbytes = min(lib.p3d_rasterize_meshes_short_workspace_bytes(F, N, H, W, bin_size, M, int(entries)), worst)
+    WORKSPACE_STATS["short_calls"] += 1
+    WORKSPACE_STATS["last_bytes"], WORKSPACE_STATS["last_entries"] = nbytes, int(entries)
+    return _workspace(nbytes, dev), need, lib.p3d_rasterize_meshes_workspace_need_offset(F, N, H, W, bin_size, M)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -206,8 +270,7 @@ def _rasterize_meshes_covered(face_verts, mesh_to_face_first_idx, num_faces_per_
         out = _mesh_outputs(N, H, W, K, dev)
         if out[0].numel() == 0:
             return out, None
-        nbytes = lib.p3d_rasterize_meshes_workspace_bytes(F, N, H, W, bin_size, M) if binned else 0
-        ws = _workspace(nbytes, dev)
+        ws, need, need_at = _mesh_workspace(lib, F, N, H, W, bin_size, M, dev) if binned else (_workspace(0, dev), None, 0)
         cover = torch.empty((N, (H + 15) // 16, (W + 15) // 16), dtype=torch.int32, device=dev) if want_cover else None
         rc = lib.p3d_rasterize_meshes_with_cover(
             _ptr(fv), _ptr(first), _ptr(count), _ptr(nb), F, N, H, W, float(blur_radius), K, bin_size if binned else 0,
@@ -215,6 +278,8 @@ def _rasterize_meshes_covered(face_verts, mesh_to_face_first_idx, num_faces_per_
             _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _ptr(cover) if want_cover else None, _ptr(ws), ws.numel(),
             _stream(dev))
         _lib.check(rc, "rasterize_meshes")
+        if need is not None:
+            need.report_later(ws, need_at)
     return out, cover
 
 

@@ -22,6 +22,8 @@ _SIGNATURES = {
     "p3d_abi_version": (c_int, []),
     "p3d_error_string": (ctypes.c_char_p, [c_int]),
     "p3d_rasterize_meshes_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int, c_int, c_int]),
+    "p3d_rasterize_meshes_short_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int, c_int, c_int, c_i64]),
+    "p3d_rasterize_meshes_workspace_need_offset": (c_size, [c_i64, c_int, c_int, c_int, c_int, c_int]),
     "p3d_rasterize_meshes": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_f32, c_int, c_int, c_int,
                                      c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "p3d_rasterize_meshes_naive": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_f32, c_int, c_int,

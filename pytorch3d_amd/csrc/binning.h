@@ -60,7 +60,8 @@ inline BinGeom make_internal_geom(int H, int W, int user_bin_size) {
 //   bg_list[j]  the j-th background row, ascending           (j < hdr[1])
 //   order[e]    the active rows by descending list length    (e < hdr[0]; kPlanClasses classes of 8 primitives,
 //               binning.hip: plan_class), valid when hdr[3] != 0 (not written by the single-workgroup scan of small launches)
-//   hdr         {A = active rows, B = background rows, unused, order valid}, then the class counts and cursors of the sort
+//   hdr         {A = active rows, B = background rows, lists overflow the workspace (short workspaces, below), order valid},
+//               then the class counts and cursors of the sort
 // The fine rasterizers use it to walk the tiles in a balanced order (raster_mesh.hip: "Which tile") and to let the
 // workgroups of active tiles write the -1 fill of the background tiles ("piggyback fill"): active row number r fills
 // background rows [r * q, (r + 1) * q), q = ceil(B / A).
@@ -87,19 +88,28 @@ struct BinWorkspace {
   int* total;        // (N*nbins)
   int64_t* offset;   // (N*nbins + 1)
   long long* blocksum;  // (ceil(N*nbins / 1024) + 1) scratch of the offsets scan
-  int* list;         // (capacity)
   int* arank;        // (N*nbins)  TilePlan
   int* bg_list;      // (N*nbins)
   int* plan_hdr;     // (4 + 2 * kPlanClasses)
   int* order;        // (N*nbins)
+  int* list;         // (capacity) -- last, so that a short workspace shortens only this
   int64_t max_chunks;
-  int64_t capacity;
+  int64_t capacity;  // ids `list` holds
+  int64_t worst;     // bin_capacity(): the most the lists can ever need
 };
 
+// Short workspaces.  The worst case of the lists (every primitive in every bin, capped by M per bin) is 100-1000 x what a
+// real batch needs (bench batch: 1.3 GB against 8.4 MB), and the exact size is only known on the device, after the scan.
+// A caller that has a fallback for the overflow case may therefore carve with list_entries >= 0: the list gets
+// max(list_entries, what is left of the arena) ids, capped at the worst case.  The offsets scan compares the lists' total
+// with the capacity and raises plan_hdr[2]; bin_fill then writes nothing, and the caller's consumers test the flag ON THE
+// DEVICE (raster_mesh.hip: p3d_rasterize_meshes_with_cover launches the binned kernel, which returns at once when the
+// flag is up, and the naive kernel, which returns at once when it is not) -- no host sync, exact either way.  offset[rows]
+// holds the total the call needed; a caller reads it back later to size its next workspace.
 int64_t bin_capacity(int64_t E, int N, const BinGeom& g, int M);
-size_t bin_workspace_bytes(int64_t E, int N, const BinGeom& g, int M);
-// Carve `arena`; returns false when it is too small.
-bool bin_carve(Arena& arena, int64_t E, int N, const BinGeom& g, int M, BinWorkspace* ws);
+size_t bin_workspace_bytes(int64_t E, int N, const BinGeom& g, int M, int64_t list_entries = -1);
+// Carve `arena`; returns false when it is too small.  list_entries < 0: the worst case or nothing.
+bool bin_carve(Arena& arena, int64_t E, int N, const BinGeom& g, int M, BinWorkspace* ws, int64_t list_entries = -1);
 
 // Build the CSR lists.  elems: face_verts (E,3,3) or points (E,3); aux: radius (E) for points.
 // ordered = false (points only): ids inside a 1024-primitive chunk land in arrival order (integer LDS

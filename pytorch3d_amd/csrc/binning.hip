@@ -360,7 +360,7 @@ __global__ __launch_bounds__(1024) void bin_scan_offsets_kernel(const int* __res
                                                                 const long long* __restrict__ blocksum,
                                                                 int64_t* __restrict__ offset, int* __restrict__ arank,
                                                                 int* __restrict__ bg_list, int* __restrict__ plan_hdr,
-                                                                int* __restrict__ order) {
+                                                                int* __restrict__ order, int64_t capacity) {
   __shared__ long long wsum[16];
   __shared__ long long part[16];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -388,6 +388,7 @@ __global__ __launch_bounds__(1024) void bin_scan_offsets_kernel(const int* __res
     if (plan_hdr) {
       plan_hdr[0] = (int)(end >> kPlanShift);
       plan_hdr[1] = (int)(rows - (end >> kPlanShift));
+      plan_hdr[2] = (end & kPlanMask) > capacity ? 1 : 0;  // the lists do not fit the workspace (binning.h: short workspaces)
       plan_hdr[3] = order != nullptr ? 1 : 0;
     }
   }
@@ -417,7 +418,8 @@ __global__ __launch_bounds__(1024) void bin_scan_offsets_kernel(const int* __res
 __global__ __launch_bounds__(1024) void bin_scan_small_kernel(int* __restrict__ counts, const int64_t* __restrict__ count,
                                                               int N, int nbins, int M, int* __restrict__ total,
                                                               int64_t* __restrict__ offset, int* __restrict__ arank,
-                                                              int* __restrict__ bg_list, int* __restrict__ plan_hdr) {
+                                                              int* __restrict__ bg_list, int* __restrict__ plan_hdr,
+                                                              int64_t capacity) {
   __shared__ int cs[kSelfPlanMax + 1];
   if (threadIdx.x == 0) plan_hdr[3] = 0;  // no sorted order from this kernel (small launches run the split kernels)
   __shared__ long long wsum[16];
@@ -451,6 +453,7 @@ __global__ __launch_bounds__(1024) void bin_scan_small_kernel(int* __restrict__ 
     offset[rows] = carry & kPlanMask;
     plan_hdr[0] = (int)(carry >> kPlanShift);
     plan_hdr[1] = (int)(rows - (carry >> kPlanShift));
+    plan_hdr[2] = (carry & kPlanMask) > capacity ? 1 : 0;
   }
 }
 
@@ -466,7 +469,8 @@ __global__ __launch_bounds__(kBinChunk) void bin_fill_kernel(const float* __rest
                                                              int bin_size, int BH, int BW, float sqrt_blur, int M,
                                                              const int* __restrict__ counts,
                                                              const int64_t* __restrict__ offset,
-                                                             int* __restrict__ list) {
+                                                             int* __restrict__ list, const int* __restrict__ plan_hdr) {
+  if (plan_hdr[2] != 0) return;  // uniform: the lists do not fit `list` (a short workspace); the caller's fallback runs instead
   __shared__ float xlo_t[32], xhi_t[32], ylo_t[32], yhi_t[32];
   __shared__ int cs_l[kSelfPlanMax + 1];
   __shared__ unsigned short wpre[ORDERED ? kWavesPerChunk : 1][kMaxBins];  // per-wave counts, then prefixes (<= 1024)
@@ -583,26 +587,37 @@ int64_t bin_capacity(int64_t E, int N, const BinGeom& g, int M) {
   return c;
 }
 
-bool bin_carve(Arena& arena, int64_t E, int N, const BinGeom& g, int M, BinWorkspace* ws) {
+bool bin_carve(Arena& arena, int64_t E, int N, const BinGeom& g, int M, BinWorkspace* ws, int64_t list_entries) {
   ws->max_chunks = ceil_div(E, kBinChunk) + N;
-  ws->capacity = bin_capacity(E, N, g, M);
+  ws->worst = bin_capacity(E, N, g, M);
   ws->chunk_start = arena.take<int>((size_t)N + 1);
   ws->counts = arena.take<int>((size_t)ws->max_chunks * g.nbins);
   ws->total = arena.take<int>((size_t)N * g.nbins);
   ws->offset = arena.take<int64_t>((size_t)N * g.nbins + 1);
   ws->blocksum = arena.take<long long>((size_t)ceil_div((int64_t)N * g.nbins, 1024) + 1);
-  ws->list = arena.take<int>((size_t)ws->capacity);
   ws->arank = arena.take<int>((size_t)N * g.nbins);
   ws->bg_list = arena.take<int>((size_t)N * g.nbins);
   ws->plan_hdr = arena.take<int>(4 + 2 * kPlanClasses);
   ws->order = arena.take<int>((size_t)N * g.nbins);
+  // the list comes last: a caller that allows short workspaces (list_entries >= 0) gets whatever is left of the arena, at
+  // least list_entries ids and never more than the worst case
+  int64_t want = ws->worst;
+  if (list_entries >= 0) {
+    want = list_entries < 1 ? 1 : (list_entries < ws->worst ? list_entries : ws->worst);
+    if (arena.base != nullptr && arena.cap > arena.off) {
+      const int64_t room = (int64_t)((arena.cap - arena.off) / sizeof(int));
+      if (room > want) want = room < ws->worst ? room : ws->worst;
+    }
+  }
+  ws->capacity = want;
+  ws->list = arena.take<int>((size_t)want);
   return arena.ok();
 }
 
-size_t bin_workspace_bytes(int64_t E, int N, const BinGeom& g, int M) {
+size_t bin_workspace_bytes(int64_t E, int N, const BinGeom& g, int M, int64_t list_entries) {
   Arena probe(nullptr, 0);
   BinWorkspace ws;
-  bin_carve(probe, E, N, g, M, &ws);
+  bin_carve(probe, E, N, g, M, &ws, list_entries);
   return probe.off;
 }
 
@@ -633,7 +648,7 @@ int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t*
   if (small) {
     LaunchScope ls("bin_scan_small", stream);
     bin_scan_small_kernel<<<1, 1024, 0, stream>>>(ws.counts, count, N, g.nbins, M, ws.total, ws.offset, ws.arank, ws.bg_list,
-                                                  ws.plan_hdr);
+                                                  ws.plan_hdr, ws.capacity);
   } else {
     {
       LaunchScope ls("bin_scan_rows", stream);
@@ -649,22 +664,22 @@ int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t*
     const unsigned nb = (unsigned)ceil_div(rows, 1024);
     bin_block_sums_kernel<<<nb, 1024, 0, stream>>>(ws.total, rows, ws.blocksum, ws.plan_hdr);
     bin_scan_offsets_kernel<<<nb, 1024, 0, stream>>>(ws.total, rows, ws.blocksum, ws.offset, ws.arank, ws.bg_list, ws.plan_hdr,
-                                                     ws.order);
+                                                     ws.order, ws.capacity);
   }
   {
     LaunchScope ls("bin_fill", stream);
     if (kind == kTriangles)
       bin_fill_kernel<kTriangles, true><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, cs, N, g.H, g.W,
                                                                          g.bin_size, g.BH, g.BW, sqrt_blur, M, ws.counts,
-                                                                         ws.offset, ws.list);
+                                                                         ws.offset, ws.list, ws.plan_hdr);
     else if (ordered)
       bin_fill_kernel<kPoints, true><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, cs, N, g.H, g.W,
                                                                       g.bin_size, g.BH, g.BW, sqrt_blur, M, ws.counts,
-                                                                      ws.offset, ws.list);
+                                                                      ws.offset, ws.list, ws.plan_hdr);
     else
       bin_fill_kernel<kPoints, false><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, cs, N, g.H, g.W,
                                                                        g.bin_size, g.BH, g.BW, sqrt_blur, M, ws.counts,
-                                                                       ws.offset, ws.list);
+                                                                       ws.offset, ws.list, ws.plan_hdr);
   }
   return launch_status();
 }
@@ -673,7 +688,7 @@ int exclusive_scan_i32(const int* in, int64_t n, long long* blocksum, int64_t* o
   if (n <= 0) return P3D_OK;
   const unsigned nb = (unsigned)ceil_div(n, 1024);
   bin_block_sums_kernel<<<nb, 1024, 0, stream>>>(in, n, blocksum, nullptr);
-  bin_scan_offsets_kernel<<<nb, 1024, 0, stream>>>(in, n, blocksum, out, nullptr, nullptr, nullptr, nullptr);
+  bin_scan_offsets_kernel<<<nb, 1024, 0, stream>>>(in, n, blocksum, out, nullptr, nullptr, nullptr, nullptr, 0);
   return launch_status();
 }
 

@@ -66,6 +66,9 @@ struct MeshArgs {
   float* dists;
   int* cover;  // row cover of the output (include/p3d_amd.h: p3d_rasterize_meshes_with_cover), zeroed by the launcher; or null
   int CY, CX;  // its 16 x 16 pixel blocks per image
+  // short workspaces (binning.h): the device flag "the lists did not fit", or null.  A binned launch returns at once when
+  // it is up, the naive launch that follows it returns at once when it is not: exactly one of the two writes the output.
+  const int* overflow;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -756,6 +759,7 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
   // background, and the few tiles with many hundred faces -- 250-330 us each, profiles/r02_fine_timeline.txt -- start at
   // arbitrary times) some CUs idle while others queue; dealt longest-first every CU draws the same mix and the launch has no
   // tail.  Measured: 1.19 -> 1.04 ms.  Otherwise (naive path, caller's bins, split mode): the XCD-aware tile map.
+  if (a.overflow != nullptr && (*a.overflow != 0) == BINNED) return;  // uniform (scalar load)
   TileCoord tc;
   unsigned blk = SPLIT ? blockIdx.x >> 2 : blockIdx.x;
   bool listed = false;
@@ -1110,6 +1114,23 @@ P3D_API size_t p3d_rasterize_meshes_workspace_bytes(int64_t F, int N, int H, int
   return (user > internal ? user : internal) + 256;
 }
 
+P3D_API size_t p3d_rasterize_meshes_short_workspace_bytes(int64_t F, int N, int H, int W, int bin_size, int max_faces_per_bin,
+                                                          int64_t list_entries) {
+  if (bin_size <= 0 || max_faces_per_bin <= 0 || N <= 0 || H <= 0 || W <= 0 || list_entries < 0) return 0;
+  return bin_workspace_bytes(F, N, make_internal_geom(H, W, bin_size), max_faces_per_bin, list_entries) + 256;
+}
+
+P3D_API size_t p3d_rasterize_meshes_workspace_need_offset(int64_t F, int N, int H, int W, int bin_size,
+                                                          int max_faces_per_bin) {
+  if (bin_size <= 0 || max_faces_per_bin <= 0 || N <= 0 || H <= 0 || W <= 0) return 0;
+  const BinGeom g = make_internal_geom(H, W, bin_size);
+  char* const origin = reinterpret_cast<char*>((uintptr_t)1 << 20);  // never dereferenced: the carve only adds to it
+  Arena probe(origin, 0);
+  BinWorkspace ws;
+  bin_carve(probe, F, N, g, max_faces_per_bin, &ws, 1);
+  return (size_t)(reinterpret_cast<char*>(ws.offset + (size_t)N * g.nbins) - origin);
+}
+
 P3D_API size_t p3d_rasterize_fine_workspace_bytes(int N, int BH, int BW, int M) {
   const size_t rows = (size_t)N * BH * BW;
   return align_up(rows * (size_t)M * sizeof(int), 256) + align_up(rows * sizeof(int), 256) +
@@ -1134,11 +1155,11 @@ static int cover_begin(MeshArgs* a, int32_t* cover, hipStream_t s) {
 static int mesh_naive_impl(const float* face_verts, const int64_t* mesh_first, const int64_t* mesh_count,
                            const int64_t* neighbor, int64_t F, int N, int H, int W, float blur_radius, int K, int persp,
                            int clip, int cull, int64_t* p2f, float* zbuf, float* bary, float* dists, int32_t* cover,
-                           p3d_stream_t stream) {
+                           p3d_stream_t stream, const int* overflow = nullptr) {
   (void)F;
   const int rc = check_common(N, H, W, K);
   if (rc != P3D_OK) return rc;
-  if (cover != nullptr) {
+  if (cover != nullptr && overflow == nullptr) {  // (as the fallback of a binned launch: that one zeroed the cover)
     MeshArgs z{};
     z.N = N;
     z.H = H;
@@ -1170,6 +1191,7 @@ static int mesh_naive_impl(const float* face_verts, const int64_t* mesh_first, c
   a.cover = cover;  // zeroed above
   a.CY = (H + 15) / 16;
   a.CX = (W + 15) / 16;
+  a.overflow = overflow;
   set_tiles(&a, H > W ? H : W, 1, 1);
   return launch_mesh_raster<false>(a, (hipStream_t)stream);
 }
@@ -1184,7 +1206,8 @@ P3D_API int p3d_rasterize_meshes_naive(const float* face_verts, const int64_t* m
 
 static int mesh_fine_from_csr(const float* face_verts, const int64_t* neighbor, const BinCSR& csr, int N, int H, int W,
                               const BinGeom& g, float blur_radius, int K, int persp, int clip, int cull, int64_t* p2f,
-                              float* zbuf, float* bary, float* dists, hipStream_t stream, int32_t* cover = nullptr) {
+                              float* zbuf, float* bary, float* dists, hipStream_t stream, int32_t* cover = nullptr,
+                              const int* overflow = nullptr) {
   MeshArgs a{};
   a.face_verts = face_verts;
   a.neighbor = neighbor;
@@ -1204,6 +1227,7 @@ static int mesh_fine_from_csr(const float* face_verts, const int64_t* neighbor, 
   a.dists = dists;
   const int st = cover_begin(&a, cover, stream);
   if (st != P3D_OK) return st;
+  a.overflow = overflow;
   set_tiles(&a, g.bin_size, g.BH, g.BW);
   return launch_mesh_raster<true>(a, stream);
 }
@@ -1234,14 +1258,19 @@ P3D_API int p3d_rasterize_meshes_with_cover(const float* face_verts, const int64
   const BinGeom g = make_internal_geom(H, W, bin_size);  // tile-sized bins: results do not depend on the binning
   Arena arena(workspace, workspace_bytes);
   BinWorkspace ws;
-  if (!workspace || !bin_carve(arena, F, N, g, max_faces_per_bin, &ws)) return P3D_ERR_WORKSPACE;
+  // a short workspace is welcome here (binning.h): the list takes what the caller gave, and the naive kernel stands by
+  if (!workspace || !bin_carve(arena, F, N, g, max_faces_per_bin, &ws, /*list_entries=*/1)) return P3D_ERR_WORKSPACE;
+  const bool is_short = ws.capacity < ws.worst;
   hipStream_t s = (hipStream_t)stream;
   int st = bin_build(kTriangles, face_verts, nullptr, mesh_first, mesh_count, F, N, g, max_faces_per_bin,
                      sqrtf(blur_radius), ws, s);
   if (st != P3D_OK) return st;
   BinCSR csr{ws.offset, ws.total, ws.list, TilePlan{ws.arank, ws.bg_list, ws.plan_hdr, ws.order}};
-  return mesh_fine_from_csr(face_verts, neighbor, csr, N, H, W, g, blur_radius, K, persp, clip, cull, p2f, zbuf, bary,
-                            dists, s, cover);
+  st = mesh_fine_from_csr(face_verts, neighbor, csr, N, H, W, g, blur_radius, K, persp, clip, cull, p2f, zbuf, bary, dists, s,
+                          cover, is_short ? ws.plan_hdr + 2 : nullptr);
+  if (st != P3D_OK || !is_short) return st;
+  return mesh_naive_impl(face_verts, mesh_first, mesh_count, neighbor, F, N, H, W, blur_radius, K, persp, clip, cull, p2f,
+                         zbuf, bary, dists, cover, stream, ws.plan_hdr + 2);
 }
 
 P3D_API int p3d_rasterize_meshes(const float* face_verts, const int64_t* mesh_first, const int64_t* mesh_count,

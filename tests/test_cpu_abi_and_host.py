@@ -71,6 +71,18 @@ def test_library_loads_and_answers_without_a_device():
     b = lib.p3d_rasterize_meshes_workspace_bytes(20000, 4, 128, 128, 16, 1000)
     assert 0 < a <= b
     assert lib.p3d_rasterize_meshes_workspace_bytes(10000, 4, 128, 128, 0, 0) == 0
+    # short workspaces: the fixed arrays + the list entries asked for, never above the worst case; the needed-entries word
+    # lies inside the fixed part, 8-byte aligned
+    bench = (321_000, 64, 512, 512, 32, 64_200)
+    worst = lib.p3d_rasterize_meshes_workspace_bytes(*bench)
+    s0 = lib.p3d_rasterize_meshes_short_workspace_bytes(*bench, 0)
+    s1 = lib.p3d_rasterize_meshes_short_workspace_bytes(*bench, 2_100_000)
+    assert 0 < s0 < s1 < worst and s1 - s0 == pytest.approx(4 * 2_100_000, abs=512)
+    assert worst > 1.2e9 and s1 < 12e6  # the bench batch: 1.3 GB -> 11 MB
+    assert lib.p3d_rasterize_meshes_short_workspace_bytes(*bench, 1 << 40) <= worst
+    at = lib.p3d_rasterize_meshes_workspace_need_offset(*bench)
+    assert 0 < at < s0 and at % 8 == 0
+    assert lib.p3d_rasterize_meshes_short_workspace_bytes(10000, 4, 128, 128, 0, 0, 100) == 0
     assert lib.p3d_rasterize_points_workspace_bytes(10000, 2, 64, 64, 8, 100) > 0
     assert lib.p3d_rasterize_fine_workspace_bytes(2, 4, 4, 10) >= 2 * 16 * 10 * 4
     # validation that precedes any launch: K > 150, too many bins, null outputs
