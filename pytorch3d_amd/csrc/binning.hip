@@ -87,6 +87,19 @@ __device__ __forceinline__ void plan_in_lds(const int64_t* __restrict__ count, i
   __syncthreads();
 }
 
+// Number of leading entries b = 0 .. n-1 (n <= 32) for which a predicate that holds on a prefix holds.
+template <typename Pred>
+__device__ __forceinline__ int prefix_count(int n, Pred holds) {
+  int lo = 0;
+#pragma unroll
+  for (int step = 32; step >= 1; step >>= 1) {
+    const int t = lo + step;
+    const int i = (t < n ? t : n) - 1;  // (n >= 1: a launch has at least one bin per side)
+    if (t <= n && holds(i)) lo = t;
+  }
+  return lo;
+}
+
 // Shared prologue of the count and fill kernels.  chunk_start == nullptr: plan in LDS (cs_l) instead.
 template <int KIND>
 __device__ __forceinline__ bool chunk_prologue(const float* __restrict__ elems, const float* __restrict__ aux,
@@ -155,17 +168,13 @@ __device__ __forceinline__ bool chunk_prologue(const float* __restrict__ elems, 
       skip = q[2] < 0.0f;
     }
     if (!skip) {
-      // overlap(b) = (min <= hi_t[b]) && (lo_t[b] < max); both predicates are monotone in b,
-      // so the overlapping bins are the interval [#(hi_t < min), #(lo_t < max) - 1].
-      int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
-      for (int b = 0; b < BW; ++b) {
-        x0 += (xmin <= xhi_t[b]) ? 0 : 1;
-        x1 += (xlo_t[b] < xmax) ? 1 : 0;
-      }
-      for (int b = 0; b < BH; ++b) {
-        y0 += (ymin <= yhi_t[b]) ? 0 : 1;
-        y1 += (ylo_t[b] < ymax) ? 1 : 0;
-      }
+      // overlap(b) = (min <= hi_t[b]) && (lo_t[b] < max); both predicates are monotone in b (the tables ascend),
+      // so the overlapping bins are the interval [#(hi_t < min), #(lo_t < max) - 1]: four bisections of <= 32 entries
+      // (six steps each; round 4 -- a linear scan of both tables was 400 of the kernels' instructions per wave).
+      const int x0 = prefix_count(BW, [&](int b) { return !(xmin <= xhi_t[b]); });
+      int x1 = prefix_count(BW, [&](int b) { return xlo_t[b] < xmax; });
+      const int y0 = prefix_count(BH, [&](int b) { return !(ymin <= yhi_t[b]); });
+      int y1 = prefix_count(BH, [&](int b) { return ylo_t[b] < ymax; });
       x1 -= 1;
       y1 -= 1;
       if (x0 <= x1 && y0 <= y1) {
@@ -189,8 +198,33 @@ __device__ __forceinline__ bool chunk_prologue(const float* __restrict__ elems, 
   return true;
 }
 
-__device__ __forceinline__ bool rect_has(const BinRect& r, int by, int bx) {
-  return bx >= r.x0 && bx <= r.x1 && by >= r.y0 && by <= r.y1;
+// Which lanes of a wave touch bin row `by` / bin column `bx`: one ballot per row and per column of the wave's union
+// rectangle, kept in LDS (rm, cm: the wave's own 32 + 32 words).  The members of bin (by, bx) are rm[by] & cm[bx]: the
+// per-bin work needs no ballot of its own, so the LANES can take a bin each (for_union_bins) where until round 4 the whole
+// wave walked the union bin by bin -- ~100 bins x 12 instructions per pass for the 64 consecutive faces of a torus strip,
+// whose own rectangles hold ~9 bins each: 3300 instructions per wave, three quarters of them in those walks.
+__device__ __forceinline__ void wave_masks(const ChunkCtx& c, int lane, unsigned long long* rm, unsigned long long* cm) {
+  for (int by = c.u.y0; by <= c.u.y1; ++by) {
+    const unsigned long long m = __ballot(by >= c.r.y0 && by <= c.r.y1);
+    if (lane == 0) rm[by] = m;
+  }
+  for (int bx = c.u.x0; bx <= c.u.x1; ++bx) {
+    const unsigned long long m = __ballot(bx >= c.r.x0 && bx <= c.r.x1);
+    if (lane == 0) cm[bx] = m;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // same wave, in-order LDS: ordering for the compiler only
+}
+
+// f(by, bx) for every bin of the union rectangle, a lane per bin, 8 x 8 bins per step
+template <typename F>
+__device__ __forceinline__ void for_union_bins(const BinRect& u, int lane, F f) {
+  const int ly = lane >> 3, lx = lane & 7;
+  for (int ty = u.y0; ty <= u.y1; ty += 8) {
+    for (int tx = u.x0; tx <= u.x1; tx += 8) {
+      const int by = ty + ly, bx = tx + lx;
+      if (by <= u.y1 && bx <= u.x1) f(by, bx);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -207,6 +241,7 @@ __global__ __launch_bounds__(kBinChunk) void bin_count_kernel(const float* __res
   __shared__ float xlo_t[32], xhi_t[32], ylo_t[32], yhi_t[32];
   __shared__ int cs_l[kSelfPlanMax + 1];
   __shared__ int blk_cnt[kMaxBins];
+  __shared__ unsigned long long rowm[ORDERED ? kWavesPerChunk : 1][kMaxBinsSide], colm[ORDERED ? kWavesPerChunk : 1][kMaxBinsSide];
   const int nbins = BH * BW;
   for (int b = threadIdx.x; b < nbins; b += kBinChunk) blk_cnt[b] = 0;
   ChunkCtx c;
@@ -215,12 +250,14 @@ __global__ __launch_bounds__(kBinChunk) void bin_count_kernel(const float* __res
     return;
   const int lane = lane_id();
   if (ORDERED) {
-    for (int by = c.u.y0; by <= c.u.y1; ++by) {
-      for (int bx = c.u.x0; bx <= c.u.x1; ++bx) {
-        const unsigned long long m = __ballot(rect_has(c.r, by, bx));
-        if (lane == 0 && m) atomicAdd(&blk_cnt[by * BW + bx], __popcll(m));
-      }
-    }
+    const int w = threadIdx.x / kWave;
+    const unsigned long long* rm = rowm[ORDERED ? w : 0];
+    const unsigned long long* cm = colm[ORDERED ? w : 0];
+    wave_masks(c, lane, rowm[ORDERED ? w : 0], colm[ORDERED ? w : 0]);
+    for_union_bins(c.u, lane, [&](int by, int bx) {
+      const int members = __popcll(rm[by] & cm[bx]);
+      if (members) atomicAdd(&blk_cnt[by * BW + bx], members);
+    });
   } else {
     // primitives in arbitrary spatial order (point clouds): the wave's union rectangle is the whole
     // image, while each primitive touches a handful of bins -- one integer LDS atomic per (primitive, bin)
@@ -478,6 +515,7 @@ __global__ __launch_bounds__(kBinChunk) void bin_fill_kernel(const float* __rest
   // where this chunk's entries of a bin start in the list (row offset + row prefix): one coalesced read per workgroup.
   // Looked up per (primitive, bin) in the placement loop it was a dependent global round trip in every iteration.
   __shared__ int64_t dst_t[kMaxBins];
+  __shared__ unsigned long long rowm[ORDERED ? kWavesPerChunk : 1][kMaxBinsSide], colm[ORDERED ? kWavesPerChunk : 1][kMaxBinsSide];
   const int nbins = BH * BW;
   if (ORDERED)
     for (int i = threadIdx.x; i < kWavesPerChunk * kMaxBins / 2; i += kBinChunk)
@@ -508,13 +546,11 @@ __global__ __launch_bounds__(kBinChunk) void bin_fill_kernel(const float* __rest
     }
     return;
   }
-  // pass A: per-wave member counts (the prologue's barrier ordered the zero fill)
-  for (int by = c.u.y0; by <= c.u.y1; ++by) {
-    for (int bx = c.u.x0; bx <= c.u.x1; ++bx) {
-      const unsigned long long m = __ballot(rect_has(c.r, by, bx));
-      if (lane == 0) wpre[w][by * BW + bx] = (unsigned short)__popcll(m);
-    }
-  }
+  // pass A: per-wave member counts (the prologue's barrier ordered the zero fill), a lane per bin of the wave's union
+  const unsigned long long* rm = rowm[ORDERED ? w : 0];
+  const unsigned long long* cm = colm[ORDERED ? w : 0];
+  wave_masks(c, lane, rowm[ORDERED ? w : 0], colm[ORDERED ? w : 0]);
+  for_union_bins(c.u, lane, [&](int by, int bx) { wpre[w][by * BW + bx] = (unsigned short)__popcll(rm[by] & cm[bx]); });
   __syncthreads();
   // pass B: exclusive prefix over the 16 waves, seeded with this chunk's row prefix
   const int64_t row0 = (int64_t)c.n * nbins;
@@ -529,16 +565,14 @@ __global__ __launch_bounds__(kBinChunk) void bin_fill_kernel(const float* __rest
     }
   }
   __syncthreads();
-  // pass C: place
-  for (int by = c.u.y0; by <= c.u.y1; ++by) {
-    for (int bx = c.u.x0; bx <= c.u.x1; ++bx) {
-      const bool mem = rect_has(c.r, by, bx);
-      const unsigned long long m = __ballot(mem);
-      if (mem) {
-        const int b = by * BW + bx;
-        const int pos = base_t[b] + wpre[ORDERED ? w : 0][b] + mask_rank(m);
-        if (pos < M) list[dst_t[b] + pos] = (int)c.e;
-      }
+  // pass C: place -- every lane walks its OWN rectangle; its rank in a bin is the number of lower lanes among the members
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int by = c.r.y0; by <= c.r.y1; ++by) {
+    const unsigned long long mr = rm[by] & below;
+    for (int bx = c.r.x0; bx <= c.r.x1; ++bx) {
+      const int b = by * BW + bx;
+      const int pos = base_t[b] + wpre[ORDERED ? w : 0][b] + __popcll(mr & cm[bx]);
+      if (pos < M) list[dst_t[b] + pos] = (int)c.e;
     }
   }
 }
