@@ -1062,7 +1062,7 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
     P3D_LAUNCH_FINE(4, true, true, TopKPairs<4>);  // perspective + clip kernels): measured -3 % / -11 % / -10 % (profiles/r03)
   else if (K < 8)  // (2 VGPRs short of four waves per SIMD with the fill + patch epilogue: three)
     P3D_LAUNCH_FINE_W(8, 3, TopKPairs<8>);
-  else if (K == 8)
+  else if (K == 8)  // (the queue WITHOUT payload at five waves per SIMD, 81 registers: 1.36 -> 1.89 ms, profiles/r04/r04c10/k8long.txt)
     P3D_LAUNCH_FINE(8, true, true, TopKPairs<8>);
   // 9..48: queues without payload in register pairs (write_pixel_long recomputes distance and barycentrics of the survivors).
   // Five capacities; a queue serves every K up to its capacity at the cost of K entries (topk.h: TopKPairs::insert skips the

@@ -297,7 +297,11 @@ __global__ __launch_bounds__(256) void area_list_kernel(const int* __restrict__ 
 template <int KT>
 struct RowsCfg {
   static constexpr int kWaves = KT >= 16 ? 5 : 6;     // waves per SIMD the kernel is built for (512 / kWaves registers)
-  static constexpr int kSlots = KT >= 16 ? 136 : 116;  // 4 waves x kSlots x 56 B of LDS per workgroup (a multiple of 4: bucket probing)
+  // 4 waves x kSlots x 56 B of LDS per workgroup (a multiple of 4: bucket probing).  The LDS, not the 70 registers, is what
+  // holds K = 8 at six waves per SIMD: with 100 slots (seven waves) the launch measured 1.036 -> 0.98 / 1.00 ms on config 3 in
+  // two runs but 0.654 -> 0.694 on the light batch, 104 and 92 slots no change (profiles/r04/r04c10/bwd_occ*.txt): not taken.
+  // At eight waves (88 slots, 64 registers) the kernel spills and returns NaN -- the build refuses it.
+  static constexpr int kSlots = KT >= 16 ? 136 : 116;
   static constexpr int kPix = 64 / KT;                 // pixels per 64-sample step
 };
 
