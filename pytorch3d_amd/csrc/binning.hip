@@ -106,12 +106,19 @@ __device__ __forceinline__ bool chunk_prologue(const float* __restrict__ elems, 
                                                const int64_t* __restrict__ first, const int64_t* __restrict__ count,
                                                const int* chunk_start, int* cs_l, int N, int H, int W, int bin_size,
                                                int BH, int BW, float sqrt_blur, float* xlo_t, float* xhi_t,
-                                               float* ylo_t, float* yhi_t, ChunkCtx* c) {
+                                               float* ylo_t, float* yhi_t, ChunkCtx* c, int* publish_plan = nullptr,
+                                               int* plan_hdr = nullptr) {
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x;
   if (chunk_start == nullptr) {
     plan_in_lds(count, N, cs_l);
     chunk_start = cs_l;
+    // batches of up to kSelfPlanMax elements have no plan kernel (bin_build): the count pass's first workgroup leaves the
+    // chunk table for the row scan and clears the tile order's class counters, as bin_plan_kernel would have
+    if (publish_plan != nullptr && chunk == 0) {
+      if (tid <= N) publish_plan[tid] = cs_l[tid];
+      if (tid < 2 * kPlanClasses) plan_hdr[kPlanHdr + tid] = 0;
+    }
   }
   if (chunk >= chunk_start[N]) return false;
   // largest n with chunk_start[n] <= chunk
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(kBinChunk) void bin_count_kernel(const float* __res
                                                               const int64_t* __restrict__ count,
                                                               const int* chunk_start, int N, int H, int W,
                                                               int bin_size, int BH, int BW, float sqrt_blur,
-                                                              int* __restrict__ counts) {
+                                                              int* __restrict__ counts, int* publish_plan, int* plan_hdr) {
   __shared__ float xlo_t[32], xhi_t[32], ylo_t[32], yhi_t[32];
   __shared__ int cs_l[kSelfPlanMax + 1];
   __shared__ int blk_cnt[kMaxBins];
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(kBinChunk) void bin_count_kernel(const float* __res
   for (int b = threadIdx.x; b < nbins; b += kBinChunk) blk_cnt[b] = 0;
   ChunkCtx c;
   if (!chunk_prologue<KIND>(elems, aux, first, count, chunk_start, cs_l, N, H, W, bin_size, BH, BW, sqrt_blur, xlo_t,
-                            xhi_t, ylo_t, yhi_t, &c))
+                            xhi_t, ylo_t, yhi_t, &c, publish_plan, plan_hdr))
     return;
   const int lane = lane_id();
   if (ORDERED) {
@@ -275,34 +282,11 @@ __global__ __launch_bounds__(kBinChunk) void bin_count_kernel(const float* __res
 //   few chunks, many rows (a batch of meshes: 6 chunks per image and 65 536 rows at the bench workload): one THREAD per
 //     row -- neighbouring threads are neighbouring bins of one batch element, so every step reads and writes one
 //     contiguous piece of a chunk's counts per wave, and the loads of eight chunks are issued together (a wave per row
-//     kept 6 of its 64 lanes busy and gathered them at a stride of a whole counts row: 0.019 -> 0.007 ms);
+//     kept 6 of its 64 lanes busy and gathered them at a stride of a whole counts row: 0.019 -> 0.007 ms) -- since round 4
+//     in one launch with the block sums of the offsets scan (bin_scan_rows_sums_kernel, further down);
 //   many chunks, few rows (a cloud of 1M points: 977 chunks, 1024 rows): one WAVE per row, 64 chunks per step (the
 //     thread-per-row form walks the 977 chunks one after the other: 0.075 ms instead of 0.019).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bin_scan_rows_thread_kernel(int* __restrict__ counts,
-                                                                   const int* __restrict__ chunk_start, int N, int nbins,
-                                                                   int M, int* __restrict__ total) {
-  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= (int64_t)N * nbins) return;
-  const int n = (int)(row / nbins);
-  const int b = (int)(row % nbins);
-  const int c0 = chunk_start[n];
-  const int nch = chunk_start[n + 1] - c0;
-  int* p = counts + (int64_t)c0 * nbins + b;
-  int carry = 0;
-  for (int base = 0; base < nch; base += 8) {
-    int v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = base + j < nch ? p[(int64_t)(base + j) * nbins] : 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (base + j < nch) p[(int64_t)(base + j) * nbins] = carry;
-      carry += v[j];
-    }
-  }
-  total[row] = carry < M ? carry : M;
-}
-
 __global__ __launch_bounds__(256) void bin_scan_rows_kernel(int* __restrict__ counts,
                                                             const int* __restrict__ chunk_start, int N, int nbins, int M,
                                                             int* __restrict__ total) {
@@ -391,6 +375,45 @@ __global__ __launch_bounds__(1024) void bin_block_sums_kernel(const int* __restr
     __syncthreads();
     if (threadIdx.x < kPlanClasses && hist[threadIdx.x] > 0) atomicAdd(&plan_hdr[kPlanHdr + threadIdx.x], hist[threadIdx.x]);
   }
+}
+
+// The thread-per-row scan and the block sums of the offsets scan in one launch (workgroups of 1024 rows, the blocks of the
+// offsets scan): a row's total goes from the register into the block's sum and the tile order's class histogram.
+__global__ __launch_bounds__(1024) void bin_scan_rows_sums_kernel(int* __restrict__ counts, const int* __restrict__ chunk_start,
+                                                                  int N, int nbins, int M, int* __restrict__ total,
+                                                                  long long* __restrict__ blocksum, int* __restrict__ plan_hdr) {
+  __shared__ long long wsum[16];
+  __shared__ int hist[kPlanClasses];
+  const int64_t rows = (int64_t)N * nbins;
+  const int64_t row = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+  if (threadIdx.x < kPlanClasses) hist[threadIdx.x] = 0;
+  int t = 0;
+  if (row < rows) {
+    const int n = (int)(row / nbins);
+    const int b = (int)(row % nbins);
+    const int c0 = chunk_start[n];
+    const int nch = chunk_start[n + 1] - c0;
+    int* p = counts + (int64_t)c0 * nbins + b;
+    int carry = 0;
+    for (int base = 0; base < nch; base += 8) {
+      int v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = base + j < nch ? p[(int64_t)(base + j) * nbins] : 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (base + j < nch) p[(int64_t)(base + j) * nbins] = carry;
+        carry += v[j];
+      }
+    }
+    t = carry < M ? carry : M;
+    total[row] = t;
+  }
+  long long all;
+  block_exclusive_scan_1024(row < rows ? plan_pack(t) : 0, wsum, &all);  // (its barrier also orders the histogram's zero fill)
+  if (threadIdx.x == 0) blocksum[blockIdx.x] = all;
+  if (t > 0) atomicAdd(&hist[plan_class(t)], 1);
+  __syncthreads();
+  if (threadIdx.x < kPlanClasses && hist[threadIdx.x] > 0) atomicAdd(&plan_hdr[kPlanHdr + threadIdx.x], hist[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(1024) void bin_scan_offsets_kernel(const int* __restrict__ total, int64_t rows,
@@ -661,8 +684,12 @@ int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t*
   const int64_t rows = (int64_t)N * g.nbins;
   // small launches: three kernels instead of six (no plan kernel, one scan kernel) -- see bin_scan_small_kernel
   const bool small = N <= kSelfPlanMax && rows <= 4096 && ws.max_chunks <= 128;
-  const int* cs = small ? nullptr : ws.chunk_start;
-  if (!small) {
+  // up to kSelfPlanMax batch elements every count / fill workgroup derives the chunk table itself (plan_in_lds) and the
+  // count pass's first workgroup publishes it for the row scan: no plan launch (round 4; the bench batch has 64 elements)
+  const bool self_plan = N <= kSelfPlanMax;
+  const int* cs = self_plan ? nullptr : ws.chunk_start;
+  int* publish = self_plan && !small ? ws.chunk_start : nullptr;
+  if (!self_plan) {
     LaunchScope ls("bin_plan", stream);
     bin_plan_kernel<<<1, 1024, 0, stream>>>(count, N, ws.chunk_start, ws.plan_hdr);
   }
@@ -671,32 +698,33 @@ int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t*
     LaunchScope ls("bin_count", stream);
     if (kind == kTriangles)
       bin_count_kernel<kTriangles, true><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, cs, N, g.H, g.W,
-                                                                          g.bin_size, g.BH, g.BW, sqrt_blur, ws.counts);
+                                                                          g.bin_size, g.BH, g.BW, sqrt_blur, ws.counts, publish, ws.plan_hdr);
     else if (ordered)
       bin_count_kernel<kPoints, true><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, cs, N, g.H, g.W,
-                                                                       g.bin_size, g.BH, g.BW, sqrt_blur, ws.counts);
+                                                                       g.bin_size, g.BH, g.BW, sqrt_blur, ws.counts, publish, ws.plan_hdr);
     else
       bin_count_kernel<kPoints, false><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, cs, N, g.H, g.W,
-                                                                        g.bin_size, g.BH, g.BW, sqrt_blur, ws.counts);
+                                                                        g.bin_size, g.BH, g.BW, sqrt_blur, ws.counts, publish, ws.plan_hdr);
   }
   if (small) {
     LaunchScope ls("bin_scan_small", stream);
     bin_scan_small_kernel<<<1, 1024, 0, stream>>>(ws.counts, count, N, g.nbins, M, ws.total, ws.offset, ws.arank, ws.bg_list,
                                                   ws.plan_hdr, ws.capacity);
   } else {
+    const unsigned nb = (unsigned)ceil_div(rows, 1024);
+    // chunks per batch element (max_chunks = ceil(E / chunk) + N bounds their sum): see the kernels
+    const bool thread_rows = ws.max_chunks <= 32 * (int64_t)N;
     {
       LaunchScope ls("bin_scan_rows", stream);
-      // chunks per batch element (max_chunks = ceil(E / chunk) + N bounds their sum): see the two kernels
-      if (ws.max_chunks <= 32 * (int64_t)N)
-        bin_scan_rows_thread_kernel<<<(unsigned)ceil_div(rows, 256), 256, 0, stream>>>(ws.counts, ws.chunk_start, N, g.nbins,
-                                                                                       M, ws.total);
+      if (thread_rows)
+        bin_scan_rows_sums_kernel<<<nb, 1024, 0, stream>>>(ws.counts, ws.chunk_start, N, g.nbins, M, ws.total, ws.blocksum,
+                                                           ws.plan_hdr);
       else
         bin_scan_rows_kernel<<<(unsigned)ceil_div(rows, 4), 256, 0, stream>>>(ws.counts, ws.chunk_start, N, g.nbins, M,
                                                                              ws.total);
     }
     LaunchScope ls("bin_scan_offsets", stream);
-    const unsigned nb = (unsigned)ceil_div(rows, 1024);
-    bin_block_sums_kernel<<<nb, 1024, 0, stream>>>(ws.total, rows, ws.blocksum, ws.plan_hdr);
+    if (!thread_rows) bin_block_sums_kernel<<<nb, 1024, 0, stream>>>(ws.total, rows, ws.blocksum, ws.plan_hdr);
     bin_scan_offsets_kernel<<<nb, 1024, 0, stream>>>(ws.total, rows, ws.blocksum, ws.offset, ws.arank, ws.bg_list, ws.plan_hdr,
                                                      ws.order, ws.capacity);
   }
