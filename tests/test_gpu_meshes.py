@@ -188,6 +188,35 @@ def test_coarse_bins_vs_oracle():
     assert torch.equal(ours, ref)
 
 
+@pytest.mark.parametrize("N,F,size,bin_size", [(70, 2100, (32, 32), 8),     # > 64 elements: the plan kernel, thread-per-row scan
+                                               (65, 9000, (48, 40), 8),      # ragged, with empty elements
+                                               (3, 150000, (64, 64), 16),    # 49+ chunks per element: the wave-per-row scan
+                                               (64, 1900, (32, 32), 16)])    # 64 elements: count pass publishes the plan
+def test_coarse_bins_of_the_launch_shapes_of_bin_build(N, F, size, bin_size):
+    """binning.hip: bin_build picks its launches by batch size (plan kernel above 64 elements, otherwise the count pass's first
+    workgroup publishes the chunk table), by rows / chunks (single-workgroup scan for small launches) and by chunks per element
+    (thread-per-row scan fused with the block sums, or wave-per-row scan + block sums): bins vs the oracle for each shape,
+    and the fused operator (internal tile bins, tile plan) vs our own naive kernel."""
+    from pytorch3d_amd import _C
+
+    d = _dev()
+    gen = torch.Generator().manual_seed(N + F)
+    fv = U.triangle_soup(F, gen, size=0.25 if F < 100000 else 0.05, behind_every=17)
+    first, count = U.split_counts(F, N)
+    if N == 65:  # two empty elements, one of them last
+        count = count.clone()
+        count[7] = 0
+        count[64] = 0
+    M = 300
+    ref, _ = orc.rasterize_meshes_coarse(fv, first, count, size, 0.005, bin_size, M)
+    ours = _C._rasterize_meshes_coarse(fv.to(d), first.to(d), count.to(d), size, 0.005, bin_size, M).cpu()
+    assert torch.equal(ours, ref)
+    nbr = torch.full((F,), -1, dtype=torch.int64)
+    naive = _run_ours(fv, first, count, nbr, size, 0.005, 4, 0, 0, True, True, False)
+    binned = _run_ours(fv, first, count, nbr, size, 0.005, 4, bin_size, 60000, True, True, False)  # (no bin overflows at this M)
+    _assert_fwd_equal(binned, naive, tag=f"N={N} F={F}")
+
+
 def test_fine_from_user_bins_with_holes():
     """_rasterize_meshes_fine accepts -1 sentinels anywhere in bin_faces (rasterize_meshes.cu:693-697)."""
     from pytorch3d_amd import _C
