@@ -191,6 +191,13 @@ int p3d_transform_verts_backward(const float* verts_world, const int64_t* mesh_t
 /* ---- point clouds -------------------------------------------------------------------- */
 
 size_t p3d_rasterize_points_workspace_bytes(int64_t P, int N, int H, int W, int bin_size, int max_points_per_bin);
+/* Short workspaces for p3d_rasterize_points, exactly as for the meshes (above): any workspace of at least
+ * p3d_rasterize_points_short_workspace_bytes(..., 0) bytes is accepted, the lists take what is left, the device decides whether
+ * they fit and the naive kernel writes the same outputs when they do not.  (1M points, 512 x 512, max_points_per_bin = P / 5:
+ * worst case 0.8 GB for one cloud, 1.3 M entries = 5 MB needed.) */
+size_t p3d_rasterize_points_short_workspace_bytes(int64_t P, int N, int H, int W, int bin_size, int max_points_per_bin,
+                                                  int64_t list_entries);
+size_t p3d_rasterize_points_workspace_need_offset(int64_t P, int N, int H, int W, int bin_size, int max_points_per_bin);
 
 /* replaces RasterizePoints, pytorch3d/csrc/rasterize_points/rasterize_points.h:343-374 (_C.rasterize_points).
  * Outputs idxs (N,H,W,K) i32, zbuf, dists (squared) f32. */

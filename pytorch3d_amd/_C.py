@@ -104,7 +104,7 @@ def _workspace(nbytes, device):
                            "bytes) or set pytorch3d_amd._C.SHORT_WORKSPACE = 'always'") from e
 
 
-# Short workspaces for rasterize_meshes (include/p3d_amd.h "Short workspaces"; csrc/binning.h).  The worst case of the bin
+# Short workspaces for rasterize_meshes and rasterize_points (include/p3d_amd.h "Short workspaces"; csrc/binning.h).  The worst case of the bin
 # lists is 100-1000 x what a batch needs (bench batch: 1.3 GB against 8.4 MB; 512 such meshes in one call: 42 GB), and
 # what it needs is only known on the device.  With a short workspace the call sizes the lists from what the SAME call shape
 # needed before (read back asynchronously: no host sync anywhere) plus a quarter of headroom, and the library decides on
@@ -145,13 +145,16 @@ class _Need:
         self.event.record()
 
 
-def _mesh_workspace(lib, F, N, H, W, bin_size, M, dev):
-    """(workspace, _Need or None, byte offset of the call's needed-entries word)."""
-    worst = lib.p3d_rasterize_meshes_workspace_bytes(F, N, H, W, bin_size, M)
+def _mesh_workspace(lib, F, N, H, W, bin_size, M, dev, what="meshes"):
+    """(workspace, _Need or None, byte offset of the call's needed-entries word); what: "meshes" (F faces) or "points"."""
+    worst_fn = getattr(lib, f"p3d_rasterize_{what}_workspace_bytes")
+    short_fn = getattr(lib, f"p3d_rasterize_{what}_short_workspace_bytes")
+    at_fn = getattr(lib, f"p3d_rasterize_{what}_workspace_need_offset")
+    worst = worst_fn(F, N, H, W, bin_size, M)
     if SHORT_WORKSPACE == "never" or (SHORT_WORKSPACE != "always" and worst <= SHORT_WORKSPACE_ABOVE):
         WORKSPACE_STATS["last_bytes"], WORKSPACE_STATS["last_entries"] = worst, None
         return _workspace(worst, dev), None, 0
-    key = (dev.index, F, N, H, W, bin_size, M)
+    key = (what, dev.index, F, N, H, W, bin_size, M)
     need = _NEEDS.get(key)
     if need is None:
         if len(_NEEDS) >= 64:
@@ -163,10 +166,10 @@ def _mesh_workspace(lib, F, N, H, W, bin_size, M, dev):
         entries = need.entries + need.entries // 4 + 4096
     else:
         entries = SHORT_WORKSPACE_FIRST_GUESS if SHORT_WORKSPACE_FIRST_GUESS is not None else 32 * F + (1 << 18)
-    nbytes = min(lib.p3d_rasterize_meshes_short_workspace_bytes(F, N, H, W, bin_size, M, int(entries)), worst)
+    nbytes = min(short_fn(F, N, H, W, bin_size, M, int(entries)), worst)
     WORKSPACE_STATS["short_calls"] += 1
     WORKSPACE_STATS["last_bytes"], WORKSPACE_STATS["last_entries"] = nbytes, int(entries)
-    return _workspace(nbytes, dev), need, lib.p3d_rasterize_meshes_workspace_need_offset(F, N, H, W, bin_size, M)
+    return _workspace(nbytes, dev), need, at_fn(F, N, H, W, bin_size, M)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -430,12 +433,13 @@ def rasterize_points(points, cloud_to_packed_first_idx, num_points_per_cloud, im
         out = _point_outputs(N, H, W, K, dev)
         if out[0].numel() == 0:
             return out
-        nbytes = lib.p3d_rasterize_points_workspace_bytes(P, N, H, W, bin_size, M) if binned else 0
-        ws = _workspace(nbytes, dev)
+        ws, need, need_at = _mesh_workspace(lib, P, N, H, W, bin_size, M, dev, "points") if binned else (_workspace(0, dev), None, 0)
         rc = lib.p3d_rasterize_points(_ptr(pts), _ptr(first), _ptr(count), _ptr(rad), P, N, H, W, K,
                                       bin_size if binned else 0, M if binned else 0, _ptr(out[0]), _ptr(out[1]),
                                       _ptr(out[2]), _ptr(ws), ws.numel(), _stream(dev))
         _lib.check(rc, "rasterize_points")
+        if need is not None:
+            need.report_later(ws, need_at)
     return out
 
 

@@ -54,6 +54,8 @@ _SIGNATURES = {
     "p3d_transform_verts_forward": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr]),
     "p3d_transform_verts_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr]),
     "p3d_rasterize_points_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int, c_int, c_int]),
+    "p3d_rasterize_points_short_workspace_bytes": (c_size, [c_i64, c_int, c_int, c_int, c_int, c_int, c_i64]),
+    "p3d_rasterize_points_workspace_need_offset": (c_size, [c_i64, c_int, c_int, c_int, c_int, c_int]),
     "p3d_rasterize_points": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr,
                                      c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "p3d_rasterize_points_naive": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_ptr,

@@ -34,6 +34,9 @@ struct PointArgs {
   int32_t* idxs;
   float* zbuf;
   float* dists;
+  // short workspaces (binning.h): the device flag "the lists did not fit", or null.  A binned launch returns at once when it
+  // is up, the naive launch behind it returns at once when it is not (as in raster_mesh.hip: MeshArgs::overflow).
+  const int* overflow;
 };
 
 // PAYLOAD: the queue carries dist2 next to (z, idx).  Without it (long queues: 2 registers per entry instead of 3) the
@@ -52,6 +55,7 @@ __global__ __launch_bounds__(kStage, WAVES) void point_raster_kernel(PointArgs a
   __shared__ ChunkOrderScratch s_ord;
   __shared__ int s_wcnt[kStage / kWave];
 
+  if (a.overflow != nullptr && (*a.overflow != 0) == BINNED) return;  // uniform (scalar load)
   TileCoord tc;
   if (!tile_of_block(a.tm, blockIdx.x, &tc)) return;
   const int n = tc.n, by = tc.by, bx = tc.bx, ty = tc.ty, tx = tc.tx;
@@ -359,6 +363,22 @@ P3D_API size_t p3d_rasterize_points_workspace_bytes(int64_t P, int N, int H, int
   return (user > internal ? user : internal) + 256;
 }
 
+P3D_API size_t p3d_rasterize_points_short_workspace_bytes(int64_t P, int N, int H, int W, int bin_size, int max_points_per_bin,
+                                                          int64_t list_entries) {
+  if (bin_size <= 0 || max_points_per_bin <= 0 || N <= 0 || H <= 0 || W <= 0 || list_entries < 0) return 0;
+  return bin_workspace_bytes(P, N, make_internal_geom(H, W, bin_size), max_points_per_bin, list_entries) + 256;
+}
+
+P3D_API size_t p3d_rasterize_points_workspace_need_offset(int64_t P, int N, int H, int W, int bin_size, int max_points_per_bin) {
+  if (bin_size <= 0 || max_points_per_bin <= 0 || N <= 0 || H <= 0 || W <= 0) return 0;
+  const BinGeom g = make_internal_geom(H, W, bin_size);
+  char* const origin = reinterpret_cast<char*>((uintptr_t)1 << 20);  // never dereferenced: the carve only adds to it
+  Arena probe(origin, 0);
+  BinWorkspace ws;
+  bin_carve(probe, P, N, g, max_points_per_bin, &ws, 1);
+  return (size_t)(reinterpret_cast<char*>(ws.offset + (size_t)N * g.nbins) - origin);
+}
+
 P3D_API int p3d_rasterize_points_naive(const float* points, const int64_t* first, const int64_t* count,
                                        const float* radius, int64_t P, int N, int H, int W, int K, int32_t* idxs,
                                        float* zbuf, float* dists, p3d_stream_t stream) {
@@ -389,7 +409,9 @@ P3D_API int p3d_rasterize_points(const float* points, const int64_t* first, cons
   const BinGeom g = make_internal_geom(H, W, bin_size);  // tile-sized bins: results do not depend on the binning
   Arena arena(workspace, workspace_bytes);
   BinWorkspace ws;
-  if (!workspace || !bin_carve(arena, P, N, g, max_points_per_bin, &ws)) return P3D_ERR_WORKSPACE;
+  // a short workspace is welcome here (binning.h): the list takes what the caller gave, and the naive kernel stands by
+  if (!workspace || !bin_carve(arena, P, N, g, max_points_per_bin, &ws, /*list_entries=*/1)) return P3D_ERR_WORKSPACE;
+  const bool is_short = ws.capacity < ws.worst;
   hipStream_t s = (hipStream_t)stream;
   // the K nearest under (z, point index) do not depend on the order inside a bin: unordered fast binning
   int st = bin_build(kPoints, points, radius, first, count, P, N, g, max_points_per_bin, 0.0f, ws, s, /*ordered=*/false);
@@ -397,8 +419,17 @@ P3D_API int p3d_rasterize_points(const float* points, const int64_t* first, cons
   PointArgs a{};
   fill_args(&a, points, radius, N, H, W, K, idxs, zbuf, dists);
   a.csr = BinCSR{ws.offset, ws.total, ws.list, TilePlan{ws.arank, ws.bg_list, ws.plan_hdr, ws.order}};
+  a.overflow = is_short ? ws.plan_hdr + 2 : nullptr;
   set_tiles(&a, g.bin_size, g.BH, g.BW);
-  return launch_point_raster<true>(a, s);
+  st = launch_point_raster<true>(a, s);
+  if (st != P3D_OK || !is_short) return st;
+  PointArgs b{};
+  fill_args(&b, points, radius, N, H, W, K, idxs, zbuf, dists);
+  b.first = first;
+  b.count = count;
+  b.overflow = ws.plan_hdr + 2;
+  set_tiles(&b, H > W ? H : W, 1, 1);
+  return launch_point_raster<false>(b, s);
 }
 
 P3D_API int p3d_rasterize_points_coarse(const float* points, const int64_t* first, const int64_t* count,

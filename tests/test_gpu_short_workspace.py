@@ -8,6 +8,7 @@ is decided on the device (no host sync), and when they do not the naive kernel w
     the private-memory queue, split mode for a single image), with and without blur, clipping flags, culling;
   * the call after it has learned the size: its workspace is a small fraction of the worst case, its lists fit (the binned
     kernel ran: the needed-entries word equals the list total of the worst-case call) and the bits are again the same;
+  * the same for rasterize_points (every queue class of the point kernels);
   * a workspace smaller than the fixed arrays is refused with the C ABI's workspace error;
   * 'auto' leaves small batches on the worst-case workspace.
 """
@@ -106,6 +107,37 @@ def test_short_workspace_is_a_fraction_of_the_worst_case_and_auto_keeps_small_ba
         assert _C.WORKSPACE_STATS["last_entries"] is not None and _same(got, want)
     finally:
         _C.SHORT_WORKSPACE_ABOVE = above
+
+
+@pytest.mark.parametrize("K", [1, 5, 8, 10, 40, 70, 120])
+def test_points_overflowing_lists_fall_back_on_the_device_with_the_same_bits(short_mode, K):
+    """rasterize_points with a short workspace: first call with one list entry of room (the naive kernel writes), second
+    call with the learned size (the binned kernel writes): idx, zbuf and dists equal the worst-case call's, bit for bit."""
+    _C = short_mode
+    d = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(K)
+    sizes = [3000, 0, 5000]
+    P = sum(sizes)
+    pts = torch.rand((P, 3), generator=gen) * torch.tensor([2.0, 2.0, 2.0]) - torch.tensor([1.0, 1.0, -0.2])
+    pts[::97, 2] = -0.5  # some behind the camera
+    rad = torch.rand((P,), generator=gen) * 0.05 + 0.01
+    first = torch.tensor([0, sizes[0], sizes[0]], dtype=torch.int64)
+    count = torch.tensor(sizes, dtype=torch.int64)
+    args = (pts.to(d), first.to(d), count.to(d), (96, 80), rad.to(d), K, 16, 3000)
+    _C.SHORT_WORKSPACE = "never"
+    want = _C.rasterize_points(*args)
+    worst = _C.WORKSPACE_STATS["last_bytes"]
+    _C.SHORT_WORKSPACE, _C.SHORT_WORKSPACE_FIRST_GUESS = "always", 1
+    got = _C.rasterize_points(*args)
+    assert _C.WORKSPACE_STATS["last_entries"] == 1 and _C.WORKSPACE_STATS["last_bytes"] < worst
+    assert _same(got, want)
+    torch.cuda.synchronize()
+    got = _C.rasterize_points(*args)
+    need = next(iter(_C._NEEDS.values())).entries
+    assert need is not None and need > 0 and _C.WORKSPACE_STATS["last_entries"] == need + need // 4 + 4096
+    assert _same(got, want)
+    bins = _C._rasterize_points_coarse(args[0], args[1], args[2], (96, 80), args[4], 16, 3000)
+    assert need == int((bins >= 0).sum())  # 16-pixel bins are the internal ones here: the word is the lists' total
 
 
 def test_a_workspace_below_the_fixed_arrays_is_refused():
