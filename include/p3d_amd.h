@@ -142,6 +142,22 @@ int p3d_rasterize_meshes_with_cover(const float* face_verts, const int64_t* mesh
                                     int cull_backfaces, int64_t* pix_to_face, float* zbuf, float* bary, float* dists,
                                     int32_t* cover, void* workspace, size_t workspace_bytes, p3d_stream_t stream);
 
+/* CUDA tie order -- p3d_rasterize_meshes_with_cover, then a replay that makes pix_to_face (and the rows that go with it) what
+ * the reference's CUDA kernels return where faces tie EXACTLY in depth at a pixel's K-th place.  The kernels of this library keep
+ * the K nearest under the total order (depth, face index), as the reference's CPU and Python implementations do
+ * (rasterize_meshes_cpu.cpp:263-288, rasterize_meshes.py); its CUDA kernels keep an unsorted array and replace "the" farthest entry
+ * only by a strictly nearer candidate (RasterizeMeshesFineCudaKernel / CheckPixelInsideFace, rasterize_meshes.cu:112-237): the
+ * same depths, but among faces of exactly the K-th depth possibly other survivors, depending on array positions, i.e. on the
+ * pixel's whole history (2 in 10^4 entries of the bench launch; zbuf is bit-equal either way).  The replay re-runs that
+ * procedure, faces in ascending index, for every pixel whose K slots are full.  A validation mode for users who diff against CUDA
+ * renders: every pixel of a full tile evaluates the tile's whole list (~10 x the time of p3d_rasterize_meshes). */
+int p3d_rasterize_meshes_cuda_order(const float* face_verts, const int64_t* mesh_to_face_first_idx,
+                                    const int64_t* num_faces_per_mesh, const int64_t* clipped_faces_neighbor_idx, int64_t F,
+                                    int N, int H, int W, float blur_radius, int faces_per_pixel, int bin_size,
+                                    int max_faces_per_bin, int perspective_correct, int clip_barycentric_coords,
+                                    int cull_backfaces, int64_t* pix_to_face, float* zbuf, float* bary, float* dists,
+                                    int32_t* cover, void* workspace, size_t workspace_bytes, p3d_stream_t stream);
+
 /* the two backward entry points with the cover of THAT pix_to_face (null: all rows are read).  workspace (optional, may be
  * null; p3d_rasterize_meshes_backward_workspace_bytes): room for the list of covered 16 x 16 areas, so that the launch holds
  * only workgroups with work -- workgroups reach the CUs round robin, and a mix of empty and full ones leaves CUs idle. */

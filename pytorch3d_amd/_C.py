@@ -175,6 +175,13 @@ def _mesh_workspace(lib, F, N, H, W, bin_size, M, dev, what="meshes"):
 # ----------------------------------------------------------------------------------------------
 # meshes
 # ----------------------------------------------------------------------------------------------
+# CUDA tie order (include/p3d_amd.h: p3d_rasterize_meshes_cuda_order).  False: the K nearest faces of a pixel under the total
+# order (depth, face index), as the reference's CPU and Python implementations return them.  True: where faces tie EXACTLY in
+# depth at the K-th place, the survivors the reference's CUDA kernels keep (bit-identical pix_to_face to a CUDA render; ~10 x
+# the forward's time -- a validation mode).  Also: P3D_CUDA_TIE_ORDER=1 in the environment.
+CUDA_TIE_ORDER = os.environ.get("P3D_CUDA_TIE_ORDER", "0") not in ("", "0")
+
+
 def _check_face_verts(face_verts):
     if not (face_verts.dim() == 3 and face_verts.size(1) == 3 and face_verts.size(2) == 3):
         raise RuntimeError("face_verts must have dimensions (num_faces, 3, 3)")
@@ -275,7 +282,8 @@ def _rasterize_meshes_covered(face_verts, mesh_to_face_first_idx, num_faces_per_
             return out, None
         ws, need, need_at = _mesh_workspace(lib, F, N, H, W, bin_size, M, dev) if binned else (_workspace(0, dev), None, 0)
         cover = torch.empty((N, (H + 15) // 16, (W + 15) // 16), dtype=torch.int32, device=dev) if want_cover else None
-        rc = lib.p3d_rasterize_meshes_with_cover(
+        entry = lib.p3d_rasterize_meshes_cuda_order if CUDA_TIE_ORDER else lib.p3d_rasterize_meshes_with_cover
+        rc = entry(
             _ptr(fv), _ptr(first), _ptr(count), _ptr(nb), F, N, H, W, float(blur_radius), K, bin_size if binned else 0,
             M if binned else 0, int(bool(perspective_correct)), int(bool(clip_barycentric_coords)), int(bool(cull_backfaces)),
             _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _ptr(cover) if want_cover else None, _ptr(ws), ws.numel(),

@@ -42,6 +42,9 @@ _SIGNATURES = {
     "p3d_rasterize_meshes_with_cover": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_f32, c_int, c_int,
                                                 c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size,
                                                 c_ptr]),
+    "p3d_rasterize_meshes_cuda_order": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_f32, c_int, c_int,
+                                                c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size,
+                                                c_ptr]),
     "p3d_rasterize_meshes_backward_workspace_bytes": (c_size, [c_int, c_int, c_int]),
     "p3d_rasterize_meshes_backward_with_cover": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int,
                                                          c_int, c_int, c_int, c_ptr, c_ptr, c_size, c_ptr]),

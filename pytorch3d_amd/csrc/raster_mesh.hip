@@ -998,6 +998,142 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// CUDA tie order (p3d_rasterize_meshes_cuda_order).  The kernels above keep the K nearest faces of a pixel under the total
+// order (z, face index) -- what the reference's CPU and Python implementations return.  Its CUDA kernels return the same
+// depths but, where faces tie EXACTLY in depth at the K-th place, possibly other faces: they keep an unsorted array, replace
+// "the" largest entry only by a strictly nearer candidate, and which of several equally far entries is "the" largest depends
+// on the array positions, i.e. on the whole history of the pixel (rasterize_meshes.cu:216-237; the final sort is by (z, index):
+// rasterize_meshes.cu:30-32, so only the survivors differ, never the order).  2 in 10^4 entries of the bench launch.  For users
+// who diff against CUDA renders this kernel REPLAYS the reference's procedure, faces in ascending index, for every pixel whose
+// queue came out full (a pixel with fewer than K hits has dropped nothing: both procedures return all of its hits) and
+// overwrites its rows.  Same per-(pixel, face) functions as everywhere else (p3d_geom.h: face_setup, face_hit): same bits.
+// A validation mode, not a fast path: every lane evaluates its tile's whole list (~10 x the fine kernel's time).
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool BINNED>
+__global__ __launch_bounds__(kStage) void mesh_cuda_order_kernel(MeshArgs a) {
+  if (a.overflow != nullptr && (*a.overflow != 0) == BINNED) return;  // short workspaces: as in mesh_raster_kernel
+  TileCoord tc;
+  if (!tile_of_block(a.tm, blockIdx.x, &tc)) return;
+  const int n = tc.n, H = a.H, W = a.W, K = a.K;
+  const int y_end = min(H, (tc.by + 1) * a.tm.bin_size), x_end = min(W, (tc.bx + 1) * a.tm.bin_size);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int yi = tc.by * a.tm.bin_size + tc.ty * kTile + (w >> 1) * 8 + (lane >> 3);
+  const int xi = tc.bx * a.tm.bin_size + tc.tx * kTile + (w & 1) * 8 + (lane & 7);
+  const bool pix_ok = yi < y_end && xi < x_end;
+  const int64_t opix = ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi);
+  const bool replay = pix_ok && K > 0 && a.p2f[opix * K + (K - 1)] >= 0;
+  if (__ballot(replay) == 0) return;  // uniform
+  int64_t src;
+  int count;
+  if (BINNED) {
+    const int64_t row = ((int64_t)n * a.tm.BH + tc.by) * a.tm.BW + tc.bx;
+    src = a.csr.offset[row];
+    count = a.csr.total[row];
+  } else {
+    src = a.mesh_first[n];
+    count = (int)a.mesh_count[n];
+  }
+  const f2 p = mk2(pix_to_ndc(xi, W, H), pix_to_ndc(yi, H, W));
+  const bool persp = a.persp != 0, clip = a.clip != 0, cull = a.cull != 0;
+  auto verts = [&](int f, f3* v0, f3* v1, f3* v2) {
+    const float* g = a.face_verts + (int64_t)f * 9;
+    *v0 = mk3(g[0], g[1], g[2]);
+    *v1 = mk3(g[3], g[4], g[5]);
+    *v2 = mk3(g[6], g[7], g[8]);
+  };
+  // the reference's array (rasterize_meshes.cu:291-294), depths and indices only: distance and barycentrics of the K
+  // survivors are recomputed at the end
+  float qz[P3D_MAX_K];
+  int qi[P3D_MAX_K];
+  int qn = 0, qmax_i = -1;
+  float qmax_z = -1000.0f;
+  for (int i = 0; i < count; ++i) {
+    const int f = BINNED ? a.csr.list[src + i] : (int)(src + i);  // uniform
+    f3 v0, v1, v2;
+    verts(f, &v0, &v1, &v2);
+    const FaceSetup fs = face_setup(v0, v1, v2, a.sqrt_blur, cull);
+    if (fs.reject) continue;  // uniform
+    FaceHit h;
+    if (!replay || outside_box(fs, p) || !face_hit(v0, v1, v2, p, a.blur, persp, clip, &h)) continue;
+    const int64_t nb = a.neighbor[f];
+    int at = -1;
+    if (nb != -1) {
+      for (int j = 0; j < qn; ++j) {
+        if (qi[j] == (int)nb) {
+          at = j;
+          break;
+        }
+      }
+    }
+    if (at != -1) {
+      // the clipped-face rule (rasterize_meshes.cu:186-213): the nearer of the two halves keeps the slot -- in place
+      f3 n0, n1, n2;
+      verts((int)nb, &n0, &n1, &n2);
+      FaceHit hn;
+      face_hit(n0, n1, n2, p, a.blur, persp, clip, &hn);
+      if (fabsf(h.dist) < fabsf(hn.dist)) {
+        qz[at] = h.z;
+        qi[at] = f;
+        if (h.z > qmax_z) {
+          qmax_z = h.z;
+          qmax_i = at;
+        }
+      }
+    } else if (qn < K) {
+      qz[qn] = h.z;
+      qi[qn] = f;
+      if (h.z > qmax_z) {
+        qmax_z = h.z;
+        qmax_i = qn;
+      }
+      ++qn;
+    } else if (h.z < qmax_z) {
+      qz[qmax_i] = h.z;
+      qi[qmax_i] = f;
+      qmax_z = h.z;
+      for (int j = 0; j < K; ++j) {
+        if (qz[j] > qmax_z) {
+          qmax_z = qz[j];
+          qmax_i = j;
+        }
+      }
+    }
+  }
+  if (!replay) return;
+  // ascending (z, index): insertion sort of the <= K entries (rasterize_meshes.cu:30-32, rasterization_utils.cuh:54-66)
+  for (int i = 1; i < qn; ++i) {
+    const float z = qz[i];
+    const int f = qi[i];
+    int j = i - 1;
+    while (j >= 0 && (qz[j] > z || (qz[j] == z && qi[j] > f))) {
+      qz[j + 1] = qz[j];
+      qi[j + 1] = qi[j];
+      --j;
+    }
+    qz[j + 1] = z;
+    qi[j + 1] = f;
+  }
+  for (int k = 0; k < K; ++k) {
+    const int64_t o = opix * K + k;
+    if (k < qn) {
+      f3 v0, v1, v2;
+      verts(qi[k], &v0, &v1, &v2);
+      FaceHit h;
+      face_hit(v0, v1, v2, p, a.blur, persp, clip, &h);
+      a.p2f[o] = qi[k];
+      a.zbuf[o] = h.z;
+      a.dists[o] = h.dist;
+      a.bary[3 * o] = h.bary.x;
+      a.bary[3 * o + 1] = h.bary.y;
+      a.bary[3 * o + 2] = h.bary.z;
+    } else {
+      a.p2f[o] = -1;
+      a.zbuf[o] = a.dists[o] = a.bary[3 * o] = a.bary[3 * o + 1] = a.bary[3 * o + 2] = -1.0f;
+    }
+  }
+}
+
 // The instantiations one (Queue, K) pair can run as: split (few tiles), compile-time persp & clip, or plain.
 template <typename Q, int KT, bool REGS, bool BINNED, bool EXACT>
 void launch_fine_variant(const MeshArgs& a, unsigned grid, bool split, size_t dyn_lds, hipStream_t stream) {
@@ -1232,25 +1368,67 @@ static int mesh_fine_from_csr(const float* face_verts, const int64_t* neighbor, 
   return launch_mesh_raster<true>(a, stream);
 }
 
-P3D_API int p3d_rasterize_meshes_with_cover(const float* face_verts, const int64_t* mesh_first, const int64_t* mesh_count,
-                                            const int64_t* neighbor, int64_t F, int N, int H, int W, float blur_radius,
-                                            int K, int bin_size, int max_faces_per_bin, int persp, int clip, int cull,
-                                            int64_t* p2f, float* zbuf, float* bary, float* dists, int32_t* cover,
-                                            void* workspace, size_t workspace_bytes, p3d_stream_t stream) {
+// the replay of p3d_rasterize_meshes_cuda_order over the outputs of the launches before it; csr: the bin lists (null: every
+// face of the pixel's mesh), overflow: the short-workspace flag the launch obeys (or null)
+static int cuda_order_replay(const float* face_verts, const int64_t* mesh_first, const int64_t* mesh_count,
+                             const int64_t* neighbor, const BinCSR* csr, const BinGeom* g, int N, int H, int W, float blur_radius,
+                             int K, int persp, int clip, int cull, int64_t* p2f, float* zbuf, float* bary, float* dists,
+                             const int* overflow, hipStream_t s) {
+  MeshArgs a{};
+  a.face_verts = face_verts;
+  a.neighbor = neighbor;
+  a.mesh_first = mesh_first;
+  a.mesh_count = mesh_count;
+  a.N = N;
+  a.H = H;
+  a.W = W;
+  a.K = K;
+  a.blur = blur_radius;
+  a.sqrt_blur = sqrtf(blur_radius);
+  a.persp = persp;
+  a.clip = clip;
+  a.cull = cull;
+  a.p2f = p2f;
+  a.zbuf = zbuf;
+  a.bary = bary;
+  a.dists = dists;
+  a.overflow = overflow;
+  LaunchScope ls("mesh_cuda_order", s);
+  if (csr != nullptr) {
+    a.csr = *csr;
+    set_tiles(&a, g->bin_size, g->BH, g->BW);
+    mesh_cuda_order_kernel<true><<<tile_grid(a.tm), kStage, 0, s>>>(a);
+  } else {
+    set_tiles(&a, H > W ? H : W, 1, 1);
+    mesh_cuda_order_kernel<false><<<tile_grid(a.tm), kStage, 0, s>>>(a);
+  }
+  return launch_status();
+}
+
+static int raster_meshes_impl(const float* face_verts, const int64_t* mesh_first, const int64_t* mesh_count,
+                              const int64_t* neighbor, int64_t F, int N, int H, int W, float blur_radius, int K, int bin_size,
+                              int max_faces_per_bin, int persp, int clip, int cull, int64_t* p2f, float* zbuf, float* bary,
+                              float* dists, int32_t* cover, void* workspace, size_t workspace_bytes, p3d_stream_t stream,
+                              bool cuda_order) {
+  hipStream_t s = (hipStream_t)stream;
+  const bool any_output = (int64_t)N * H * W * K != 0;
   if (bin_size <= 0 || max_faces_per_bin <= 0) {
-    return mesh_naive_impl(face_verts, mesh_first, mesh_count, neighbor, F, N, H, W, blur_radius, K, persp, clip, cull,
-                           p2f, zbuf, bary, dists, cover, stream);
+    const int st = mesh_naive_impl(face_verts, mesh_first, mesh_count, neighbor, F, N, H, W, blur_radius, K, persp, clip, cull,
+                                   p2f, zbuf, bary, dists, cover, stream);
+    if (st != P3D_OK || !cuda_order || !any_output) return st;
+    return cuda_order_replay(face_verts, mesh_first, mesh_count, neighbor, nullptr, nullptr, N, H, W, blur_radius, K, persp, clip,
+                             cull, p2f, zbuf, bary, dists, nullptr, s);
   }
   const int rc = check_common(N, H, W, K);
   if (rc != P3D_OK) return rc;
-  if (cover != nullptr && (int64_t)N * H * W * K == 0) {
+  if (cover != nullptr && !any_output) {
     MeshArgs z{};
     z.N = N;
     z.H = H;
     z.W = W;
-    return cover_begin(&z, cover, (hipStream_t)stream);
+    return cover_begin(&z, cover, s);
   }
-  if ((int64_t)N * H * W * K == 0) return P3D_OK;
+  if (!any_output) return P3D_OK;
   if ((!face_verts || !neighbor) && F > 0) return P3D_ERR_INVALID_ARG;
   if (!mesh_first || !mesh_count || !p2f || !zbuf || !bary || !dists) return P3D_ERR_INVALID_ARG;
   const BinGeom gu = make_geom(H, W, bin_size);
@@ -1261,16 +1439,40 @@ P3D_API int p3d_rasterize_meshes_with_cover(const float* face_verts, const int64
   // a short workspace is welcome here (binning.h): the list takes what the caller gave, and the naive kernel stands by
   if (!workspace || !bin_carve(arena, F, N, g, max_faces_per_bin, &ws, /*list_entries=*/1)) return P3D_ERR_WORKSPACE;
   const bool is_short = ws.capacity < ws.worst;
-  hipStream_t s = (hipStream_t)stream;
+  const int* overflow = is_short ? ws.plan_hdr + 2 : nullptr;
   int st = bin_build(kTriangles, face_verts, nullptr, mesh_first, mesh_count, F, N, g, max_faces_per_bin,
                      sqrtf(blur_radius), ws, s);
   if (st != P3D_OK) return st;
   BinCSR csr{ws.offset, ws.total, ws.list, TilePlan{ws.arank, ws.bg_list, ws.plan_hdr, ws.order}};
   st = mesh_fine_from_csr(face_verts, neighbor, csr, N, H, W, g, blur_radius, K, persp, clip, cull, p2f, zbuf, bary, dists, s,
-                          cover, is_short ? ws.plan_hdr + 2 : nullptr);
+                          cover, overflow);
+  if (st == P3D_OK && is_short)
+    st = mesh_naive_impl(face_verts, mesh_first, mesh_count, neighbor, F, N, H, W, blur_radius, K, persp, clip, cull, p2f, zbuf,
+                         bary, dists, cover, stream, overflow);
+  if (st != P3D_OK || !cuda_order) return st;
+  st = cuda_order_replay(face_verts, mesh_first, mesh_count, neighbor, &csr, &g, N, H, W, blur_radius, K, persp, clip, cull, p2f,
+                         zbuf, bary, dists, overflow, s);
   if (st != P3D_OK || !is_short) return st;
-  return mesh_naive_impl(face_verts, mesh_first, mesh_count, neighbor, F, N, H, W, blur_radius, K, persp, clip, cull, p2f,
-                         zbuf, bary, dists, cover, stream, ws.plan_hdr + 2);
+  return cuda_order_replay(face_verts, mesh_first, mesh_count, neighbor, nullptr, nullptr, N, H, W, blur_radius, K, persp, clip,
+                           cull, p2f, zbuf, bary, dists, overflow, s);
+}
+
+P3D_API int p3d_rasterize_meshes_with_cover(const float* face_verts, const int64_t* mesh_first, const int64_t* mesh_count,
+                                            const int64_t* neighbor, int64_t F, int N, int H, int W, float blur_radius,
+                                            int K, int bin_size, int max_faces_per_bin, int persp, int clip, int cull,
+                                            int64_t* p2f, float* zbuf, float* bary, float* dists, int32_t* cover,
+                                            void* workspace, size_t workspace_bytes, p3d_stream_t stream) {
+  return raster_meshes_impl(face_verts, mesh_first, mesh_count, neighbor, F, N, H, W, blur_radius, K, bin_size, max_faces_per_bin,
+                            persp, clip, cull, p2f, zbuf, bary, dists, cover, workspace, workspace_bytes, stream, false);
+}
+
+P3D_API int p3d_rasterize_meshes_cuda_order(const float* face_verts, const int64_t* mesh_first, const int64_t* mesh_count,
+                                            const int64_t* neighbor, int64_t F, int N, int H, int W, float blur_radius,
+                                            int K, int bin_size, int max_faces_per_bin, int persp, int clip, int cull,
+                                            int64_t* p2f, float* zbuf, float* bary, float* dists, int32_t* cover,
+                                            void* workspace, size_t workspace_bytes, p3d_stream_t stream) {
+  return raster_meshes_impl(face_verts, mesh_first, mesh_count, neighbor, F, N, H, W, blur_radius, K, bin_size, max_faces_per_bin,
+                            persp, clip, cull, p2f, zbuf, bary, dists, cover, workspace, workspace_bytes, stream, true);
 }
 
 P3D_API int p3d_rasterize_meshes(const float* face_verts, const int64_t* mesh_first, const int64_t* mesh_count,

@@ -84,6 +84,9 @@ def test_full_bench_batch_forward_and_backward_vs_reference_device_kernels(torus
     assert bad_d == 0 and bad_b == 0
     assert unexplained == 0
     assert n_idx <= 1e-3 * total  # observed: 1.7e-4 (torus_div 1.5); all of them at exact depth ties (asserted above)
+    # (With `_C.CUDA_TIE_ORDER` our survivors at exact ties are those of the reference's procedure on faces in ascending index --
+    # equal to its NAIVE device kernel bit for bit, tests/test_gpu_vs_reference_device_kernels.py; its binned path, compared here,
+    # orders a bin's faces across 512-face chunks by atomicAdd arrival, rasterize_coarse.cu:185, and is not a fixed target at ties.)
     del theirs, tie, same
     torch.cuda.empty_cache()
 

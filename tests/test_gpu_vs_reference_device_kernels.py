@@ -102,6 +102,88 @@ def test_small_soups_bit_equal_to_reference_device_code(persp, clip, cull):
         _assert_equal_up_to_exact_depth_ties(f"soup {size} blur {blur} bin {bs}", ours, theirs)
 
 
+@pytest.fixture
+def cuda_tie_order():
+    from pytorch3d_amd import _C
+
+    saved = _C.CUDA_TIE_ORDER
+    _C.CUDA_TIE_ORDER = True
+    yield _C
+    _C.CUDA_TIE_ORDER = saved
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 8, 12, 20, 60])
+def test_cuda_tie_order_is_the_references_device_result_where_depths_tie_exactly(cuda_tie_order, K):
+    """`_C.CUDA_TIE_ORDER` (include/p3d_amd.h: p3d_rasterize_meshes_cuda_order): a soup in which every face exists three times
+    (exact depth ties at every sample, at every place of the queue) and every eighth face has a clipped-face neighbour: with the
+    switch on, ALL FOUR outputs equal the reference's device kernels bit for bit -- naive and binned, three flag sets; with it
+    off the indices differ (the test has teeth).  270 faces: ONE 512-face chunk of the reference's coarse stage, whose bins
+    are then in ascending face order -- see the next test."""
+    _C = cuda_tie_order
+    mod = _need(True)
+    gen = torch.Generator().manual_seed(100 + K)
+    base = U.triangle_soup(90, gen, behind_every=13)
+    order = torch.randperm(270, generator=gen)
+    fv = base.repeat(3, 1, 1)[order].contiguous()  # copies of a face at scattered indices
+    F = fv.shape[0]
+    nbr = torch.full((F,), -1, dtype=torch.int64)
+    for a in range(0, F - 1, 8):
+        nbr[a], nbr[a + 1] = a + 1, a
+    first, count = U.split_counts(F, 2)
+    differed = 0
+    for (size, blur, bs), (persp, clip, cull) in zip((((40, 40), 0.01, 0), ((64, 48), 0.004, 16), ((33, 70), 0.0, 8)),
+                                                     ((True, True, False), (False, False, False), (True, False, True))):
+        _C.CUDA_TIE_ORDER = True
+        ours, theirs = _both(mod, fv, first, count, nbr, size, blur, K, bs, 400 if bs else 0, persp, clip, cull)
+        assert torch.equal(ours[0], theirs[0]), f"K={K} {size} bin {bs}: {int((ours[0] != theirs[0]).sum())} indices differ"
+        for name, x, y in zip(("zbuf", "bary", "dists"), ours[1:], theirs[1:]):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32)), f"K={K} {size} bin {bs}: {name}"
+        _C.CUDA_TIE_ORDER = False
+        plain, _ = _both(mod, fv, first, count, nbr, size, blur, K, bs, 400 if bs else 0, persp, clip, cull)
+        differed += int((plain[0] != theirs[0]).sum())
+    if K <= 8:  # (beyond: few pixels of this soup collect K hits)
+        assert differed > 0, "the soup was meant to hold boundary ties"
+
+
+def test_cuda_tie_order_on_bench_meshes_equals_the_references_naive_device_kernel(cuda_tie_order):
+    """Two meshes of the bench batch (config 3 as written) at 512^2, K = 8: our binned launch with the CUDA tie order against the
+    reference's NAIVE device kernel (every pixel walks its mesh's faces in ascending index, rasterize_meshes.cu:300-320) -- all
+    four outputs bit-equal.  The reference's BINNED device path is not a fixed target at ties: its coarse stage appends the
+    faces of each 512-face chunk to a bin at an offset taken with atomicAdd (rasterize_coarse.cu:185), so the order of a bin's
+    faces across chunks, and with it which of several equally deep faces survives at the K-th place, is whatever order the
+    chunks' workgroups arrived in; the count of entries in which the reference's own two paths differ is printed."""
+    _C = cuda_tie_order
+    mod = _need(True)
+    verts, faces = U.hetero_batch(64, seed=0, torus_div=U.CONFIG3_TORUS_DIV)
+    nf = [int(f.shape[0]) for f in faces]
+    order = sorted(range(64), key=lambda i: nf[i])
+    pick = [order[40], order[20]]
+    from pytorch3d_amd import PackedMeshes
+
+    m = PackedMeshes([verts[i] for i in pick], [faces[i] for i in pick])
+    fv = m.verts_packed()[m.faces_packed()].contiguous()
+    first, count = m.mesh_to_faces_packed_first_idx(), m.num_faces_per_mesh()
+    F = fv.shape[0]
+    nbr = torch.full((F,), -1, dtype=torch.int64)
+    d = _d()
+    dev = [t.to(d) for t in (fv, first, count, nbr)]
+    M = int(max(10000, F / 5))
+    ours = _C.rasterize_meshes(*dev, (512, 512), SOFTRAS_BLUR, 8, 32, M, True, True, False)
+    naive = mod.rasterize_meshes(*dev, (512, 512), SOFTRAS_BLUR, 8, 0, 0, True, True, False)
+    binned = mod.rasterize_meshes(*dev, (512, 512), SOFTRAS_BLUR, 8, 32, M, True, True, False)
+    torch.cuda.synchronize()
+    _C.CUDA_TIE_ORDER = False
+    plain = _C.rasterize_meshes(*dev, (512, 512), SOFTRAS_BLUR, 8, 32, M, True, True, False)
+    n = ours[0].numel()
+    print(f"[bench meshes {[nf[i] for i in pick]} faces, 512^2, K=8] pix_to_face entries differing from the reference's naive device "
+          f"kernel: ours with the (z, index) order {int((plain[0] != naive[0]).sum())}, ours with the CUDA tie order "
+          f"{int((ours[0] != naive[0]).sum())}, the reference's own binned path {int((binned[0] != naive[0]).sum())} (of {n})")
+    assert torch.equal(ours[0], naive[0])
+    for x, y in zip(ours[1:], naive[1:]):
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    assert int((plain[0] != naive[0]).sum()) > 0  # the ties are there
+
+
 def test_cow_and_bench_meshes_bit_equal_to_reference_device_code():
     mod = _need(True)
     g = np.load(os.path.join(U.GOLDEN, "cow_ref.npz"))
