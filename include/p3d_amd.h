@@ -222,6 +222,15 @@ int p3d_rasterize_points(const float* points, const int64_t* cloud_to_packed_fir
                          int points_per_pixel, int bin_size, int max_points_per_bin, int32_t* idxs, float* zbuf,
                          float* dists, void* workspace, size_t workspace_bytes, p3d_stream_t stream);
 
+/* p3d_rasterize_points, then the CUDA tie order (see p3d_rasterize_meshes_cuda_order): the reference's point kernels keep the same
+ * unsorted array (rasterize_points.cu:38-84) and sort it by depth ALONE (rasterize_points.cu:26-28, stable): where points tie
+ * exactly in depth, the survivors at the K-th place and the order of the tied entries follow the array positions.  The replay
+ * re-runs that procedure, points in ascending index, for every pixel whose K slots are full. */
+int p3d_rasterize_points_cuda_order(const float* points, const int64_t* cloud_to_packed_first_idx,
+                                    const int64_t* num_points_per_cloud, const float* radius, int64_t P, int N, int H, int W,
+                                    int points_per_pixel, int bin_size, int max_points_per_bin, int32_t* idxs, float* zbuf,
+                                    float* dists, void* workspace, size_t workspace_bytes, p3d_stream_t stream);
+
 /* replaces RasterizePointsNaive, rasterize_points.h:70-99 (_C._rasterize_points_naive). */
 int p3d_rasterize_points_naive(const float* points, const int64_t* cloud_to_packed_first_idx,
                                const int64_t* num_points_per_cloud, const float* radius, int64_t P, int N, int H, int W,

@@ -178,7 +178,8 @@ def _mesh_workspace(lib, F, N, H, W, bin_size, M, dev, what="meshes"):
 # CUDA tie order (include/p3d_amd.h: p3d_rasterize_meshes_cuda_order).  False: the K nearest faces of a pixel under the total
 # order (depth, face index), as the reference's CPU and Python implementations return them.  True: where faces tie EXACTLY in
 # depth at the K-th place, the survivors the reference's CUDA kernels keep (bit-identical pix_to_face to a CUDA render; ~10 x
-# the forward's time -- a validation mode).  Also: P3D_CUDA_TIE_ORDER=1 in the environment.
+# the forward's time -- a validation mode).  rasterize_points obeys it too (there the reference's CUDA kernels also ORDER tied
+# entries by array position: rasterize_points.cu:26-28).  Also: P3D_CUDA_TIE_ORDER=1 in the environment.
 CUDA_TIE_ORDER = os.environ.get("P3D_CUDA_TIE_ORDER", "0") not in ("", "0")
 
 
@@ -442,9 +443,9 @@ def rasterize_points(points, cloud_to_packed_first_idx, num_points_per_cloud, im
         if out[0].numel() == 0:
             return out
         ws, need, need_at = _mesh_workspace(lib, P, N, H, W, bin_size, M, dev, "points") if binned else (_workspace(0, dev), None, 0)
-        rc = lib.p3d_rasterize_points(_ptr(pts), _ptr(first), _ptr(count), _ptr(rad), P, N, H, W, K,
-                                      bin_size if binned else 0, M if binned else 0, _ptr(out[0]), _ptr(out[1]),
-                                      _ptr(out[2]), _ptr(ws), ws.numel(), _stream(dev))
+        entry = lib.p3d_rasterize_points_cuda_order if CUDA_TIE_ORDER else lib.p3d_rasterize_points
+        rc = entry(_ptr(pts), _ptr(first), _ptr(count), _ptr(rad), P, N, H, W, K, bin_size if binned else 0, M if binned else 0,
+                   _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(ws), ws.numel(), _stream(dev))
         _lib.check(rc, "rasterize_points")
         if need is not None:
             need.report_later(ws, need_at)

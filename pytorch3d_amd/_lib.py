@@ -61,6 +61,8 @@ _SIGNATURES = {
     "p3d_rasterize_points_workspace_need_offset": (c_size, [c_i64, c_int, c_int, c_int, c_int, c_int]),
     "p3d_rasterize_points": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr,
                                      c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "p3d_rasterize_points_cuda_order": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr,
+                                                c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "p3d_rasterize_points_naive": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_ptr,
                                            c_ptr, c_ptr]),
     "p3d_rasterize_points_coarse": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_int, c_ptr,

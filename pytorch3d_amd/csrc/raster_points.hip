@@ -270,6 +270,97 @@ int launch_point_raster(const PointArgs& a, hipStream_t stream) {
 
 void set_tiles(PointArgs* a, int bin_size, int BH, int BW) { a->tm = make_tile_map(a->N, a->H, a->W, bin_size, BH, BW, true); }
 
+// CUDA tie order for points (p3d_rasterize_points_cuda_order; see raster_mesh.hip: mesh_cuda_order_kernel for the meshes).  The
+// reference's point kernels keep the same unsorted array as its mesh kernels (rasterize_points.cu:38-84) but sort it by depth
+// ALONE at the end (rasterize_points.cu:26-28, a stable bubble sort): where points tie exactly in depth both the survivors at the
+// K-th place and the order of the tied entries follow the array positions.  The replay below re-runs that procedure, points in
+// ascending index (the lists are binned in order for it), for every pixel whose K slots came out full -- a pixel with fewer hits
+// has dropped nothing and holds its hits in ascending (depth, index), which is the reference's arrival order.
+template <bool BINNED>
+__global__ __launch_bounds__(kStage) void point_cuda_order_kernel(PointArgs a) {
+  if (a.overflow != nullptr && (*a.overflow != 0) == BINNED) return;  // short workspaces: as in point_raster_kernel
+  TileCoord tc;
+  if (!tile_of_block(a.tm, blockIdx.x, &tc)) return;
+  const int n = tc.n, H = a.H, W = a.W, K = a.K;
+  const int y_end = min(H, (tc.by + 1) * a.tm.bin_size), x_end = min(W, (tc.bx + 1) * a.tm.bin_size);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int yi = tc.by * a.tm.bin_size + tc.ty * kTile + (w >> 1) * 8 + (lane >> 3);
+  const int xi = tc.bx * a.tm.bin_size + tc.tx * kTile + (w & 1) * 8 + (lane & 7);
+  const bool pix_ok = yi < y_end && xi < x_end;
+  const int64_t base = (((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi)) * K;
+  const bool replay = pix_ok && K > 0 && a.idxs[base + (K - 1)] >= 0;
+  if (__ballot(replay) == 0) return;  // uniform
+  int64_t src;
+  int count;
+  if (BINNED) {
+    const int64_t row = ((int64_t)n * a.tm.BH + tc.by) * a.tm.BW + tc.bx;
+    src = a.csr.offset[row];
+    count = a.csr.total[row];
+  } else {
+    src = a.first[n];
+    count = (int)a.count[n];
+  }
+  const float xf = pix_to_ndc(xi, W, H), yf = pix_to_ndc(yi, H, W);
+  float qz[P3D_MAX_K];
+  int qi[P3D_MAX_K];
+  int qn = 0, qmax_i = -1;
+  float qmax_z = -1000.0f;
+  for (int i = 0; i < count; ++i) {
+    const int pid = BINNED ? a.csr.list[src + i] : (int)(src + i);  // uniform
+    const float* g = a.points + (int64_t)pid * 3;
+    const float pz = g[2];
+    if (pz < 0.0f) continue;  // uniform
+    const float r = a.radius[pid];
+    const float dx = xf - g[0], dy = yf - g[1];
+    const float dist2 = dx * dx + dy * dy;
+    if (!replay || !(dist2 < r * r)) continue;
+    if (qn < K) {
+      qz[qn] = pz;
+      qi[qn] = pid;
+      if (pz > qmax_z) {
+        qmax_z = pz;
+        qmax_i = qn;
+      }
+      ++qn;
+    } else if (pz < qmax_z) {
+      qz[qmax_i] = pz;
+      qi[qmax_i] = pid;
+      qmax_z = pz;
+      for (int j = 0; j < K; ++j) {
+        if (qz[j] > qmax_z) {
+          qmax_z = qz[j];
+          qmax_i = j;
+        }
+      }
+    }
+  }
+  if (!replay) return;
+  for (int i = 1; i < qn; ++i) {  // stable, by depth alone
+    const float z = qz[i];
+    const int id = qi[i];
+    int j = i - 1;
+    while (j >= 0 && qz[j] > z) {
+      qz[j + 1] = qz[j];
+      qi[j + 1] = qi[j];
+      --j;
+    }
+    qz[j + 1] = z;
+    qi[j + 1] = id;
+  }
+  for (int k = 0; k < K; ++k) {
+    if (k < qn) {
+      const float* g = a.points + (int64_t)qi[k] * 3;
+      const float dx = xf - g[0], dy = yf - g[1];
+      a.idxs[base + k] = qi[k];
+      a.zbuf[base + k] = qz[k];
+      a.dists[base + k] = dx * dx + dy * dy;
+    } else {
+      a.idxs[base + k] = -1;
+      a.zbuf[base + k] = a.dists[base + k] = -1.0f;
+    }
+  }
+}
+
 // Backward (rasterize_points.cu:366-411): every (pixel, k) entry adds (2*gd*dx, 2*gd*dy, gz) to its point.  A point of
 // radius r is hit by ~pi*r^2 neighbouring pixels, so a wave owns an 8x8 pixel tile, walks its 64*K entries in
 // memory order (rows of 8*K contiguous entries) and merges per point in a wave-private LDS table (wave_table.h):
@@ -394,12 +485,33 @@ P3D_API int p3d_rasterize_points_naive(const float* points, const int64_t* first
   return launch_point_raster<false>(a, (hipStream_t)stream);
 }
 
-P3D_API int p3d_rasterize_points(const float* points, const int64_t* first, const int64_t* count, const float* radius,
-                                 int64_t P, int N, int H, int W, int K, int bin_size, int max_points_per_bin,
-                                 int32_t* idxs, float* zbuf, float* dists, void* workspace, size_t workspace_bytes,
-                                 p3d_stream_t stream) {
-  if (bin_size <= 0 || max_points_per_bin <= 0)
-    return p3d_rasterize_points_naive(points, first, count, radius, P, N, H, W, K, idxs, zbuf, dists, stream);
+static int point_cuda_order_replay(const PointArgs& fine, bool binned, const int64_t* first, const int64_t* count,
+                                   const int* overflow, hipStream_t s) {
+  PointArgs a = fine;
+  a.overflow = overflow;
+  LaunchScope ls("points_cuda_order", s);
+  if (binned) {
+    point_cuda_order_kernel<true><<<tile_grid(a.tm), kStage, 0, s>>>(a);
+  } else {
+    a.first = first;
+    a.count = count;
+    set_tiles(&a, a.H > a.W ? a.H : a.W, 1, 1);
+    point_cuda_order_kernel<false><<<tile_grid(a.tm), kStage, 0, s>>>(a);
+  }
+  return launch_status();
+}
+
+static int raster_points_impl(const float* points, const int64_t* first, const int64_t* count, const float* radius, int64_t P, int N,
+                              int H, int W, int K, int bin_size, int max_points_per_bin, int32_t* idxs, float* zbuf, float* dists,
+                              void* workspace, size_t workspace_bytes, p3d_stream_t stream, bool cuda_order) {
+  hipStream_t s = (hipStream_t)stream;
+  if (bin_size <= 0 || max_points_per_bin <= 0) {
+    const int st = p3d_rasterize_points_naive(points, first, count, radius, P, N, H, W, K, idxs, zbuf, dists, stream);
+    if (st != P3D_OK || !cuda_order || (int64_t)N * H * W * K == 0) return st;
+    PointArgs a{};
+    fill_args(&a, points, radius, N, H, W, K, idxs, zbuf, dists);
+    return point_cuda_order_replay(a, false, first, count, nullptr, s);
+  }
   const int rc = check_common(N, H, W, K);
   if (rc != P3D_OK) return rc;
   if ((int64_t)N * H * W * K == 0) return P3D_OK;
@@ -412,24 +524,46 @@ P3D_API int p3d_rasterize_points(const float* points, const int64_t* first, cons
   // a short workspace is welcome here (binning.h): the list takes what the caller gave, and the naive kernel stands by
   if (!workspace || !bin_carve(arena, P, N, g, max_points_per_bin, &ws, /*list_entries=*/1)) return P3D_ERR_WORKSPACE;
   const bool is_short = ws.capacity < ws.worst;
-  hipStream_t s = (hipStream_t)stream;
-  // the K nearest under (z, point index) do not depend on the order inside a bin: unordered fast binning
-  int st = bin_build(kPoints, points, radius, first, count, P, N, g, max_points_per_bin, 0.0f, ws, s, /*ordered=*/false);
+  const int* overflow = is_short ? ws.plan_hdr + 2 : nullptr;
+  // the K nearest under (z, point index) do not depend on the order inside a bin: unordered fast binning (the replay of the
+  // CUDA tie order walks the lists in ascending index: ordered binning then)
+  int st = bin_build(kPoints, points, radius, first, count, P, N, g, max_points_per_bin, 0.0f, ws, s, /*ordered=*/cuda_order);
   if (st != P3D_OK) return st;
   PointArgs a{};
   fill_args(&a, points, radius, N, H, W, K, idxs, zbuf, dists);
   a.csr = BinCSR{ws.offset, ws.total, ws.list, TilePlan{ws.arank, ws.bg_list, ws.plan_hdr, ws.order}};
-  a.overflow = is_short ? ws.plan_hdr + 2 : nullptr;
+  a.overflow = overflow;
   set_tiles(&a, g.bin_size, g.BH, g.BW);
   st = launch_point_raster<true>(a, s);
+  if (st == P3D_OK && is_short) {
+    PointArgs b{};
+    fill_args(&b, points, radius, N, H, W, K, idxs, zbuf, dists);
+    b.first = first;
+    b.count = count;
+    b.overflow = overflow;
+    set_tiles(&b, H > W ? H : W, 1, 1);
+    st = launch_point_raster<false>(b, s);
+  }
+  if (st != P3D_OK || !cuda_order) return st;
+  st = point_cuda_order_replay(a, true, first, count, overflow, s);
   if (st != P3D_OK || !is_short) return st;
-  PointArgs b{};
-  fill_args(&b, points, radius, N, H, W, K, idxs, zbuf, dists);
-  b.first = first;
-  b.count = count;
-  b.overflow = ws.plan_hdr + 2;
-  set_tiles(&b, H > W ? H : W, 1, 1);
-  return launch_point_raster<false>(b, s);
+  return point_cuda_order_replay(a, false, first, count, overflow, s);
+}
+
+P3D_API int p3d_rasterize_points(const float* points, const int64_t* first, const int64_t* count, const float* radius,
+                                 int64_t P, int N, int H, int W, int K, int bin_size, int max_points_per_bin,
+                                 int32_t* idxs, float* zbuf, float* dists, void* workspace, size_t workspace_bytes,
+                                 p3d_stream_t stream) {
+  return raster_points_impl(points, first, count, radius, P, N, H, W, K, bin_size, max_points_per_bin, idxs, zbuf, dists, workspace,
+                            workspace_bytes, stream, false);
+}
+
+P3D_API int p3d_rasterize_points_cuda_order(const float* points, const int64_t* first, const int64_t* count, const float* radius,
+                                            int64_t P, int N, int H, int W, int K, int bin_size, int max_points_per_bin,
+                                            int32_t* idxs, float* zbuf, float* dists, void* workspace, size_t workspace_bytes,
+                                            p3d_stream_t stream) {
+  return raster_points_impl(points, first, count, radius, P, N, H, W, K, bin_size, max_points_per_bin, idxs, zbuf, dists, workspace,
+                            workspace_bytes, stream, true);
 }
 
 P3D_API int p3d_rasterize_points_coarse(const float* points, const int64_t* first, const int64_t* count,

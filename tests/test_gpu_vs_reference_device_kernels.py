@@ -184,6 +184,38 @@ def test_cuda_tie_order_on_bench_meshes_equals_the_references_naive_device_kerne
     assert int((plain[0] != naive[0]).sum()) > 0  # the ties are there
 
 
+@pytest.mark.parametrize("K", [1, 2, 5, 8, 10, 40, 70, 120])
+def test_points_cuda_tie_order_equals_the_references_naive_device_kernel(cuda_tie_order, K):
+    """rasterize_points with `_C.CUDA_TIE_ORDER`: a cloud in which every point exists three times (same position and depth,
+    scattered indices) at radii that put dozens of them on a pixel -- exact depth ties at every place of the queue.  idx, zbuf and
+    dists of the naive and the binned launch equal the reference's NAIVE device kernel bit for bit (its binned path orders a bin
+    across 512-point chunks by atomicAdd arrival, rasterize_coarse.cu:185); without the switch the indices differ."""
+    _C = cuda_tie_order
+    mod = _need(True)
+    d = _d()
+    gen = torch.Generator().manual_seed(300 + K)
+    base = torch.rand((700, 3), generator=gen) * torch.tensor([2.0, 2.0, 2.0]) - torch.tensor([1.0, 1.0, -0.1])
+    base[::41, 2] = -0.3
+    order = torch.randperm(2100, generator=gen)
+    pts = base.repeat(3, 1)[order].contiguous().to(d)
+    rad = (torch.rand((700,), generator=gen) * 0.25 + 0.05).repeat(3)[order].contiguous().to(d)
+    first = torch.tensor([0, 900], dtype=torch.int64, device=d)
+    count = torch.tensor([900, 1200], dtype=torch.int64, device=d)
+    differed = 0
+    for size, bs in (((48, 48), 0), ((64, 40), 16), ((33, 70), 8)):
+        theirs = mod.rasterize_points(pts, first, count, size, rad, K, 0, 0)
+        _C.CUDA_TIE_ORDER = True
+        ours = _C.rasterize_points(pts, first, count, size, rad, K, bs, 3000 if bs else 0)
+        assert torch.equal(ours[0], theirs[0]), f"K={K} {size} bin {bs}: {int((ours[0] != theirs[0]).sum())} indices differ"
+        assert torch.equal(ours[1].view(torch.int32), theirs[1].view(torch.int32))
+        assert torch.equal(ours[2].view(torch.int32), theirs[2].view(torch.int32))
+        _C.CUDA_TIE_ORDER = False
+        plain = _C.rasterize_points(pts, first, count, size, rad, K, bs, 3000 if bs else 0)
+        differed += int((plain[0] != theirs[0]).sum())
+    if 2 <= K <= 40:  # (K = 1: both procedures keep the lowest index of the nearest depth)
+        assert differed > 0, "the cloud was meant to hold boundary ties"
+
+
 def test_cow_and_bench_meshes_bit_equal_to_reference_device_code():
     mod = _need(True)
     g = np.load(os.path.join(U.GOLDEN, "cow_ref.npz"))
