@@ -96,6 +96,7 @@ struct BinWorkspace {
   int64_t max_chunks;
   int64_t capacity;  // ids `list` holds
   int64_t worst;     // bin_capacity(): the most the lists can ever need
+  size_t need_at;    // byte offset of offset[rows] inside the arena (what a caller of a short workspace reads back)
 };
 
 // Short workspaces.  The worst case of the lists (every primitive in every bin, capped by M per bin) is 100-1000 x what a

@@ -650,6 +650,7 @@ bool bin_carve(Arena& arena, int64_t E, int N, const BinGeom& g, int M, BinWorks
   ws->chunk_start = arena.take<int>((size_t)N + 1);
   ws->counts = arena.take<int>((size_t)ws->max_chunks * g.nbins);
   ws->total = arena.take<int>((size_t)N * g.nbins);
+  ws->need_at = arena.off + (size_t)N * g.nbins * sizeof(int64_t);  // offset[rows]: the list total the build needed
   ws->offset = arena.take<int64_t>((size_t)N * g.nbins + 1);
   ws->blocksum = arena.take<long long>((size_t)ceil_div((int64_t)N * g.nbins, 1024) + 1);
   ws->arank = arena.take<int>((size_t)N * g.nbins);

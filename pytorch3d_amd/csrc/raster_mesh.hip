@@ -1260,11 +1260,10 @@ P3D_API size_t p3d_rasterize_meshes_workspace_need_offset(int64_t F, int N, int 
                                                           int max_faces_per_bin) {
   if (bin_size <= 0 || max_faces_per_bin <= 0 || N <= 0 || H <= 0 || W <= 0) return 0;
   const BinGeom g = make_internal_geom(H, W, bin_size);
-  char* const origin = reinterpret_cast<char*>((uintptr_t)1 << 20);  // never dereferenced: the carve only adds to it
-  Arena probe(origin, 0);
+  Arena probe(nullptr, 0);
   BinWorkspace ws;
   bin_carve(probe, F, N, g, max_faces_per_bin, &ws, 1);
-  return (size_t)(reinterpret_cast<char*>(ws.offset + (size_t)N * g.nbins) - origin);
+  return ws.need_at;
 }
 
 P3D_API size_t p3d_rasterize_fine_workspace_bytes(int N, int BH, int BW, int M) {

@@ -463,11 +463,10 @@ P3D_API size_t p3d_rasterize_points_short_workspace_bytes(int64_t P, int N, int 
 P3D_API size_t p3d_rasterize_points_workspace_need_offset(int64_t P, int N, int H, int W, int bin_size, int max_points_per_bin) {
   if (bin_size <= 0 || max_points_per_bin <= 0 || N <= 0 || H <= 0 || W <= 0) return 0;
   const BinGeom g = make_internal_geom(H, W, bin_size);
-  char* const origin = reinterpret_cast<char*>((uintptr_t)1 << 20);  // never dereferenced: the carve only adds to it
-  Arena probe(origin, 0);
+  Arena probe(nullptr, 0);
   BinWorkspace ws;
   bin_carve(probe, P, N, g, max_points_per_bin, &ws, 1);
-  return (size_t)(reinterpret_cast<char*>(ws.offset + (size_t)N * g.nbins) - origin);
+  return ws.need_at;
 }
 
 P3D_API int p3d_rasterize_points_naive(const float* points, const int64_t* first, const int64_t* count,
