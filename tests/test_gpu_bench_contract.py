@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(cmd, env=None, timeout=600):
+def _run(cmd, env=None, timeout=240):
     e = dict(os.environ)
     e.update(env or {})
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=e)

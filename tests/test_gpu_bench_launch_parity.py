@@ -41,7 +41,8 @@ def _bits(t):
     return t.view(torch.int32)
 
 
-@pytest.mark.parametrize("torus_div", [U.CONFIG3_TORUS_DIV, 1.5], ids=["config3_literal", "light_div1.5"])
+# (the lighter torus_div = 1.5 batch of rounds 1-3 is no longer a parameter: 22 s of the suite for a workload nothing quotes)
+@pytest.mark.parametrize("torus_div", [U.CONFIG3_TORUS_DIV], ids=["config3_literal"])
 def test_full_bench_batch_forward_and_backward_vs_reference_device_kernels(torus_div):
     mod = orc.ref_hip_module(nofma=True)
     if mod is None:

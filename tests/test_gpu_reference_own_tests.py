@@ -65,7 +65,7 @@ def _run(mode):
     cmd = [sys.executable, os.path.join(ROOT, "tests", "run_reference_suite.py"), "--out", out]
     if mode == "patched":
         cmd.append("--patch-python")
-    res = subprocess.run(cmd + MUST_PASS_MODULES + RENDER_MODULES, capture_output=True, text=True, timeout=1500)
+    res = subprocess.run(cmd + MUST_PASS_MODULES + RENDER_MODULES, capture_output=True, text=True, timeout=400)
     print(res.stdout[-6000:])
     assert res.returncode == 0, res.stderr[-3000:]
     with open(out) as f:
@@ -138,7 +138,7 @@ def test_known_rectangle_cases_on_the_references_own_device_build():
     for who, extra in (("ours", []), ("reference_fma", ["--hip-from-reference", "fma"]), ("reference_nofma", ["--hip-from-reference", "nofma"])):
         out = os.path.join(ROOT, "gpurun_out", f"ref_suite_rectangle_{who}.json")
         res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "run_reference_suite.py"), "--out", out, "-k", "test_gpu"] + extra +
-                             ["test_rasterize_rectangle_images"], capture_output=True, text=True, timeout=900)
+                             ["test_rasterize_rectangle_images"], capture_output=True, text=True, timeout=240)
         assert res.returncode == 0, res.stderr[-3000:]
         rep = json.load(open(out))["test_rasterize_rectangle_images"]
         for tid, r in rep.items():
