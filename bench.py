@@ -46,6 +46,25 @@ TORUS_DIV = 1.0
 TORUS_SCALE = "tori r=0.4+0.2u, R=1.0 unscaled as SURVEY.md 8(d) config 3 defines them (tests/_util.py::hetero_batch(torus_div=1.0))"
 
 
+def usable_cores():
+    """Cores this process may really use: the affinity mask and the cgroup CPU quota, not os.cpu_count().  The round-5 GPU boxes
+    show 256 cores and grant 16 (`/sys/fs/cgroup/cpu.max` = 1600000 100000): 256 OpenMP / intra-op threads on 16 cores spend their
+    time spinning at barriers (the round-4 GPU suite: 1123 s with 256 threads, 122 s with 16)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,8 +116,9 @@ def cpu_baseline(verts, faces, H, W, K, blur, budget_s):
     rasterize_meshes_cpu.cpp:412-529)."""
     from oracle import oracle as orc
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))  # the C oracle's OpenMP loops, should the "port" leg run
     t_start = time.perf_counter()
     py = python_reference_baseline(orc)
     ref = orc.ref_module()
@@ -146,6 +166,7 @@ def cpu_baseline(verts, faces, H, W, K, blur, budget_s):
         "value": px / dt / 1e6,
         "unit": "Mpix/s",
         "cores": cores,
+        "cores_visible": os.cpu_count(),
         "kind": kind,
         "sample": f"{done} of the seeded 8-mesh subset (randperm seed 0; visited smallest / largest / inwards) of the batch, faces {nf}, {H}x{W}, K={K}, "
                   f"naive fwd {t_fwd:.1f} s (multi-threaded over rows, {cores} threads) + bwd {t_bwd:.1f} s (single-threaded, "
@@ -312,7 +333,7 @@ def spawn_ranks(args):
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n)))
     return subprocess.call(cmd, env=env)
 
 
@@ -375,6 +396,7 @@ def light_workload_sensitivity(device, B, H, W, K, blur, steps=20):
 
 def main():
     args = parse()
+    torch.set_num_threads(usable_cores())  # host-side glue only (seeded randn of the upstream gradients); see usable_cores()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))

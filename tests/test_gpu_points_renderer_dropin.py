@@ -1,0 +1,45 @@
+"""SURVEY.md 8(d) config 4 AS WRITTEN, through the drop-in: the unmodified reference `PointsRenderer(PointsRasterizer,
+AlphaCompositor)` on 1M points / 512^2 / K = 10 with `pytorch3d._C` = pytorch3d_amd, loss = sum(image * g), autograd backward to
+points and features (pytorch3d/renderer/points/renderer.py:55-76) -- and the SAME Python chain with `_C` = the reference's own
+device kernels (oracle/_ref/p3d_ref_hip_nofma.so) in the same process (profiles/dropin_points_timing.py --check; a subprocess,
+so the shim does not leak into the other tests).
+
+Gates: zbuf bit-equal; idx differences only at exact depth ties (the reference's CUDA queue orders by z alone, ours by
+(z, idx): SURVEY appendix A) and fewer than 1e-4 of the entries; dists bit-equal where idx agrees; image within 1e-5 (north_star;
+tests/test_compositing.py:207 uses 1e-6 on sums of a few terms, here ten N(0,1)-weighted terms per pixel); gradients within 1e-4 of
+their largest entry (tests/test_rasterize_points.py:234 atol 2e-6 for unit upstreams; ~80 entries meet per point here)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STAGE = os.path.join(ROOT, "oracle", "_ref", "reference_py")
+
+
+def test_points_renderer_chain_config4_vs_reference_device_kernels():
+    if not os.path.isdir(os.path.join(STAGE, "pytorch3d", "renderer")):
+        pytest.skip("oracle/_ref/reference_py is not staged (run __graft_entry__.build() where /root/reference exists)")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "dropin_points_timing.py"), "--check", "--steps", "5"],
+                         capture_output=True, text=True, timeout=240, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert lines, res.stdout[-2000:]
+    j = json.loads(lines[-1])
+    print(json.dumps(j, indent=1))
+    assert j["grad_finite"] and j["ms_per_step"] > 0
+    assert set(j["our_kernels_ms_per_step"]) >= {"points_fine", "points_backward", "alpha_composite_fwd", "alpha_composite_bwd"}, j
+    c = j["check"]
+    if "skipped" in c:
+        pytest.skip(c["skipped"])
+    assert c["zbuf_bit_equal"]
+    assert c["idx_differences_not_at_exact_depth_ties"] == 0 and c["idx_differences"] <= 1e-4 * c["idx_entries"]
+    assert c["dists_bit_equal_where_idx_agrees"]
+    assert c["image_max_abs_diff"] <= 1e-5
+    assert c["grad_points_max_abs_diff"] <= 1e-4 * c["grad_points_max_abs"]
+    assert c["grad_features_max_abs_diff"] <= 1e-4 * c["grad_features_max_abs"]
+    assert c["points_with_gradient"][0] == c["points_with_gradient"][1]
