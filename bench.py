@@ -344,7 +344,7 @@ def dropin_timing(batch, image_size):
     import subprocess
 
     out = {}
-    for mode, div in (("c_only", TORUS_DIV), ("patched", TORUS_DIV), ("c_only", 1.5), ("patched", 1.5)):
+    for mode, div in (("c_only", TORUS_DIV), ("patched", TORUS_DIV)):
         key = mode if div == TORUS_DIV else f"{mode}_torus_div_{div}"
         try:
             res = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "dropin_timing.py"), "--mode", mode, "--batch", str(batch),
@@ -354,6 +354,21 @@ def dropin_timing(batch, image_size):
         except Exception as e:  # never sink the measurement
             out[key] = {"value": None, "reason": repr(e)}
     return out
+
+
+def dropin_points_timing():
+    """SURVEY.md 8(d) config 4 as written: the UNMODIFIED reference PointsRenderer(PointsRasterizer, AlphaCompositor) on 1M points,
+    512^2, K = 10, loss = sum(image * g), autograd backward to points and features, through the shim
+    (profiles/dropin_points_timing.py, a subprocess)."""
+    import subprocess
+
+    try:
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "dropin_points_timing.py")], capture_output=True, text=True,
+                             timeout=300, cwd=ROOT)
+        lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+        return json.loads(lines[-1]) if lines else {"value": None, "reason": (res.stderr or res.stdout)[-400:]}
+    except Exception as e:  # never sink the measurement
+        return {"value": None, "reason": repr(e)}
 
 
 def light_workload_sensitivity(device, B, H, W, K, blur, steps=20):
@@ -646,6 +661,8 @@ def main():
                 "global_batch": world * B * (steps if jobs_mode else 1), "image_size": [H, W], "faces_per_pixel": K, "blur_radius": blur,
                 "total_faces_per_rank": total_faces, "pixel_slot_fill": hit_frac, "covered_pixel_fraction": covered / px,
                 "parallelism": f"batch-sharded x{world}, final gather to rank 0 only",
+                "path": "pytorch3d_amd.rasterize_meshes -- this package's L2 mirror of renderer/mesh/rasterize_meshes.py (autograd Function over "
+                        "the C ABI); the unmodified reference MeshRasterizer over pytorch3d._C on the same batch is timed beside it: dropin_ms_per_step",
             },
             "roofline": roofline,
             "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in sorted(kernels.items())},
@@ -663,6 +680,11 @@ def main():
         if world == 1 and not jobs_mode and not args.no_dropin:
             out["dropin"] = dropin_timing(B, H)
             out["dropin"]["mirror_ms_per_step"] = elapsed / steps * 1e3
+            # what `from pytorch3d.renderer import MeshRasterizer` gets on the same batch, next to the headline's own path
+            out["config"]["dropin_ms_per_step"] = {k: round(v["ms_per_step"], 4) for k, v in out["dropin"].items()
+                                                   if isinstance(v, dict) and v.get("ms_per_step")}
+            if B == 64 and H == 512 and isinstance(out.get("other_configs"), dict):
+                out["other_configs"]["config4_points_renderer_dropin"] = dropin_points_timing()
         if world == 1 and not args.no_cpu_baseline:
             try:
                 _, _, _, verts_cpu, faces_cpu = batches[0]
