@@ -337,6 +337,14 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def _child_env():
+    """Environment of the drop-in subprocesses: torch's intra-op / OpenMP pools sized to the cores the box grants (usable_cores)."""
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(usable_cores()))
+    env.setdefault("MKL_NUM_THREADS", str(usable_cores()))
+    return env
+
+
 def dropin_timing(batch, image_size):
     """The UNMODIFIED reference `MeshRasterizer.forward` + backward through the shim on the same batch, `_C` only and with
     shim.install(patch_python=True) (profiles/dropin_timing.py, one subprocess each: the shim must not leak into this
@@ -348,7 +356,8 @@ def dropin_timing(batch, image_size):
         key = mode if div == TORUS_DIV else f"{mode}_torus_div_{div}"
         try:
             res = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "dropin_timing.py"), "--mode", mode, "--batch", str(batch),
-                                  "--image-size", str(image_size), "--torus-div", str(div)], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                                  "--image-size", str(image_size), "--torus-div", str(div)], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                                 env=_child_env())
             lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
             out[key] = json.loads(lines[-1]) if lines else {"value": None, "reason": (res.stderr or res.stdout)[-400:]}
         except Exception as e:  # never sink the measurement
@@ -358,17 +367,20 @@ def dropin_timing(batch, image_size):
 
 def dropin_points_timing():
     """SURVEY.md 8(d) config 4 as written: the UNMODIFIED reference PointsRenderer(PointsRasterizer, AlphaCompositor) on 1M points,
-    512^2, K = 10, loss = sum(image * g), autograd backward to points and features, through the shim
-    (profiles/dropin_points_timing.py, a subprocess)."""
+    512^2, K = 10, loss = sum(image * g), autograd backward to points and features, through the shim -- `_C` only and with
+    shim.install(patch_python=True) (profiles/dropin_points_timing.py, one subprocess each)."""
     import subprocess
 
-    try:
-        res = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "dropin_points_timing.py")], capture_output=True, text=True,
-                             timeout=300, cwd=ROOT)
-        lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
-        return json.loads(lines[-1]) if lines else {"value": None, "reason": (res.stderr or res.stdout)[-400:]}
-    except Exception as e:  # never sink the measurement
-        return {"value": None, "reason": repr(e)}
+    out = {}
+    for mode in ("c_only", "patched"):
+        try:
+            res = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "dropin_points_timing.py"), "--mode", mode], capture_output=True,
+                                 text=True, timeout=300, cwd=ROOT, env=_child_env())
+            lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+            out[mode] = json.loads(lines[-1]) if lines else {"value": None, "reason": (res.stderr or res.stdout)[-400:]}
+        except Exception as e:  # never sink the measurement
+            out[mode] = {"value": None, "reason": repr(e)}
+    return out
 
 
 def light_workload_sensitivity(device, B, H, W, K, blur, steps=20):

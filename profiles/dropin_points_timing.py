@@ -34,6 +34,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--points", type=int, default=1_000_000)
     ap.add_argument("--image-size", type=int, default=512)
+    ap.add_argument("--mode", default="c_only", choices=["c_only", "patched"],
+                    help="patched: shim.install(patch_python=True) -- PointsRasterizer.forward transforms the PACKED points in one launch, "
+                         "the compositing functions run as one autograd node without clones")
     ap.add_argument("--check", action="store_true", help="compare with the reference's own device kernels under the same Python")
     args = ap.parse_args()
     stage = os.path.join(ROOT, "oracle", "_ref", "reference_py")
@@ -58,6 +61,8 @@ def main():
                                     PointsRenderer)
     from pytorch3d.structures import Pointclouds
 
+    if args.mode == "patched":
+        shim.patch_reference_python()
     from pytorch3d_amd import _lib
 
     d = torch.device("cuda:0")
@@ -92,14 +97,27 @@ def main():
     wall = (time.perf_counter() - t0) / args.steps * 1e3
     lib.p3d_profile_enable(0)
     kern = {k: round(ms / args.steps, 4) for k, (n, ms) in sorted(_lib.profile_snapshot().items())}
-    out = {"chain": "PointsRenderer(PointsRasterizer, AlphaCompositor) fwd + sum(image*g).backward() to points and features, "
+    out = {"mode": args.mode, "chain": "PointsRenderer(PointsRasterizer, AlphaCompositor) fwd + sum(image*g).backward() to points and features, "
                     "unmodified reference classes over pytorch3d._C = pytorch3d_amd",
            "points": P, "image_size": H, "points_per_pixel": K, "radius": r, "ms_per_step": wall, "steps": args.steps,
            "Mpix_s": H * H / (wall * 1e-3) / 1e6, "our_kernels_ms_per_step": kern, "our_kernels_sum_ms": round(sum(kern.values()), 4),
            "grad_finite": bool(torch.isfinite(pts.grad).all() and torch.isfinite(feats.grad).all()),
            "covered": float((image.abs().sum(-1) > 0).float().mean()),
            "reference": ref_root if ref_root != stage else "oracle/_ref/reference_py (staged copy)"}
-    if args.check:
+    if args.mode == "patched":
+        out["patched_calls"] = {k: v for k, v in shim.PATCH_CALLS.items()}
+    if args.check and args.mode == "patched":
+        # the patched chain against the un-patched one (the reference's own Python over the same `_C`) in this process
+        mine = {"image": image.detach().clone(), "gp": pts.grad.clone(), "gf": feats.grad.clone()}
+        shim.uninstall_python_patches()
+        image_c = step()
+        torch.cuda.synchronize()
+        out["check"] = {"against": "the same chain with the reference's own Python (patches uninstalled) over the same _C",
+                        "image_bit_equal": bool(torch.equal(mine["image"], image_c.detach())),
+                        "image_max_abs_diff": float((mine["image"] - image_c.detach()).abs().max()),
+                        "grad_points_max_abs_diff": float((mine["gp"] - pts.grad).abs().max()), "grad_points_max_abs": float(pts.grad.abs().max()),
+                        "grad_features_max_abs_diff": float((mine["gf"] - feats.grad).abs().max()), "grad_features_max_abs": float(feats.grad.abs().max())}
+    if args.check and args.mode == "c_only":
         from oracle import oracle as orc
 
         mod = orc.ref_hip_module(nofma=True)
@@ -128,16 +146,27 @@ def main():
             tie[..., 1:] |= z[..., 1:] == z[..., :-1]
             tie[..., :-1] |= z[..., :-1] == z[..., 1:]
             tie[..., K - 1] = True
+            # Where the two queues kept different points at an exact depth tie (the reference's CUDA queue orders by z alone, ours by
+            # (z, idx)) the pixel composites other features: image and gradients are compared on the pixels whose K indices all
+            # agree, and on the points that appear in no differing pixel (a pixel's transmittances couple all of its entries).
+            bad_pix = (~same).any(-1)  # (1, H, W)
+            touched = torch.zeros(P, dtype=torch.bool, device=d)
+            for t in (ours["idx"], fr.idx):
+                ids = t[bad_pix].reshape(-1).long()
+                touched[ids[ids >= 0]] = True
+            good = ~bad_pix
+            clean = ~touched
             out["check"] = {
                 "against": "oracle/_ref/p3d_ref_hip_nofma.so (the reference's .cu files for gfx950, -ffp-contract=off) under the same Python",
                 "reference_step_ms_single_run": ref_ms,
                 "zbuf_bit_equal": bool(torch.equal(ours["zbuf"].view(torch.int32), fr.zbuf.view(torch.int32))),
                 "idx_differences": int((~same).sum()), "idx_differences_not_at_exact_depth_ties": int((~same & ~tie).sum()),
-                "idx_entries": same.numel(),
+                "idx_entries": same.numel(), "pixels_with_an_idx_difference": int(bad_pix.sum()), "points_in_those_pixels": int(touched.sum()),
                 "dists_bit_equal_where_idx_agrees": bool(torch.equal(ours["dists"].view(torch.int32)[same], fr.dists.view(torch.int32)[same])),
-                "image_max_abs_diff": float((ours["image"] - image_ref.detach()).abs().max()),
-                "grad_points_max_abs_diff": float((ours["gp"] - pts.grad).abs().max()), "grad_points_max_abs": float(pts.grad.abs().max()),
-                "grad_features_max_abs_diff": float((ours["gf"] - feats.grad).abs().max()), "grad_features_max_abs": float(feats.grad.abs().max()),
+                "image_max_abs_diff": float((ours["image"] - image_ref.detach())[good].abs().max()),
+                "image_max_abs_diff_all_pixels": float((ours["image"] - image_ref.detach()).abs().max()),
+                "grad_points_max_abs_diff": float((ours["gp"] - pts.grad)[clean].abs().max()), "grad_points_max_abs": float(pts.grad.abs().max()),
+                "grad_features_max_abs_diff": float((ours["gf"] - feats.grad)[clean].abs().max()), "grad_features_max_abs": float(feats.grad.abs().max()),
                 "points_with_gradient": [int((ours["gp"] != 0).any(1).sum()), int((pts.grad != 0).any(1).sum())]}
     print(json.dumps(out))
 

@@ -264,7 +264,20 @@ def patch_reference_python():
     textures.TexturesAtlas.sample_textures = atlas_sample
     _PATCHED.append((textures.TexturesAtlas, "sample_textures", atlas_orig, atlas_sample))
 
+    # compositing.py:68-96, 148-175, 227-247: one autograd node for the three modes; no .clone() of features / alphas / indices
+    # (the kernels never write them) and the renderer's permuted views go to the C ABI with their strides
+    our_comp = importlib.import_module(__package__ + ".compositing")
+    comp = importlib.import_module("pytorch3d.renderer.compositing")
+
+    def comp_ok(pointsidx, alphas, pt_clds):
+        return (_is_hip_f32(alphas) and _is_hip_f32(pt_clds) and pointsidx.is_cuda and pointsidx.dtype == torch.int64
+                and pointsidx.dim() == 4 and tuple(pointsidx.shape) == tuple(alphas.shape) and pt_clds.dim() == 2)
+
+    for fname in ("alpha_composite", "norm_weighted_sum", "weighted_sum"):
+        _replace_everywhere(getattr(comp, fname), wrap(fname, getattr(comp, fname), getattr(our_comp, fname), comp_ok))
+
     _patch_mesh_rasterizer(our_rm)
+    _patch_points_rasterizer(our_rm)
     _patch_soft_phong_shader(our_shade)
     _patch_meshes_offset_verts()
     _patch_hard_and_silhouette_shaders()
@@ -360,6 +373,77 @@ def _patch_mesh_rasterizer(our_rm):
     forward.__wrapped__ = orig
     rz.MeshRasterizer.forward = forward
     _PATCHED.append((rz.MeshRasterizer, "forward", orig, forward))
+
+
+def _patch_points_rasterizer(our_rm):
+    """PointsRasterizer.forward (renderer/points/rasterizer.py:118-168).  The reference transforms the PADDED points with two
+    batched 4x4 `transform_points` (four hipBLASLt GEMMs, cat, homogeneous divides, `update_padded` -> a new Pointclouds:
+    ~1 ms of GPU time and ~50 small copies per call at 1M points) before `rasterize_points`.  Here: both matrices from the
+    cameras, ONE kernel on the packed points (csrc/transform.hip: p3d_transform_verts_forward / _backward, the kernel
+    MeshRasterizer.forward uses for vertices: x, y to NDC, z = view depth, as rasterizer.py:140-141 keeps it) and the
+    rasterizer's own autograd node.  Falls back to the reference's forward when the cameras have no matrix form, need an
+    `eps`, or their matrices require grad."""
+    import importlib
+
+    pr = importlib.import_module("pytorch3d.renderer.points.rasterizer")
+    our_rp = importlib.import_module(__package__ + ".rasterize_points")
+    orig = pr.PointsRasterizer.forward
+
+    def forward(self, point_clouds, **kwargs):
+        cameras = kwargs.get("cameras", self.cameras)
+        ok = cameras is not None and kwargs.get("eps", None) is None
+        if ok:
+            try:
+                pts = point_clouds.points_packed()
+                ok = _is_hip_f32(pts) and pts.dim() == 2 and pts.shape[1] == 3 and len(cameras) in (1, len(point_clouds))
+                if ok:
+                    cm = camera_matrices(cameras, kwargs)
+                    ok = cm is not None
+                    if ok:
+                        w2v, v2n = cm[0], cm[1]
+                        ok = not (w2v.requires_grad or v2n.requires_grad) and w2v.device == pts.device
+            except Exception:
+                ok = False
+        _count("PointsRasterizer.forward", ok)
+        if not ok:
+            return orig(self, point_clouds, **kwargs)
+        rs = kwargs.get("raster_settings", self.raster_settings)
+        mats = our_rm._pack_matrices(w2v, v2n, len(point_clouds), pts.device)
+        ndc = our_rm._TransformVerts.apply(pts, point_clouds.cloud_to_packed_first_idx().contiguous(), mats)
+        idx, zbuf, dists2 = our_rp.rasterize_points(_PackedPointsView(point_clouds, ndc), image_size=rs.image_size, radius=rs.radius,
+                                                    points_per_pixel=rs.points_per_pixel, bin_size=rs.bin_size,
+                                                    max_points_per_bin=rs.max_points_per_bin)
+        return pr.PointFragments(idx=idx, zbuf=zbuf, dists=dists2)
+
+    forward.__wrapped__ = orig
+    pr.PointsRasterizer.forward = forward
+    _PATCHED.append((pr.PointsRasterizer, "forward", orig, forward))
+
+
+class _PackedPointsView:
+    """The accessors pytorch3d_amd.rasterize_points reads, with the packed points replaced (everything else is the cloud's)."""
+
+    def __init__(self, clouds, points_packed):
+        self._clouds, self._points = clouds, points_packed
+
+    def __len__(self):
+        return len(self._clouds)
+
+    def points_packed(self):
+        return self._points
+
+    def cloud_to_packed_first_idx(self):
+        return self._clouds.cloud_to_packed_first_idx()
+
+    def num_points_per_cloud(self):
+        return self._clouds.num_points_per_cloud()
+
+    def padded_to_packed_idx(self):
+        return self._clouds.padded_to_packed_idx()
+
+    @property
+    def _P(self):
+        return self._clouds._P
 
 
 def _patch_soft_phong_shader(our_shade):

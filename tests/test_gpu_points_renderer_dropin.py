@@ -43,3 +43,22 @@ def test_points_renderer_chain_config4_vs_reference_device_kernels():
     assert c["grad_points_max_abs_diff"] <= 1e-4 * c["grad_points_max_abs"]
     assert c["grad_features_max_abs_diff"] <= 1e-4 * c["grad_features_max_abs"]
     assert c["points_with_gradient"][0] == c["points_with_gradient"][1]
+
+
+def test_patched_points_renderer_chain_equals_the_unpatched_one():
+    """shim.install(patch_python=True): PointsRasterizer.forward with the camera transform on the PACKED points in one launch
+    (csrc/transform.hip) and the compositing functions as one autograd node -- same image as the reference's own Python over the
+    same `_C` (the NDC points may differ in the last bit: the reference multiplies two 4x4 matrices per point with hipBLASLt),
+    gradients within 1e-4 of their largest entry."""
+    if not os.path.isdir(os.path.join(STAGE, "pytorch3d", "renderer")):
+        pytest.skip("oracle/_ref/reference_py is not staged (run __graft_entry__.build() where /root/reference exists)")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "dropin_points_timing.py"), "--mode", "patched", "--check", "--steps", "5"],
+                         capture_output=True, text=True, timeout=240, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    j = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    print(json.dumps(j, indent=1))
+    assert j["grad_finite"] and j["patched_calls"]["PointsRasterizer.forward"][0] > 0 and j["patched_calls"]["alpha_composite"][0] > 0, j
+    c = j["check"]
+    assert c["image_max_abs_diff"] <= 1e-5
+    assert c["grad_points_max_abs_diff"] <= 1e-4 * c["grad_points_max_abs"]
+    assert c["grad_features_max_abs_diff"] <= 1e-4 * c["grad_features_max_abs"]
