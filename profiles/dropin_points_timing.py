@@ -156,6 +156,11 @@ def main():
                 touched[ids[ids >= 0]] = True
             good = ~bad_pix
             clean = ~touched
+            diff_img = (ours["image"] - image_ref.detach()).abs().amax(-1) * good
+            wy, wx = divmod(int(diff_img[0].argmax()), H)
+            worst = {"pixel": [wy, wx], "ours_idx": ours["idx"][0, wy, wx].tolist(), "ref_idx": fr.idx[0, wy, wx].tolist(),
+                     "ours_zbuf": ours["zbuf"][0, wy, wx].tolist(), "ours_dists": ours["dists"][0, wy, wx].tolist(), "ref_dists": fr.dists[0, wy, wx].tolist(),
+                     "ours_image": ours["image"][0, wy, wx].tolist(), "ref_image": image_ref[0, wy, wx].tolist()}
             out["check"] = {
                 "against": "oracle/_ref/p3d_ref_hip_nofma.so (the reference's .cu files for gfx950, -ffp-contract=off) under the same Python",
                 "reference_step_ms_single_run": ref_ms,
@@ -167,7 +172,8 @@ def main():
                 "image_max_abs_diff_all_pixels": float((ours["image"] - image_ref.detach()).abs().max()),
                 "grad_points_max_abs_diff": float((ours["gp"] - pts.grad)[clean].abs().max()), "grad_points_max_abs": float(pts.grad.abs().max()),
                 "grad_features_max_abs_diff": float((ours["gf"] - feats.grad)[clean].abs().max()), "grad_features_max_abs": float(feats.grad.abs().max()),
-                "points_with_gradient": [int((ours["gp"] != 0).any(1).sum()), int((pts.grad != 0).any(1).sum())]}
+                "points_with_gradient": [int((ours["gp"] != 0).any(1).sum()), int((pts.grad != 0).any(1).sum())],
+                "worst_good_pixel": worst}
     print(json.dumps(out))
 
 

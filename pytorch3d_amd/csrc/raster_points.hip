@@ -210,9 +210,266 @@ __global__ __launch_bounds__(kStage, WAVES) void point_raster_kernel(PointArgs a
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Sorted fine stage (round 5): ONE WAVE = ONE 8x8 SUB-TILE, no workgroup barrier, no sorted-insertion network.
+//
+// The kernel above walks a tile's list in arrival order, 256 points at a time behind barriers, and keeps every pixel's K nearest
+// in a sorted register queue: an insertion costs ~4 VALU per entry and runs for the whole wave whenever ONE of its 64 pixels
+// admits the point -- on BASELINE configs[3] (1M points, ~80 splats over every pixel, K = 10) that was ~26 000 VALU
+// instructions per wave for ~650 candidate points, with one wave per SIMD slot and no second round to balance (0.175 ms:
+// 0.034 of the HBM roofline).  Here the wave first puts ITS candidates -- the points of the bin whose
+// box touches its sub-tile -- in exact ascending (depth, index) order, then visits them front to back:
+//   pass A  64 list entries at a time: load, sub-tile box cull, ordered ballot compaction of the 64-bit keys (z bits | index)
+//           into LDS (at most kSortCap per round; a longer list takes several rounds, see below);
+//   pass B  exact sort: 64 depth buckets between the round's min and max depth (one LDS integer atomic per key gives its place
+//           in the bucket, a wave scan the bucket starts), then every key's rank INSIDE its bucket by counting the bucket's
+//           smaller keys (buckets hold ~10 keys) -- ~50 instructions per 64 keys for the buckets, ~6 per bucket mate for the rank;
+//   pass C  front to back, 64 candidates per block (their x, y, r gathered by index: only visited blocks pay for it): a pixel
+//           inside the splat APPENDS the key to its queue -- LDS, [k][lane] layout: one ds_write_b64, conflict-free -- because
+//           a sorted stream arrives in queue order; the pixel is done when it holds K entries, the wave when all its pixels are
+//           (one ballot per block and per candidate): ~170 of the ~650 candidates are ever visited at K = 10.
+// A queue in LDS has no capacity classes: the same kernel serves K = 1 .. 150 (dynamic LDS K x 512 B) -- the K = 100 register
+// queue took 3.0 ms on this cloud, the private-memory queue above it more.  Lists longer than kSortCap candidates: later rounds
+// are sorted the same way but no longer arrive in QUEUE order, so their points are inserted (per lane: shift the larger entries,
+// in LDS), and pass A drops every key that is not below the largest K-th key of the wave.  Results are those of the kernel above
+// bit for bit: the K smallest keys under the total order (z, index), dist2 recomputed by the same expression at the store.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kSortCap = 768;   // keys sorted per round and wave: 2 x 6 KB of LDS
+constexpr int kSortSlots = kSortCap / kWave;
+
+__device__ __forceinline__ int depth_bucket(unsigned zbits, float zlo, float scale) {
+  const int b = (int)((__uint_as_float(zbits) - zlo) * scale);  // monotone in z: subtraction, product with scale >= 0, conversion
+  return b < 0 ? 0 : (b > kWave - 1 ? kWave - 1 : b);
+}
+
+template <bool BINNED>
+__global__ __launch_bounds__(kWave, 2) void point_sorted_kernel(PointArgs a) {
+  extern __shared__ __align__(16) unsigned long long s_queue[];  // [K][64]: entry k of lane l at k * 64 + l
+  __shared__ unsigned long long s_a[kSortCap];
+  __shared__ unsigned long long s_b[kSortCap];
+  __shared__ int s_hist[kWave];
+  __shared__ int s_start[kWave];
+  __shared__ unsigned s_zrange[2];
+
+  if (a.overflow != nullptr && (*a.overflow != 0) == BINNED) return;  // uniform (scalar load)
+  TileCoord tc;
+  if (!tile_of_block(a.tm, blockIdx.x >> 2, &tc)) return;
+  const int n = tc.n, H = a.H, W = a.W, K = a.K;
+  const int y_end = min(H, (tc.by + 1) * a.tm.bin_size);
+  const int x_end = min(W, (tc.bx + 1) * a.tm.bin_size);
+  const int sub = (int)(blockIdx.x & 3u);
+  const int sy0 = tc.by * a.tm.bin_size + tc.ty * kTile + (sub >> 1) * 8;
+  const int sx0 = tc.bx * a.tm.bin_size + tc.tx * kTile + (sub & 1) * 8;
+  if (sy0 >= y_end || sx0 >= x_end) return;  // uniform
+  const int lane = threadIdx.x;
+  const int yi = sy0 + (lane >> 3), xi = sx0 + (lane & 7);
+  const bool pix_ok = yi < y_end && xi < x_end;
+  // one pix_to_ndc per lane: lane l < 8 the sub-tile's pixel column sx0 + l, lane 8 + l its row sy0 + l (lanes 16.. repeat)
+  const float pxy = (lane & 8) ? pix_to_ndc(sy0 + (lane & 7), H, W) : pix_to_ndc(sx0 + (lane & 7), W, H);
+  auto centre = [&](int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pxy), l)); };
+  const float xf = __int_as_float(__builtin_amdgcn_ds_bpermute((lane & 7) << 2, __float_as_int(pxy)));
+  const float yf = __int_as_float(__builtin_amdgcn_ds_bpermute((8 + (lane >> 3)) << 2, __float_as_int(pxy)));
+  const float sub_x0 = centre(0), sub_x1 = centre(min(sx0 + 8, x_end) - 1 - sx0);
+  const float sub_y0 = centre(8), sub_y1 = centre(8 + min(sy0 + 8, y_end) - 1 - sy0);
+
+  int64_t src_base;
+  int count;
+  if (BINNED) {
+    const int64_t row = ((int64_t)n * a.tm.BH + tc.by) * a.tm.BW + tc.bx;
+    src_base = a.csr.offset[row];
+    count = a.csr.total[row];
+  } else {
+    src_base = a.first[n];
+    count = (int)a.count[n];
+  }
+
+  int cnt = 0;                     // entries of this lane's queue (ascending keys)
+  unsigned long long kth = ~0ull;  // the K-th key once the queue is full: nothing at or above it can enter
+  bool first = true;               // this round's stream arrives in queue order (the queues were empty when it was sorted)
+  int pos = 0;
+  while (pos < count) {  // uniform: one round = up to kSortCap candidates
+    // a later round: no lane can use a key at or above the largest K-th key of the wave (~0 while some queue has room)
+    unsigned long long kmax = 0;
+    if (first) {
+      kmax = ~0ull;
+    } else {
+      unsigned long long rem = __ballot(pix_ok);
+      while (rem) {  // uniform
+        const int l = __builtin_ctzll(rem);
+        rem &= rem - 1;
+        const unsigned long long kl = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(kth >> 32), l) << 32) |
+                                      (unsigned)__builtin_amdgcn_readlane((int)(unsigned)kth, l);
+        kmax = kl > kmax ? kl : kmax;
+      }
+    }
+    // ---- pass A ----
+    int nc = 0;
+    unsigned zlo_l = 0xffffffffu, zhi_l = 0u;
+    while (pos < count && nc <= kSortCap - kWave) {  // uniform
+      const int i = pos + lane;
+      bool keep = false;
+      unsigned long long key = 0;
+      if (i < count) {
+        const int pid = BINNED ? a.csr.list[src_base + i] : (int)(src_base + i);
+        const float* g = a.points + (int64_t)pid * 3;
+        const float px = g[0], py = g[1], pz = g[2];
+        const float r = a.radius[pid];
+        // a pixel with dist2 < r*r lies inside [x-r, x+r] x [y-r, y+r]: the cull of point_raster_kernel, on the sub-tile
+        const bool off = sub_x0 > px + r || sub_x1 < px - r || sub_y0 > py + r || sub_y1 < py - r;
+        // +0.0 canonicalises a zero depth: the keys order by their bits (as the pair queues of the kernel above)
+        key = ((unsigned long long)__float_as_uint(pz + 0.0f) << 32) | (unsigned)pid;
+        keep = !(pz < 0.0f) && !off && key < kmax;
+      }
+      const unsigned long long km = __ballot(keep);
+      if (keep) {
+        s_a[nc + mask_rank(km)] = key;
+        const unsigned zb = (unsigned)(key >> 32);
+        zlo_l = zb < zlo_l ? zb : zlo_l;
+        zhi_l = zb > zhi_l ? zb : zhi_l;
+      }
+      nc += __popcll(km);
+      pos += kWave;
+    }
+    if (nc == 0) continue;  // uniform
+    // ---- pass B: exact ascending order of s_a[0 .. nc) ----
+    if (lane == 0) {
+      s_zrange[0] = 0xffffffffu;
+      s_zrange[1] = 0u;
+    }
+    s_hist[lane] = 0;
+    __syncthreads();
+    atomicMin(&s_zrange[0], zlo_l);
+    atomicMax(&s_zrange[1], zhi_l);
+    __syncthreads();
+    const float zlo = __uint_as_float(s_zrange[0]);
+    const float zspan = __uint_as_float(s_zrange[1]) - zlo;
+    const float scale = zspan > 0.0f && zspan < INFINITY ? (float)kWave / zspan : 0.0f;
+    unsigned long long mine[kSortSlots];
+    int tag[kSortSlots];  // bucket << 16 | place in the bucket (arrival order)
+#pragma unroll
+    for (int t = 0; t < kSortSlots; ++t) {
+      const int i = t * kWave + lane;
+      mine[t] = 0;
+      tag[t] = 0;
+      if (i < nc) {
+        mine[t] = s_a[i];
+        const int b = depth_bucket((unsigned)(mine[t] >> 32), zlo, scale);
+        tag[t] = (b << 16) | atomicAdd(&s_hist[b], 1);
+      }
+    }
+    __syncthreads();
+    const int hcount = s_hist[lane];
+    int incl = hcount;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const int up = __shfl_up(incl, d, kWave);
+      if (lane >= d) incl += up;
+    }
+    s_start[lane] = incl - hcount;
+    int hmax = hcount;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) hmax = max(hmax, __shfl_xor(hmax, d, kWave));
+    hmax = __builtin_amdgcn_readfirstlane(hmax);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < kSortSlots; ++t) {
+      const int i = t * kWave + lane;
+      if (i < nc) s_b[s_start[tag[t] >> 16] + (tag[t] & 0xffff)] = mine[t];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int jb = 0; jb < nc; jb += kWave) {
+      const int j = jb + lane;
+      if (j < nc) {
+        const unsigned long long key = s_b[j];
+        const int b = depth_bucket((unsigned)(key >> 32), zlo, scale);
+        const int s0 = s_start[b], e0 = s0 + s_hist[b];
+        int less = 0;
+        for (int t = 0; t < hmax; ++t) {  // uniform bound; lanes of short buckets idle
+          const int at = s0 + t;
+          if (at < e0) less += s_b[at] < key ? 1 : 0;
+        }
+        s_a[s0 + less] = key;
+      }
+    }
+    __syncthreads();
+    // ---- pass C: front to back ----
+#pragma unroll 1
+    for (int jb = 0; jb < nc; jb += kWave) {
+      const int j = jb + lane;
+      const unsigned long long ck = j < nc ? s_a[j] : ~0ull;
+      const unsigned clo = (unsigned)ck, chi = (unsigned)(ck >> 32);
+      {
+        // the block's first key is its smallest: is it still below some pixel's K-th key?
+        const unsigned long long k0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)chi) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((int)clo);
+        if (__ballot(pix_ok && k0 < kth) == 0) break;  // uniform
+      }
+      float cx = 0.0f, cy = 0.0f, cr2 = 0.0f;
+      if (j < nc) {
+        const float* g = a.points + (int64_t)clo * 3;
+        cx = g[0];
+        cy = g[1];
+        const float r = a.radius[clo];
+        cr2 = r * r;
+      }
+      const int m = min(kWave, nc - jb);
+      for (int t = 0; t < m; ++t) {  // uniform
+        const unsigned long long key = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)chi, t) << 32) |
+                                       (unsigned)__builtin_amdgcn_readlane((int)clo, t);
+        const bool live = pix_ok && key < kth;
+        if (__ballot(live) == 0) break;  // uniform: keys ascend, so do the misses
+        const float dx = xf - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cx), t));
+        const float dy = yf - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cy), t));
+        const float dist2 = dx * dx + dy * dy;
+        if (live && dist2 < __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cr2), t))) {
+          if (first) {  // uniform
+            s_queue[cnt * kWave + lane] = key;
+            ++cnt;
+            if (cnt == K) kth = key;
+          } else {
+            int at = cnt < K ? cnt : K - 1;  // the hole: a new last entry, or the K-th falls off
+            while (at > 0) {
+              const unsigned long long prev = s_queue[(at - 1) * kWave + lane];
+              if (!(prev > key)) break;
+              s_queue[at * kWave + lane] = prev;
+              --at;
+            }
+            s_queue[at * kWave + lane] = key;
+            if (cnt < K) ++cnt;
+            if (cnt == K) kth = s_queue[(K - 1) * kWave + lane];
+          }
+        }
+      }
+    }
+    first = false;
+    __syncthreads();
+  }
+
+  if (pix_ok) {
+    const int64_t base = (((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi)) * K;
+    for (int k = 0; k < K; ++k) {
+      int id = -1;
+      float z = -1.0f, d2 = -1.0f;
+      if (k < cnt) {
+        const unsigned long long key = s_queue[k * kWave + lane];
+        id = (int)(unsigned)key;
+        z = __uint_as_float((unsigned)(key >> 32));
+        const float* g = a.points + (int64_t)id * 3;
+        const float dx = xf - g[0];
+        const float dy = yf - g[1];
+        d2 = dx * dx + dy * dy;
+      }
+      a.idxs[base + k] = id;
+      a.zbuf[base + k] = z;
+      a.dists[base + k] = d2;
+    }
+  }
+}
+
 #define P3D_COMMA ,
 template <bool BINNED>
-int launch_point_raster(const PointArgs& a, hipStream_t stream) {
+int launch_point_raster_queues(const PointArgs& a, hipStream_t stream) {
   const unsigned grid = tile_grid(a.tm);
   LaunchScope ls(BINNED ? "points_fine" : "points_naive", stream);
   const int K = a.K;
@@ -265,6 +522,25 @@ int launch_point_raster(const PointArgs& a, hipStream_t stream) {
     point_raster_kernel<TopKPairs<100, true, 0>, 100, true, BINNED, false, 1><<<grid, kStage, 0, stream>>>(a);
   else  // 101..150: 300 queue registers do not fit the 256 VGPRs + 256 AGPRs of a lane without scratch
     point_raster_kernel<TopKMem<P3D_MAX_K, 1>, P3D_MAX_K, false, BINNED><<<grid, kStage, 0, stream>>>(a);
+  return launch_status();
+}
+
+template <bool BINNED>
+int launch_point_raster(const PointArgs& a, hipStream_t stream) {
+  const size_t grid = (size_t)tile_grid(a.tm) * 4;  // one single-wave workgroup per 8x8 sub-tile
+  if (grid > 0x7fffffffull) return P3D_ERR_INVALID_ARG;
+  const size_t dyn = (size_t)a.K * kWave * sizeof(unsigned long long);
+  if (dyn > 48 * 1024) {  // K > 96: past the default dynamic-LDS limit (gfx950 has 160 KB per CU)
+    static bool raised[2] = {false, false};
+    if (!raised[BINNED ? 1 : 0]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&point_sorted_kernel<BINNED>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              P3D_MAX_K * kWave * (int)sizeof(unsigned long long)) != hipSuccess)
+        return P3D_ERR_LAUNCH;
+      raised[BINNED ? 1 : 0] = true;
+    }
+  }
+  LaunchScope ls(BINNED ? "points_fine" : "points_naive", stream);
+  point_sorted_kernel<BINNED><<<(unsigned)grid, kWave, dyn, stream>>>(a);
   return launch_status();
 }
 
