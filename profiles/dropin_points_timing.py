@@ -131,15 +131,27 @@ def main():
             saved = {n: getattr(shim_mod, n) for n in HOT}
             for n in HOT:  # the reference's Python looks the operators up on the module at call time
                 setattr(shim_mod, n, getattr(mod, n))
+            # The reference's binned device path is not deterministic where depths tie exactly (a bin's points across 512-point chunks
+            # arrive in atomicAdd order, rasterize_coarse.cu:185): the fragments compared below are the ones THIS step composited.
+            seen = []
+
+            def recording(*a):
+                res = mod.rasterize_points(*a)
+                seen.append(res)
+                return res
+
+            shim_mod.rasterize_points = recording
             try:
                 t0 = time.perf_counter()
                 image_ref = step()
                 torch.cuda.synchronize()
                 ref_ms = (time.perf_counter() - t0) * 1e3
-                fr = renderer.rasterizer(Pointclouds(points=[pts0], features=[feats0]))
             finally:
                 for n in HOT:
                     setattr(shim_mod, n, saved[n])
+            import collections
+
+            fr = collections.namedtuple("F", "idx zbuf dists")(*seen[-1])
             same = ours["idx"] == fr.idx
             z = ours["zbuf"]
             tie = torch.zeros_like(same)

@@ -39,6 +39,119 @@ struct PointArgs {
   const int* overflow;
 };
 
+// Tile pre-sort (round 5).  The chunk loop below visits each 256-point chunk of the tile's list front to back, but the chunks
+// themselves come in list order: on a dense cloud (BASELINE configs[3]: ~1700 points per tile, seven chunks, ~80 splats over
+// every pixel) every chunk holds points that displace queued ones, so all seven are staged and walked and the insertion network
+// runs for most candidates.  The K nearest do not depend on the visiting order, so the workgroup first deals the WHOLE list into
+// 256 depth buckets (one pass: every thread requests its <= 16 list entries and their depths at once -- two memory round trips
+// for the list -- then one integer LDS atomic per point, a workgroup scan, a scatter of the point indices) and the chunk loop
+// reads the bucket-ordered copy: chunk c then holds nearer points than chunk c + 1 (up to bucket granularity), queues fill from
+// the first chunks, and the loop ends as soon as the smallest depth of the chunks still to come (`cmin`, suffix minima) lies
+// behind every pixel's K-th entry in all four waves.  Exactness is the queues' business, as before: the order is only a schedule.
+constexpr int kPreCap = 4096;                 // list entries ordered ahead of the chunk loop (longer lists: list order, as before)
+constexpr int kPreSlots = kPreCap / kStage;   // per thread
+
+struct PreSortLds {
+  int sorted[kPreCap];
+  int hist[kStage];
+  int start[kStage];
+  unsigned cmin[kPreSlots + 1];
+  unsigned range[2];
+  int wsum[kStage / kWave];
+};
+
+// All 256 threads.  list[0 .. count): the tile's points, kStage < count <= kPreCap.  Ends with a barrier.
+__device__ __forceinline__ void presort_tile(const float* __restrict__ points, const int* __restrict__ list, int count, PreSortLds& L,
+                                             int tid) {
+  const int lane = tid & 63, w = tid >> 6;
+  const unsigned kBehind = 0x7f800000u;  // +inf: points behind the camera (dropped at staging) go last
+  int pid[kPreSlots];
+  unsigned zb[kPreSlots];
+#pragma unroll
+  for (int s = 0; s < kPreSlots; ++s) {
+    const int i = s * kStage + tid;
+    pid[s] = i < count ? list[i] : -1;
+  }
+  unsigned lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+  for (int s = 0; s < kPreSlots; ++s) {
+    zb[s] = kBehind;
+    if (pid[s] >= 0) {
+      const float z = points[(int64_t)pid[s] * 3 + 2];
+      if (z >= 0.0f && z < INFINITY) {
+        zb[s] = __float_as_uint(z + 0.0f);
+        lo = zb[s] < lo ? zb[s] : lo;
+        hi = zb[s] > hi ? zb[s] : hi;
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned lo2 = (unsigned)__shfl_xor((int)lo, d), hi2 = (unsigned)__shfl_xor((int)hi, d);
+    lo = lo2 < lo ? lo2 : lo;
+    hi = hi2 > hi ? hi2 : hi;
+  }
+  L.hist[tid] = 0;
+  if (tid <= kPreSlots) L.cmin[tid] = kBehind;
+  if (tid == 0) {
+    L.range[0] = 0xffffffffu;
+    L.range[1] = 0u;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    atomicMin(&L.range[0], lo);
+    atomicMax(&L.range[1], hi);
+  }
+  __syncthreads();
+  const float zlo = __uint_as_float(L.range[0]);
+  const float span = __uint_as_float(L.range[1]) - zlo;
+  const float scale = span > 0.0f && span < INFINITY ? 255.0f / span : 0.0f;
+  int tag[kPreSlots];
+#pragma unroll
+  for (int s = 0; s < kPreSlots; ++s) {
+    tag[s] = 0;
+    if (pid[s] >= 0) {
+      int b = kStage - 1;
+      if (zb[s] != kBehind) {
+        b = (int)((__uint_as_float(zb[s]) - zlo) * scale);  // monotone in z
+        b = b < 0 ? 0 : (b > kStage - 1 ? kStage - 1 : b);
+      }
+      tag[s] = (b << 16) | atomicAdd(&L.hist[b], 1);
+    }
+  }
+  __syncthreads();
+  {
+    const int c = L.hist[tid];
+    int x = c;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const int y = __shfl_up(x, d);
+      if (lane >= d) x += y;
+    }
+    if (lane == kWave - 1) L.wsum[w] = x;
+    __syncthreads();
+    int before = 0;
+#pragma unroll
+    for (int j = 0; j < kStage / kWave; ++j)
+      if (j < w) before += L.wsum[j];
+    L.start[tid] = before + x - c;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < kPreSlots; ++s) {
+    if (pid[s] >= 0) {
+      const int at = L.start[tag[s] >> 16] + (tag[s] & 0xffff);
+      L.sorted[at] = pid[s];
+      atomicMin(&L.cmin[at >> 8], zb[s]);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {  // suffix minima: cmin[c] = the smallest depth of chunks c, c + 1, ...
+    for (int c = kPreSlots - 1; c >= 0; --c) L.cmin[c] = L.cmin[c] < L.cmin[c + 1] ? L.cmin[c] : L.cmin[c + 1];
+  }
+  __syncthreads();
+}
+
 // PAYLOAD: the queue carries dist2 next to (z, idx).  Without it (long queues: 2 registers per entry instead of 3) the
 // distance is recomputed from the point's coordinates when the pixel is written -- the same two subtractions, two
 // products and one sum as in the test (rasterize_points.cu:55-60), so the same bits.
@@ -54,6 +167,7 @@ __global__ __launch_bounds__(kStage, WAVES) void point_raster_kernel(PointArgs a
   __shared__ int s_order[kStage];
   __shared__ ChunkOrderScratch s_ord;
   __shared__ int s_wcnt[kStage / kWave];
+  __shared__ PreSortLds s_pre;
 
   if (a.overflow != nullptr && (*a.overflow != 0) == BINNED) return;  // uniform (scalar load)
   TileCoord tc;
@@ -100,17 +214,27 @@ __global__ __launch_bounds__(kStage, WAVES) void point_raster_kernel(PointArgs a
     count = (int)a.count[n];
   }
 
+  // more than one chunk (a single one is ordered by chunk_bucket_order anyway) and short enough for the LDS copy: uniform
+  const bool presorted = BINNED && count > kStage && count <= kPreCap;
+  if (presorted) presort_tile(a.points, a.csr.list + src_base, count, s_pre, tid);
+
   Queue q;
   q.init();
   const int K = EXACTK ? KT : a.K;
 
   for (int base = 0; base < count; base += kStage) {
+    if (presorted && base > 0) {
+      // every point of this and the later chunks is at least this deep: done when that is behind every pixel's K-th entry
+      const float low = __uint_as_float(s_pre.cmin[base >> 8]);
+      const bool done = !wave_ok || __ballot(pix_ok && !(low > q.kth_z(K))) == 0;
+      if (__syncthreads_and(done ? 1 : 0)) break;  // uniform
+    }
     const int i = base + tid;
     bool keep = false;
     float px = 0.f, py = 0.f, pz = 0.f, r = 0.f;
     int pid = -1;
     if (i < count) {
-      pid = BINNED ? a.csr.list[src_base + i] : (int)(src_base + i);
+      pid = !BINNED ? (int)(src_base + i) : (presorted ? s_pre.sorted[i] : a.csr.list[src_base + i]);
       const float* g = a.points + (int64_t)pid * 3;
       px = g[0];
       py = g[1];
@@ -236,6 +360,7 @@ __global__ __launch_bounds__(kStage, WAVES) void point_raster_kernel(PointArgs a
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kSortCap = 768;   // keys sorted per round and wave: 2 x 6 KB of LDS
 constexpr int kSortSlots = kSortCap / kWave;
+constexpr int kBatch = 8;           // sub-batches of 64 list entries loaded at once in pass A
 
 __device__ __forceinline__ int depth_bucket(unsigned zbits, float zlo, float scale) {
   const int b = (int)((__uint_as_float(zbits) - zlo) * scale);  // monotone in z: subtraction, product with scale >= 0, conversion
@@ -302,33 +427,59 @@ __global__ __launch_bounds__(kWave, 2) void point_sorted_kernel(PointArgs a) {
         kmax = kl > kmax ? kl : kmax;
       }
     }
-    // ---- pass A ----
+    // ---- pass A ----  kBatch x 64 list entries in flight at once: a lane's loads (list entry -> point, radius) are a chain of two
+    // memory round trips, and one entry per lane and trip made this pass the kernel (first build: 27 chains per wave on
+    // BASELINE configs[3], ~0.1 ms of 0.13 at K = 1).  The sub-batches are committed in list order; the one that would not fit the
+    // round's buffer ends the round and is read again by the next (only the first round is order-free anyway).
     int nc = 0;
     unsigned zlo_l = 0xffffffffu, zhi_l = 0u;
-    while (pos < count && nc <= kSortCap - kWave) {  // uniform
-      const int i = pos + lane;
-      bool keep = false;
-      unsigned long long key = 0;
-      if (i < count) {
-        const int pid = BINNED ? a.csr.list[src_base + i] : (int)(src_base + i);
-        const float* g = a.points + (int64_t)pid * 3;
-        const float px = g[0], py = g[1], pz = g[2];
-        const float r = a.radius[pid];
-        // a pixel with dist2 < r*r lies inside [x-r, x+r] x [y-r, y+r]: the cull of point_raster_kernel, on the sub-tile
-        const bool off = sub_x0 > px + r || sub_x1 < px - r || sub_y0 > py + r || sub_y1 < py - r;
-        // +0.0 canonicalises a zero depth: the keys order by their bits (as the pair queues of the kernel above)
-        key = ((unsigned long long)__float_as_uint(pz + 0.0f) << 32) | (unsigned)pid;
-        keep = !(pz < 0.0f) && !off && key < kmax;
+    bool full = false;
+    while (pos < count && !full) {  // uniform
+      int pid[kBatch];
+      float px[kBatch], py[kBatch], pz[kBatch], pr[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        const int i = pos + u * kWave + lane;
+        pid[u] = -1;
+        if (i < count) pid[u] = BINNED ? a.csr.list[src_base + i] : (int)(src_base + i);
       }
-      const unsigned long long km = __ballot(keep);
-      if (keep) {
-        s_a[nc + mask_rank(km)] = key;
-        const unsigned zb = (unsigned)(key >> 32);
-        zlo_l = zb < zlo_l ? zb : zlo_l;
-        zhi_l = zb > zhi_l ? zb : zhi_l;
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        px[u] = py[u] = pz[u] = pr[u] = 0.0f;
+        if (pid[u] >= 0) {
+          const float* g = a.points + (int64_t)pid[u] * 3;
+          px[u] = g[0];
+          py[u] = g[1];
+          pz[u] = g[2];
+          pr[u] = a.radius[pid[u]];
+        }
       }
-      nc += __popcll(km);
-      pos += kWave;
+      int done = 0;
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        if (!full && pos + u * kWave < count) {  // uniform
+          // a pixel with dist2 < r*r lies inside [x-r, x+r] x [y-r, y+r]: the cull of point_raster_kernel, on the sub-tile
+          const bool off = sub_x0 > px[u] + pr[u] || sub_x1 < px[u] - pr[u] || sub_y0 > py[u] + pr[u] || sub_y1 < py[u] - pr[u];
+          // +0.0 canonicalises a zero depth: the keys order by their bits (as the pair queues of the kernel above)
+          const unsigned long long key = ((unsigned long long)__float_as_uint(pz[u] + 0.0f) << 32) | (unsigned)pid[u];
+          const bool keep = pid[u] >= 0 && !(pz[u] < 0.0f) && !off && key < kmax;
+          const unsigned long long km = __ballot(keep);
+          const int c = __popcll(km);
+          if (nc + c > kSortCap) {
+            full = true;
+          } else {
+            if (keep) {
+              s_a[nc + mask_rank(km)] = key;
+              const unsigned zb = (unsigned)(key >> 32);
+              zlo_l = zb < zlo_l ? zb : zlo_l;
+              zhi_l = zb > zhi_l ? zb : zhi_l;
+            }
+            nc += c;
+            done = u + 1;
+          }
+        }
+      }
+      pos += done * kWave;
     }
     if (nc == 0) continue;  // uniform
     // ---- pass B: exact ascending order of s_a[0 .. nc) ----
@@ -394,10 +545,17 @@ __global__ __launch_bounds__(kWave, 2) void point_sorted_kernel(PointArgs a) {
     }
     __syncthreads();
     // ---- pass C: front to back ----
+    // (the x, y, r of block jb + 64 are requested before block jb is walked: the walk has no memory access of its own)
+    unsigned long long ck = lane < nc ? s_a[lane] : ~0ull;
+    float cx = 0.0f, cy = 0.0f, cr = 0.0f;
+    if (lane < nc) {
+      const float* g = a.points + (int64_t)(unsigned)ck * 3;
+      cx = g[0];
+      cy = g[1];
+      cr = a.radius[(unsigned)ck];
+    }
 #pragma unroll 1
     for (int jb = 0; jb < nc; jb += kWave) {
-      const int j = jb + lane;
-      const unsigned long long ck = j < nc ? s_a[j] : ~0ull;
       const unsigned clo = (unsigned)ck, chi = (unsigned)(ck >> 32);
       {
         // the block's first key is its smallest: is it still below some pixel's K-th key?
@@ -405,13 +563,14 @@ __global__ __launch_bounds__(kWave, 2) void point_sorted_kernel(PointArgs a) {
                                       (unsigned)__builtin_amdgcn_readfirstlane((int)clo);
         if (__ballot(pix_ok && k0 < kth) == 0) break;  // uniform
       }
-      float cx = 0.0f, cy = 0.0f, cr2 = 0.0f;
-      if (j < nc) {
-        const float* g = a.points + (int64_t)clo * 3;
+      const float bx = cx, by = cy, br2 = cr * cr;
+      const int jn = jb + kWave + lane;
+      ck = jn < nc ? s_a[jn] : ~0ull;
+      if (jn < nc) {
+        const float* g = a.points + (int64_t)(unsigned)ck * 3;
         cx = g[0];
         cy = g[1];
-        const float r = a.radius[clo];
-        cr2 = r * r;
+        cr = a.radius[(unsigned)ck];
       }
       const int m = min(kWave, nc - jb);
       for (int t = 0; t < m; ++t) {  // uniform
@@ -419,10 +578,10 @@ __global__ __launch_bounds__(kWave, 2) void point_sorted_kernel(PointArgs a) {
                                        (unsigned)__builtin_amdgcn_readlane((int)clo, t);
         const bool live = pix_ok && key < kth;
         if (__ballot(live) == 0) break;  // uniform: keys ascend, so do the misses
-        const float dx = xf - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cx), t));
-        const float dy = yf - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cy), t));
+        const float dx = xf - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx), t));
+        const float dy = yf - __int_as_float(__builtin_amdgcn_readlane(__float_as_int(by), t));
         const float dist2 = dx * dx + dy * dy;
-        if (live && dist2 < __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cr2), t))) {
+        if (live && dist2 < __int_as_float(__builtin_amdgcn_readlane(__float_as_int(br2), t))) {
           if (first) {  // uniform
             s_queue[cnt * kWave + lane] = key;
             ++cnt;
@@ -447,25 +606,60 @@ __global__ __launch_bounds__(kWave, 2) void point_sorted_kernel(PointArgs a) {
   }
 
   if (pix_ok) {
+    // a pixel's K entries are contiguous in each output: 16-byte stores when K % 4 == 0, 8-byte ones when K is even
     const int64_t base = (((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi)) * K;
-    for (int k = 0; k < K; ++k) {
-      int id = -1;
-      float z = -1.0f, d2 = -1.0f;
+    auto entry = [&](int k, int* id, float* z, float* d2) {
+      *id = -1;
+      *z = -1.0f;
+      *d2 = -1.0f;
       if (k < cnt) {
         const unsigned long long key = s_queue[k * kWave + lane];
-        id = (int)(unsigned)key;
-        z = __uint_as_float((unsigned)(key >> 32));
-        const float* g = a.points + (int64_t)id * 3;
+        *id = (int)(unsigned)key;
+        *z = __uint_as_float((unsigned)(key >> 32));
+        const float* g = a.points + (int64_t)*id * 3;
         const float dx = xf - g[0];
         const float dy = yf - g[1];
-        d2 = dx * dx + dy * dy;
+        *d2 = dx * dx + dy * dy;
       }
-      a.idxs[base + k] = id;
-      a.zbuf[base + k] = z;
-      a.dists[base + k] = d2;
+    };
+    if ((K & 3) == 0) {
+      for (int k = 0; k < K; k += 4) {
+        int id[4];
+        float z[4], d2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) entry(k + j, &id[j], &z[j], &d2[j]);
+        *reinterpret_cast<int4*>(a.idxs + base + k) = make_int4(id[0], id[1], id[2], id[3]);
+        *reinterpret_cast<float4*>(a.zbuf + base + k) = make_float4(z[0], z[1], z[2], z[3]);
+        *reinterpret_cast<float4*>(a.dists + base + k) = make_float4(d2[0], d2[1], d2[2], d2[3]);
+      }
+    } else if ((K & 1) == 0) {
+      for (int k = 0; k < K; k += 2) {
+        int id[2];
+        float z[2], d2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) entry(k + j, &id[j], &z[j], &d2[j]);
+        *reinterpret_cast<int2*>(a.idxs + base + k) = make_int2(id[0], id[1]);
+        *reinterpret_cast<float2*>(a.zbuf + base + k) = make_float2(z[0], z[1]);
+        *reinterpret_cast<float2*>(a.dists + base + k) = make_float2(d2[0], d2[1]);
+      }
+    } else {
+      for (int k = 0; k < K; ++k) {
+        int id;
+        float z, d2;
+        entry(k, &id, &z, &d2);
+        a.idxs[base + k] = id;
+        a.zbuf[base + k] = z;
+        a.dists[base + k] = d2;
+      }
     }
   }
 }
+
+// Which kernel (1M points, 512^2, r = 0.01, points_fine ms; profiles/r05/c5): register queues + tile pre-sort / sorted kernel
+//   K = 1 0.045 / 0.136, 4 0.067 / 0.156, 8 0.098 / 0.186, 10 0.112 / 0.208, 12 0.186 / 0.213, 16 0.259 / 0.291, 24 0.656 / 0.361,
+//   32 0.603 / 0.481 -- and beyond 32 (round-4 register / private-memory queues) 50 1.57 / 0.73, 64 2.01 / 0.97, 100 3.0 / 1.35,
+//   150 15.4 / 2.63.  (Round 4 without the pre-sort: K = 1 0.079, 8 0.152, 10 0.180, 16 0.334.)
+constexpr int kQueueMaxK = 16;
 
 #define P3D_COMMA ,
 template <bool BINNED>
@@ -474,20 +668,13 @@ int launch_point_raster_queues(const PointArgs& a, hipStream_t stream) {
   LaunchScope ls(BINNED ? "points_fine" : "points_naive", stream);
   const int K = a.K;
   // The common capacities as payload-free pair queues with one 64-bit key compare per entry (topk.h: TopKPairs<KT, true, 0>;
-  // the distance is recomputed at the store; staged depths are >= +0).  Measured in round 3 against the cndmask queues
-  // below (1M points, 512^2): K = 10 0.27 -> 0.18 ms, K = 32 1.55 -> 0.73, K = 50 2.34 -> 1.54, K = 100 9.1 -> 3.0 ms
-  // (two waves per SIMD instead of one with 241 AGPRs).  Other K take the queue of the next capacity below.
+  // the distance is recomputed at the store; staged depths are >= +0).  Other K take the register queue of the next capacity.
 #define P3D_PQ(KT_, WAVES_) \
   point_raster_kernel<TopKPairs<KT_ P3D_COMMA true P3D_COMMA 0>, KT_, true, BINNED, false, WAVES_, true><<<grid, kStage, 0, stream>>>(a)
   switch (K) {
     case 8: P3D_PQ(8, 2); return launch_status();
     case 10: P3D_PQ(10, 2); return launch_status();
     case 16: P3D_PQ(16, 2); return launch_status();
-    case 32: P3D_PQ(32, 2); return launch_status();
-    case 40: P3D_PQ(40, 2); return launch_status();
-    case 50: P3D_PQ(50, 2); return launch_status();
-    case 64: P3D_PQ(64, 2); return launch_status();
-    case 100: P3D_PQ(100, 1); return launch_status();
     default: break;
   }
 #undef P3D_PQ
@@ -503,30 +690,14 @@ int launch_point_raster_queues(const PointArgs& a, hipStream_t stream) {
     point_raster_kernel<TopKReg<10, 1>, 10, true, BINNED><<<grid, kStage, 0, stream>>>(a);
   else if (K <= 12)
     point_raster_kernel<TopKReg<12, 1>, 12, true, BINNED><<<grid, kStage, 0, stream>>>(a);
-  else if (K <= 16)
+  else
     point_raster_kernel<TopKReg<16, 1>, 16, true, BINNED><<<grid, kStage, 0, stream>>>(a);
-  else if (K <= 24)  // 3 registers per entry: still cheaper than a queue in private memory, which a dense cloud keeps full
-    point_raster_kernel<TopKReg<24, 1>, 24, true, BINNED><<<grid, kStage, 0, stream>>>(a);
-  else if (K <= 32)
-    point_raster_kernel<TopKReg<32, 1>, 32, true, BINNED><<<grid, kStage, 0, stream>>>(a);
-  // Longer queues stay in registers too, without the payload.  A dense cloud keeps the queue full (~80 splats cover a
-  // pixel at the BASELINE density), so a queue in private memory shifts O(K) entries through scratch for every
-  // admitted splat (K = 50: 7.8 ms, K = 100: 14.7 ms); here an insertion is ~5 VALU per slot on registers.
-  else if (K <= 40)
-    point_raster_kernel<TopKReg<40, 0>, 40, true, BINNED, false, 2><<<grid, kStage, 0, stream>>>(a);
-  else if (K <= 50)  // an insertion walks the whole queue: capacities follow the common settings (50, 100) exactly
-    point_raster_kernel<TopKReg<50, 0>, 50, true, BINNED, false, 2><<<grid, kStage, 0, stream>>>(a);
-  else if (K <= 64)
-    point_raster_kernel<TopKReg<64, 0>, 64, true, BINNED, false, 2><<<grid, kStage, 0, stream>>>(a);
-  else if (K <= 100)  // 65..99: the pair queue of 100 entries with K live ones (TopKReg<100, 0> spilled 465 VGPRs: refused by the build)
-    point_raster_kernel<TopKPairs<100, true, 0>, 100, true, BINNED, false, 1><<<grid, kStage, 0, stream>>>(a);
-  else  // 101..150: 300 queue registers do not fit the 256 VGPRs + 256 AGPRs of a lane without scratch
-    point_raster_kernel<TopKMem<P3D_MAX_K, 1>, P3D_MAX_K, false, BINNED><<<grid, kStage, 0, stream>>>(a);
   return launch_status();
 }
 
 template <bool BINNED>
 int launch_point_raster(const PointArgs& a, hipStream_t stream) {
+  if (a.K <= kQueueMaxK) return launch_point_raster_queues<BINNED>(a, stream);
   const size_t grid = (size_t)tile_grid(a.tm) * 4;  // one single-wave workgroup per 8x8 sub-tile
   if (grid > 0x7fffffffull) return P3D_ERR_INVALID_ARG;
   const size_t dyn = (size_t)a.K * kWave * sizeof(unsigned long long);
