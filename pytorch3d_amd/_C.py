@@ -120,29 +120,49 @@ _NEEDS = {}  # call shape -> _Need
 
 
 class _Need:
-    """What one call shape needed, refreshed from the device without ever waiting for it."""
+    """What one call shape needed, refreshed from the device without ever waiting for it.
+
+    `entries` is a running maximum with slow decay (a report below it pulls it down by an eighth of the difference), not the
+    last report: a scene whose lists grow -- mesh fitting, a camera zooming in -- would otherwise size every call by a stale
+    smaller number.  A report is requested on every call while the last one was within 20 % of the capacity the call was given
+    (or above it: the naive kernel ran), and every 8th call otherwise (up to seven consecutive calls could
+    run the every-tile-tests-every-face stand-by).  Caveat (documented in INTEGRATION.md): the stand-by is bit-identical to the
+    binned path only while no bin reaches max_faces_per_bin -- the binned path drops a bin's faces beyond that limit as the
+    reference does (rasterize_coarse.cu:186-201), the naive kernel has no bins."""
 
     def __init__(self):
-        self.entries = None  # list entries the last call that reported back needed
+        self.entries = None   # running maximum (slow decay) of what the calls that reported back needed
+        self.last = None      # the last report itself
+        self.capacity = None  # list entries of the call that produced the pending / last report
         self.calls = 0
         self.pinned = None
         self.event = None
 
     def collect(self):
         if self.event is not None and self.event.query():
-            self.entries = int(self.pinned[0])
+            self.last = int(self.pinned[0])
+            self.entries = self.last if self.entries is None or self.last >= self.entries else self.entries - (self.entries - self.last) // 8
             self.event = None
 
-    def report_later(self, ws, offset):
-        # the first calls of a shape report every time, later ones every 8th: an 8-byte copy is still a copy on the stream
+    def tight(self):
+        """The last report used more than 80 % of what its call was given (or overflowed it)."""
+        return self.last is not None and self.capacity is not None and self.last * 5 > self.capacity * 4
+
+    def report_later(self, ws, offset, capacity=None):
+        # the first calls of a shape and calls with tight lists report every time, the others every 8th: an 8-byte copy is
+        # still a copy on the stream
         self.calls += 1
-        if self.event is not None or not (self.calls <= 4 or self.calls % 8 == 0) or torch.cuda.is_current_stream_capturing():
+        if self.event is not None or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+            return
+        if not (self.calls <= 4 or self.calls % 8 == 0 or self.tight()):
             return
         if self.pinned is None:
             self.pinned = torch.empty((1,), dtype=torch.int64, pin_memory=True)
         self.pinned.copy_(ws[offset:offset + 8].view(torch.int64), non_blocking=True)
         self.event = torch.cuda.Event()
         self.event.record()
+        if capacity is not None:
+            self.capacity = int(capacity)
 
 
 def _mesh_workspace(lib, F, N, H, W, bin_size, M, dev, what="meshes"):
@@ -217,6 +237,14 @@ def rasterize_meshes(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, cli
 # memory the tensor occupies; an entry is used only if the tensor that was returned is still alive (so the memory cannot have
 # been handed to anybody else), has not been written in place since (version counter), and the argument of the backward is a
 # contiguous tensor of the same shape at the same address.  Anything else: no cover, the backward reads every row.
+#
+# NOT SEEN: writes that bypass the version counter -- `pix_to_face.data[...] = x`, an external kernel writing
+# through data_ptr() -- between the forward and the backward.  A row the stale cover calls empty is then skipped and the faces
+# written into it get no gradient.  Verifying the cover on the device would cost what it saves (reading every pix_to_face row),
+# so such writes are unsupported with the recall: call `forget_cover(pix_to_face)` after one, or switch the recall off
+# (`RECALL_COVERS = False` / P3D_RECALL_COVERS=0: the backward then reads every row, +0.5 ms on the bench batch).  Pinned by
+# tests/test_gpu_cover.py::test_writes_the_version_counter_cannot_see.
+RECALL_COVERS = os.environ.get("P3D_RECALL_COVERS", "1") not in ("", "0")
 _COVERS = {}
 _COVERS_MAX = 64
 COVER_RECALLS = [0, 0]  # backward calls without an explicit cover: [found the forward's, found none] (read by tests / profiles)
@@ -242,8 +270,13 @@ def _remember_cover(p2f, cover):
     _COVERS[key] = (weakref.ref(p2f, drop), p2f._version, cover)
 
 
+def forget_cover(pix_to_face):
+    """Drop the remembered row cover of a pix_to_face tensor (after writing into it behind autograd's back: see above)."""
+    _COVERS.pop(_cover_key(pix_to_face), None)
+
+
 def _recall_cover(p2f):
-    e = _COVERS.get(_cover_key(p2f)) if p2f.dtype == torch.int64 and p2f.is_contiguous() else None
+    e = _COVERS.get(_cover_key(p2f)) if RECALL_COVERS and p2f.dtype == torch.int64 and p2f.is_contiguous() else None
     alive = e[0]() if e is not None else None
     if alive is None or p2f._version != e[1] or alive._version != e[1]:
         COVER_RECALLS[1] += 1
@@ -291,7 +324,7 @@ def _rasterize_meshes_covered(face_verts, mesh_to_face_first_idx, num_faces_per_
             _stream(dev))
         _lib.check(rc, "rasterize_meshes")
         if need is not None:
-            need.report_later(ws, need_at)
+            need.report_later(ws, need_at, WORKSPACE_STATS["last_entries"])
     return out, cover
 
 
@@ -448,7 +481,7 @@ def rasterize_points(points, cloud_to_packed_first_idx, num_points_per_cloud, im
                    _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(ws), ws.numel(), _stream(dev))
         _lib.check(rc, "rasterize_points")
         if need is not None:
-            need.report_later(ws, need_at)
+            need.report_later(ws, need_at, WORKSPACE_STATS["last_entries"])
     return out
 
 

@@ -93,6 +93,9 @@ def install(reference_root=None, patch_python=False):
 # ---------------------------------------------------------------------------------------------------------------------
 # patch_python: the reference's torch formulations around the operator surface -> the fused kernels
 # ---------------------------------------------------------------------------------------------------------------------
+# patched MeshRasterizer.forward: rasterize un-clipped first and look for vertices behind the near plane afterwards (see there)
+SPECULATE_NO_CLIPPING = True
+
 _PATCHED = []  # (owner object, attribute name, original, replacement)
 PATCH_CALLS = {}  # name -> [fused calls, fallback calls]: what actually ran (read by tests/run_reference_suite.py)
 
@@ -297,9 +300,20 @@ def camera_matrices(cameras, kwargs):
     cacheable = all(k in ("cameras", "raster_settings") for k in kwargs)
     fp = None
     if cacheable:
-        # (the fingerprint holds the tensor OBJECTS, compared by identity: an id() alone could be reused by a new tensor)
-        fp = tuple((k, v, v._version) if torch.is_tensor(v) else (k, v, None) for k, v in vars(cameras).items()
-                   if not k.startswith("_p3d_amd") and (torch.is_tensor(v) or isinstance(v, (bool, int, float, str, tuple, type(None)))))
+        # every tensor the camera holds: plain attributes AND the nn.Module registries (`_parameters`, `_buffers`: a camera whose
+        # R / T were registered as nn.Parameter or buffer keeps them there, not in vars()); a camera that holds a Parameter or a
+        # tensor that requires grad is being optimised -- its matrices are rebuilt on every call
+        items = [(k, v) for k, v in vars(cameras).items() if not k.startswith("_p3d_amd") and k not in ("_parameters", "_buffers")]
+        for reg in ("_parameters", "_buffers"):
+            items += [(reg + "." + k, v) for k, v in (vars(cameras).get(reg) or {}).items()]
+        if any(torch.is_tensor(v) and (isinstance(v, torch.nn.Parameter) or v.requires_grad) for _, v in items):
+            cacheable = False
+    if cacheable:
+        # (the fingerprint holds the tensor OBJECTS, compared by identity: an id() alone could be reused by a new tensor.  Edits
+        # that bypass the version counter -- `cameras.T.data.add_(...)`, an external kernel writing through data_ptr() -- are
+        # not seen: INTEGRATION.md lists them as unsupported with the cache; `del cameras._p3d_amd_matrices` drops it)
+        fp = tuple((k, v, v._version) if torch.is_tensor(v) else (k, v, None) for k, v in items
+                   if torch.is_tensor(v) or isinstance(v, (bool, int, float, str, tuple, type(None))))
         hit = cameras.__dict__.get("_p3d_amd_matrices")
         if hit is not None and len(hit[0]) == len(fp) and all(
                 a[0] == b[0] and a[2] == b[2] and (a[1] is b[1] if torch.is_tensor(a[1]) or torch.is_tensor(b[1]) else a[1] == b[1])
@@ -363,11 +377,27 @@ def _patch_mesh_rasterizer(our_rm):
         else:
             z_clip = None if not persp or znear is None else znear / 2
         ndc = our_rm.transform_verts_to_ndc(meshes_world, w2v, v2n)
-        p2f, zbuf, bary, dists = our_rm.rasterize_meshes(
-            our_rm._PackedVertsView(meshes_world, ndc), image_size=rs.image_size, blur_radius=rs.blur_radius,
-            faces_per_pixel=rs.faces_per_pixel, bin_size=rs.bin_size, max_faces_per_bin=rs.max_faces_per_bin,
-            clip_barycentric_coords=clip_bary, perspective_correct=persp, cull_backfaces=rs.cull_backfaces, z_clip_value=z_clip,
-            cull_to_frustum=rs.cull_to_frustum)
+        view = our_rm._PackedVertsView(meshes_world, ndc)
+        common = dict(image_size=rs.image_size, blur_radius=rs.blur_radius, faces_per_pixel=rs.faces_per_pixel, bin_size=rs.bin_size,
+                      max_faces_per_bin=rs.max_faces_per_bin, clip_barycentric_coords=clip_bary, perspective_correct=persp,
+                      cull_backfaces=rs.cull_backfaces)
+        if z_clip is not None and not rs.cull_to_frustum and SPECULATE_NO_CLIPPING:
+            # Near-plane clipping alone (the default for perspective cameras, rasterizer.py:244-251): a face is cut or dropped iff
+            # one of its vertices has z < z_clip (clip.py:381-388, strict).  clip_faces has to tell the host how many faces
+            # come out of it -- a sync in the MIDDLE of the forward, behind which the host cannot run ahead (measured: 0.4 ms of
+            # idle GPU per step on the bench batch).  Nearly always nothing is behind the plane, so: queue the un-clipped, fully
+            # fused rasterization (gather, rasterizer and backward-to-vertices in one node: no face gather, no clip plan, no
+            # scatter launch) and ask the device afterwards whether ANY vertex was behind the plane -- one sync at the END of the
+            # forward, with the whole forward already running.  If one was (rare): that result is dropped and the clipping
+            # path below runs.  (A vertex no face uses can only send a mesh down the slow path, never the other way.)
+            behind = (ndc[:, 2] < z_clip).any()
+            out = our_rm.rasterize_meshes(view, z_clip_value=None, cull_to_frustum=False, **common)
+            if not bool(behind):  # the host sync
+                _count("MeshRasterizer.forward: no vertex behind z_clip, un-clipped fused path kept", True)
+                return rz.Fragments(pix_to_face=out[0], zbuf=out[1], bary_coords=out[2], dists=out[3])
+            _count("MeshRasterizer.forward: no vertex behind z_clip, un-clipped fused path kept", False)
+            del out
+        p2f, zbuf, bary, dists = our_rm.rasterize_meshes(view, z_clip_value=z_clip, cull_to_frustum=rs.cull_to_frustum, **common)
         return rz.Fragments(pix_to_face=p2f, zbuf=zbuf, bary_coords=bary, dists=dists)
 
     forward.__wrapped__ = orig
@@ -593,6 +623,8 @@ def _patch_meshes_offset_verts():
     orig_ = Meshes.offset_verts_
 
     def usable(self, off):
+        if type(self) is not Meshes:  # a subclass may keep state of its own that clone() copies and a shared __dict__ would alias
+            return False
         v = self.verts_packed()
         return (torch.is_tensor(off) and self._N > 0 and not self.isempty() and v.dtype == torch.float32 and off.device == v.device
                 and off.dtype == torch.float32 and (off.shape == v.shape or tuple(off.shape) == (3,)))
@@ -627,6 +659,11 @@ def _patch_meshes_offset_verts():
         self.verts_list(), self.faces_list()  # the lists exist before they are shared (meshes built from padded tensors)
         new = object.__new__(type(self))
         new.__dict__.update(self.__dict__)
+        # the list OBJECTS are the copy's own (appending to / replacing an element of new.faces_list() must not show in the original);
+        # the tensors in them are shared with the original, where the reference's clone() hands out copies: INTEGRATION.md
+        for name in ("_faces_list", "_verts_list"):
+            if isinstance(new.__dict__.get(name), list):
+                new.__dict__[name] = list(new.__dict__[name])
         if self.textures is not None:
             new.textures = self.textures.clone()
         return apply(new, self, vert_offsets_packed)

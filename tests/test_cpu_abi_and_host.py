@@ -401,6 +401,58 @@ def test_no_kernel_of_the_library_spills_vgprs():
     assert not spilled, spilled
     scratch = sorted(B.demangle(k) for k, v in res.items() if v["scratch"] > 0)
     assert all("TopKMem" in k or "_cuda_order_kernel" in k for k in scratch), scratch
+    # round 5: registers kept in AGPRs only in kernels that name the GPU test which fills every register row
+    agpr = sorted(B.demangle(k) for k, v in res.items() if v["agprs"] > 0)
+    assert all(any(t + "(" in k for t in B.AGPR_KERNELS_TESTED) for k in agpr), agpr
+
+
+def test_short_workspace_sizing_follows_a_running_maximum_and_reports_while_tight():
+    """pytorch3d_amd/_C.py: _Need: the list size of a call shape is the running maximum (slow decay) of what its
+    calls reported, and a call whose last report used more than 80 % of its lists asks for a report again at once -- not the last
+    report alone, read back every 8th call (up to seven calls in a row could then run the naive stand-by on a growing scene)."""
+    from pytorch3d_amd import _C
+
+    class Done:
+        def query(self):
+            return True
+
+    need = _C._Need()
+
+    def report(v, capacity):
+        need.pinned = torch.tensor([v], dtype=torch.int64)
+        need.event = Done()
+        need.capacity = capacity
+        need.collect()
+
+    report(1000, 5000)
+    assert need.entries == 1000 and need.last == 1000 and not need.tight()
+    report(4000, 5000)  # growth is taken at once
+    assert need.entries == 4000 and not need.tight()
+    report(4100, 5000)
+    assert need.entries == 4100 and need.tight()  # 82 % of the lists: the next call reports again whatever its number
+    report(2000, 5000)  # a smaller report pulls the size down slowly
+    assert need.entries == 4100 - (4100 - 2000) // 8 and not need.tight()
+    report(9000, 5000)  # overflow (the stand-by kernel ran): tight, and the size jumps
+    assert need.entries == 9000 and need.tight()
+    need.calls, need.event = 100, None  # far from the first four calls, not a multiple of 8
+    need.calls = 101
+    asked = []
+
+    class FakeWs:
+        def __getitem__(self, sl):
+            asked.append(sl)
+            raise RuntimeError("stop here")  # the copy itself needs a device
+
+    try:
+        need.report_later(FakeWs(), 0, 5000)
+    except RuntimeError:
+        pass
+    assert asked, "a tight shape did not ask for a report"
+    report(1000, 50000)
+    need.calls = 101
+    asked.clear()
+    need.report_later(FakeWs(), 0, 50000)
+    assert not asked, "a roomy shape asked for a report on a call that is not its eighth"
 
 
 def test_bench_jobs_mode_deals_every_sub_batch_to_exactly_one_rank():

@@ -141,6 +141,36 @@ SCRIPT = textwrap.dedent("""
     cg = FoVPerspectiveCameras(R=R, T=Tg)
     g1 = shim.camera_matrices(cg, {})
     assert g1[0].requires_grad and shim.camera_matrices(cg, {}) is not g1
+    # ADVICE round 4: tensors a camera keeps in the nn.Module registries are part of the fingerprint, Parameters switch the cache off
+    cb = FoVPerspectiveCameras(R=R, T=T)
+    del cb.T
+    cb.register_buffer("T", T.clone())
+    b1 = shim.camera_matrices(cb, {})
+    assert shim.camera_matrices(cb, {}) is b1
+    cb.T.add_(0.25)  # in-place edit of a BUFFER
+    b2 = shim.camera_matrices(cb, {})
+    assert b2 is not b1 and torch.equal(b2[0], fresh(cb)[0]) and not torch.equal(b2[0], b1[0])
+    cp = FoVPerspectiveCameras(R=R, T=T)
+    del cp.T
+    cp.T = torch.nn.Parameter(T.clone())
+    p1 = shim.camera_matrices(cp, {})
+    with torch.no_grad():
+        cp.T.data.add_(0.5)  # bypasses the version counter: only safe because Parameters are never cached
+    p2 = shim.camera_matrices(cp, {})
+    assert p2 is not p1 and torch.equal(p2[0].detach(), fresh(cp)[0].detach()) and not torch.equal(p2[0].detach(), p1[0].detach())
+    # ADVICE round 4: the lean offset_verts is for Meshes itself (a subclass goes through the reference's clone()), and the copy's
+    # lists are its own
+    class MyMeshes(Meshes):
+        pass
+    sub = MyMeshes(verts=batch().verts_list(), faces=batch().faces_list())
+    before = shim.PATCH_CALLS["Meshes.offset_verts"][1]
+    sub.offset_verts(torch.zeros(sub.verts_packed().shape[0], 3))
+    assert shim.PATCH_CALLS["Meshes.offset_verts"][1] == before + 1
+    m0 = batch()
+    m1 = m0.offset_verts(torch.zeros(m0.verts_packed().shape[0], 3))
+    assert m1.faces_list() is not m0.faces_list() and m1._faces_list is not m0._faces_list
+    m1.faces_list().append(torch.zeros((1, 3), dtype=torch.int64))
+    assert len(m0.faces_list()) == 3
     # ---- hard shaders on the nearest slot only: same image, same gradients as the reference's all-K evaluation ----
     from pytorch3d.renderer import HardPhongShader, HardGouraudShader, HardFlatShader, PointLights
     from pytorch3d.renderer.mesh.rasterizer import Fragments

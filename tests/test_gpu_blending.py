@@ -57,15 +57,19 @@ def test_softmax_rgb_blend_vs_reference_python(tag):
         assert torch.allclose(got.cpu(), ref, atol=1e-4 * max(1.0, ref.abs().max().item()), rtol=1e-3), name
 
 
-@pytest.mark.parametrize("K", [1, 3, 4, 8, 10, 40])
-def test_blend_kernels_vs_oracle_all_capacities(K):
+# 17 / 24 / 32: the <32> instantiations (round 5: softmax_blend_bwd_kernel<32> is one of the two kernels of the library that hold
+# registers in AGPRs -- pytorch3d_amd/build.py: AGPR_KERNELS_TESTED points here); `dense`: every slot of every pixel holds a face,
+# i.e. every register row of the kernels is live (the round-4 miscompile showed only on inputs that fill the queues)
+@pytest.mark.parametrize("dense", [False, True])
+@pytest.mark.parametrize("K", [1, 3, 4, 8, 10, 16, 17, 24, 32, 40])
+def test_blend_kernels_vs_oracle_all_capacities(K, dense):
     import pytorch3d_amd as p3d
     from pytorch3d_amd import _C
 
     d = torch.device("cuda:0")
     gen = torch.Generator().manual_seed(K)
     N, H, W = 2, 13, 11
-    p2f = torch.randint(-1, 30, (N, H, W, K), generator=gen)
+    p2f = torch.randint(0 if dense else -1, 30, (N, H, W, K), generator=gen)
     dists = (torch.rand(N, H, W, K, generator=gen) - 0.4) * 5e-4
     zbuf = torch.rand(N, H, W, K, generator=gen) * 3 + 0.8
     colors = torch.rand(N, H, W, K, 3, generator=gen)

@@ -189,3 +189,56 @@ def test_the_reference_style_backward_call_finds_the_cover_of_its_pix_to_face():
     hits, misses = _C.COVER_RECALLS
     _C.rasterize_meshes_backward(fv, out[0], gz, gb, gd, True, True)
     assert _C.COVER_RECALLS == [hits, misses + 1]
+
+
+def test_writes_the_version_counter_cannot_see():
+    """ADVICE round 4 / VERDICT round 4 weak 11: `pix_to_face.data[...] = x` (its own version counter) between the forward and the
+    backward leaves the remembered cover stale -- documented as unsupported with the recall (pytorch3d_amd/_C.py: RECALL_COVERS).
+    This test pins the three ways out: `forget_cover`, `RECALL_COVERS = False`, and that an ordinary in-place write IS seen."""
+    from pytorch3d_amd import _C
+
+    d = torch.device("cuda:0")
+    _, fv, first, cnt = _batch(2, 9)
+    nbr = torch.full((fv.shape[0],), -1, dtype=torch.int64, device=d)
+    size, K = (64, 64), 4
+    out = _C.rasterize_meshes(fv, first, cnt, nbr, size, 1e-3, K, 32, 5000, True, True, False)
+    p2f = out[0]
+    empty = (p2f[..., 0] < 0).nonzero()
+    assert empty.shape[0] > 0
+    # a face painted into a 16-pixel row segment the forward left empty, behind autograd's back
+    cov = _C._recall_cover(p2f)
+    bits = cover_from_pix_to_face(p2f)
+    assert torch.equal(cov, bits)
+    n, y, x = None, None, None
+    for e in empty.tolist():
+        if not (int(bits[e[0], e[1] // 16, e[2] // 16]) >> (e[1] % 16)) & 1:
+            n, y, x = e
+            break
+    assert n is not None, "no empty row segment in this render"
+    p2f.data[n, y, x, 0] = 0
+    gen = torch.Generator().manual_seed(4)
+    gz, gd = (torch.randn(out[1].shape, generator=gen).to(d) for _ in range(2))
+    gb = torch.randn(out[2].shape, generator=gen).to(d)
+    truth = _C.rasterize_meshes_backward(fv, p2f.clone(), gz, gb, gd, True, True)  # a copy: every row is read
+    scale = truth.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1e-6)
+    # (1) forget_cover
+    _C.forget_cover(p2f)
+    hits, misses = _C.COVER_RECALLS
+    got = _C.rasterize_meshes_backward(fv, p2f, gz, gb, gd, True, True)
+    assert _C.COVER_RECALLS == [hits, misses + 1]
+    assert float(((got - truth).abs() / scale).max()) < 5e-3
+    # (2) the switch
+    out2 = _C.rasterize_meshes(fv, first, cnt, nbr, size, 1e-3, K, 32, 5000, True, True, False)
+    out2[0].data[n, y, x, 0] = 0
+    saved = _C.RECALL_COVERS
+    _C.RECALL_COVERS = False
+    try:
+        got = _C.rasterize_meshes_backward(fv, out2[0], gz, gb, gd, True, True)
+    finally:
+        _C.RECALL_COVERS = saved
+    assert float(((got - truth).abs() / scale).max()) < 5e-3
+    # (3) the same write through the ordinary API bumps the version counter: the cover is dropped by itself
+    out3 = _C.rasterize_meshes(fv, first, cnt, nbr, size, 1e-3, K, 32, 5000, True, True, False)
+    out3[0][n, y, x, 0] = 0
+    got = _C.rasterize_meshes_backward(fv, out3[0], gz, gb, gd, True, True)
+    assert float(((got - truth).abs() / scale).max()) < 5e-3
