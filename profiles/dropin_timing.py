@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--image-size", type=int, default=512)
+    ap.add_argument("--cprofile", action="store_true", help="after the timing: 20 more steps under cProfile, top functions on stderr")
     ap.add_argument("--torus-div", type=float, default=1.0, help="1.0: SURVEY 8(d) config 3 as written (the bench headline); 1.5: the lighter batch of rounds 1-3")
     args = ap.parse_args()
     stage = os.path.join(ROOT, "oracle", "_ref", "reference_py")
@@ -113,6 +114,20 @@ def main():
     if args.mode == "patched":
         out["patched_calls"] = {k: v for k, v in shim.PATCH_CALLS.items()}
     print(json.dumps(out))
+    if args.cprofile:
+        import cProfile
+        import pstats
+
+        pr = cProfile.Profile()
+        torch.cuda.synchronize()
+        pr.enable()
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        pr.disable()
+        st = pstats.Stats(pr, stream=sys.stderr)
+        st.sort_stats("cumulative").print_stats(45)
+        st.sort_stats("tottime").print_stats(25)
 
 
 if __name__ == "__main__":

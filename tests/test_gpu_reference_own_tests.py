@@ -100,8 +100,15 @@ def test_reference_hot_path_test_modules_pass_on_the_hip_kernels(report):
             assert patched.get(name, {}).get("fused", 0) > 0, f"{name}: the fused replacement never ran ({patched.get(name)})"
         print("fused / fallback calls of the patched reference functions:", patched)
     # (patched: the fused rasterize_meshes calls the C ABI itself, forward and backward, not `_C.rasterize_meshes*`)
-    for op in ("rasterize_points", "rasterize_points_backward", "accum_alphacomposite", "accum_weightedsumnorm", "accum_weightedsum",
-               "interp_face_attrs_forward", "sigmoid_alpha_blend") + (("rasterize_meshes", "rasterize_meshes_backward") if patched is None else ()):
+    # (patched, round 5: alpha_composite / norm_weighted_sum / weighted_sum are one autograd node over the C ABI, and PointsRasterizer.forward
+    # transforms the packed points itself: counted in the patch record, not as `_C.accum_*` calls)
+    ops = ("rasterize_points", "rasterize_points_backward", "interp_face_attrs_forward", "sigmoid_alpha_blend")
+    if patched is None:
+        ops += ("rasterize_meshes", "rasterize_meshes_backward", "accum_alphacomposite", "accum_weightedsumnorm", "accum_weightedsum")
+    else:
+        for name in ("alpha_composite", "norm_weighted_sum", "weighted_sum", "PointsRasterizer.forward"):
+            assert patched.get(name, {}).get("fused", 0) > 0, f"{name}: the fused replacement never ran ({patched.get(name)})"
+    for op in ops:
         assert calls["hip"].get(op, 0) > 0, f"{op} never reached pytorch3d_amd"
 
 
