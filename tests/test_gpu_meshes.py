@@ -86,6 +86,41 @@ def test_all_queue_capacities(K):
             _assert_fwd_equal(ours, ref, tag=f"K={K} persp={persp} clip={clip} 20x37 bin={bin_size}")
 
 
+@pytest.mark.parametrize("K", [49, 64, 100, 150])
+@pytest.mark.parametrize("persp,clip", [(True, True), (False, False)])
+def test_k_above_the_register_queues_on_a_scene_with_sparse_and_dense_tiles(K, persp, clip):
+    """raster_mesh.hip, K > 48 (the private-memory queue; round 5 tried a register first pass + redo of the tiles with a full queue
+    on this test: profiles/r05/exp_two_pass_k49.md, dropped).  A scene with BOTH kinds of tiles: two
+    small meshes seen with SoftRas blur (a covered pixel holds ~10-30 faces: first-pass tiles) and, in one corner, a stack of 60
+    coincident-footprint triangles at different depths (every pixel under it overflows 32: redone tiles) -- against the oracle,
+    binned; images with ragged tiles; with the reference's neighbour rule in play (GENERAL nest) in a third mesh."""
+    gen = torch.Generator().manual_seed(4000 + K)
+    verts, faces = U.hetero_batch(2, seed=11, fmin=300, fmax=700)
+    from pytorch3d_amd import PackedMeshes
+
+    m = PackedMeshes(verts, faces)
+    fv = m.verts_packed()[m.faces_packed()].contiguous()
+    stack = torch.tensor([[-0.95, -0.95, 1.0], [-0.45, -0.95, 1.0], [-0.7, -0.5, 1.0]]).repeat(60, 1, 1)
+    stack[:, :, 2] += torch.rand(60, 1, generator=gen) * 2.0
+    stack[:, :, :2] += (torch.rand(60, 3, 2, generator=gen) - 0.5) * 0.02
+    soup = U.triangle_soup(40, gen)
+    fv = torch.cat([fv, stack, soup], 0).contiguous()
+    first = torch.cat([m.mesh_to_faces_packed_first_idx(), torch.tensor([int(m.faces_packed().shape[0]) + 60])])
+    count = torch.cat([m.num_faces_per_mesh(), torch.tensor([40])])
+    count[1] += 60  # the stack belongs to the second mesh
+    nbr = torch.full((fv.shape[0],), -1, dtype=torch.int64)
+    s0 = int(first[2])
+    for a in range(s0, s0 + 40, 4):
+        nbr[a], nbr[a + 1] = a + 1, a
+    size, blur = (72, 100), 2e-3
+    ref = orc.rasterize_meshes_naive(fv, first, count, nbr, size, blur, K, persp, clip, False)
+    per_pixel = (ref[0] >= 0).sum(-1)
+    assert int((per_pixel > 32).sum()) > 0 and int(((per_pixel > 0) & (per_pixel < 32)).sum()) > 0, "the scene should hold both kinds of pixels"
+    for bin_size in (16, 32):
+        ours = _run_ours(fv, first, count, nbr, size, blur, K, bin_size, 2000, persp, clip, False)
+        _assert_fwd_equal(ours, ref, tag=f"K={K} bin={bin_size}")
+
+
 def test_k_too_large_raises():
     from pytorch3d_amd import _C
 
