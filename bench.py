@@ -266,6 +266,45 @@ def other_configs(lib, _lib, device):
         alg = H * H * K * 28 + F * 44 + 16
         out["config2_cow_256_k8_fwd"] = {"wall_ms": round(wall, 4), "kernels_ms": kern, "kernel_sum_ms": round(sum(kern.values()), 4),
                                          "algorithmic_bytes": alg, "gbps_of_wall": alg / (wall * 1e-3) / 1e9, "faces": F}
+        # the same call (`_C.rasterize_meshes` on the gathered face vertices) replayed from a HIP graph: five launches, the gaps between
+        # which are what separates wall from kernel sum on one small image (the C ABI allocates nothing and never synchronises)
+        try:
+            fv = m.verts_packed()[m.faces_packed()].contiguous()
+            first = torch.zeros(1, dtype=torch.int64, device=device)
+            cnt = torch.tensor([F], dtype=torch.int64, device=device)
+            nbr = torch.full((F,), -1, dtype=torch.int64, device=device)
+            cargs = (fv, first, cnt, nbr, (H, H), blur, K, 16, max(10000, F // 5), True, True, False)
+            ref = _C.rasterize_meshes(*cargs)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    _C.rasterize_meshes(*cargs)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                gout = _C.rasterize_meshes(*cargs)
+
+            def wall_of(fn, iters=200):
+                for _ in range(10):
+                    fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / iters * 1e3
+
+            eager_ms = wall_of(lambda: _C.rasterize_meshes(*cargs))
+            replay_ms = wall_of(graph.replay)
+            graph.replay()
+            torch.cuda.synchronize()
+            out["config2_cow_256_k8_fwd"]["hip_graph"] = {
+                "eager_C_call_ms": round(eager_ms, 4), "graph_replay_ms": round(replay_ms, 4),
+                "identical_outputs": bool(all(torch.equal(a, b) for a, b in zip(gout, ref))),
+                "note": "_C.rasterize_meshes (binning + fine, 4-5 launches) captured with torch.cuda.graph and replayed"}
+        except Exception as e:
+            out["config2_cow_256_k8_fwd"]["hip_graph"] = {"error": repr(e)}
     except Exception as e:
         out["config2_cow_256_k8_fwd"] = {"error": repr(e)}
     # configs[3]: 1M points, 512^2, K=10, r=0.01, rasterizer + alpha compositor, forward + backward

@@ -19,7 +19,10 @@ import sys
 OURS = {"mesh_raster_kernel": "mesh_fine", "area_list_kernel": "mesh_backward_areas", "mesh_backward": "mesh_backward", "points_raster": "points_fine",
         "bin_count": "bin_count", "bin_fill": "bin_fill", "bin_scan_offsets": "bin_scan_offsets",
         "bin_scan_rows": "bin_scan_rows", "bin_scan_small": "bin_scan_small", "bin_plan": "bin_plan", "gather_faces": "gather_face_verts",
-        "scatter_face": "scatter_face_grads"}
+        "scatter_face": "scatter_face_grads", "point_raster_kernel": "points_fine (register queues + tile pre-sort)",
+        "point_sorted_kernel": "points_fine (sorted kernel, LDS queues)", "point_backward": "points_backward",
+        "composite_fwd": "composite_fwd", "composite_bwd": "composite_bwd", "transform_verts": "transform_verts",
+        "interp_fwd": "interp_fwd", "interp_bwd": "interp_bwd", "softmax_blend": "softmax_blend", "phong": "phong", "soft_phong": "soft_phong"}
 
 
 def short(name):
@@ -31,9 +34,12 @@ def short(name):
 
 def main():
     src, dst = sys.argv[1], sys.argv[2]
+    # argv[4] (optional): the profiled command, when it is not bench.py's (then profiles/traffic.json is left alone: bench.py reads
+    # it as the counters of ITS dominant kernel)
+    cmd_text = sys.argv[4] if len(sys.argv) > 4 else "python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs --no-dropin"
     lines = ["# rocprofv3 summary (" + os.path.basename(dst) + ")", "",
-             "Command: `python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs --no-dropin` under `rocprofv3` "
-             "(profiles/run_rocprof.sh), MI355X / gfx950.", ""]
+             "Command: `" + cmd_text + "` under `rocprofv3` (profiles/run_rocprof.sh: `--kernel-trace --stats`, then one run per `--pmc` set), "
+             "MI355X / gfx950.", ""]
     f = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
     if f:
         rows = list(csv.DictReader(open(f[0])))
@@ -92,6 +98,9 @@ def main():
             lines.append("")
     with open(dst + "_rocprof.md", "w") as fh:
         fh.write("\n".join(lines) + "\n")
+    if len(sys.argv) > 4:
+        print("\n".join(lines))
+        return
     here = os.path.dirname(os.path.abspath(__file__))
     with open(os.path.join(here, "traffic.json"), "w") as fh:
         json.dump({k: v["hbm_bytes"] for k, v in traffic.items()} | {"_detail": traffic, "_source": os.path.basename(dst),

@@ -838,33 +838,61 @@ __global__ __launch_bounds__(256) void point_backward_kernel(const float* __rest
   // the backward un-flips the stored indices); once per wave
   float centres = (lane & 8) ? pix_to_ndc(H - 1 - (y0 + (lane & 7)), H, W) : pix_to_ndc(W - 1 - (x0 + (lane & 7)), W, H);
   asm volatile("" : "+v"(centres));
-  for (int base = 0; base < total; base += 64) {
+  // Three steps in flight (round 5): a step's chain is idx -> point gather -> table; with one step at a time the wave sat out
+  // two memory round trips per 64 entries (0.078 ms for 55 MB on BASELINE configs[3], the wave waiting or stalled 88 % of its
+  // cycles).  Now, while step s is summed, step s + 1's point gather (its index arrived during step s - 1) and step s + 2's
+  // index and upstream gradients (which need no index) are on their way.
+  struct Step {
+    int p, xo, yo;
+    float gd, gz, qx, qy;
+  };
+  auto fetch_idx = [&](int base) {  // the index and the two gradients of the lane's entry of the step that starts at `base`
+    Step st;
+    st.p = -1;
+    st.gd = st.gz = st.qx = st.qy = 0.f;
     const int e = base + lane;
-    int p = -1;
-    float g[3] = {0.f, 0.f, 0.f};
     // exact for these small operands: (e + 0.5) / d is at least 0.5 / d away from an integer
     const int r = (int)(((float)e + 0.5f) * inv_run);
     const int ee = e - r * run;
-    const int xo = x0 + (int)(((float)ee + 0.5f) * inv_k);
-    const int yo = y0 + r;
+    st.xo = x0 + (int)(((float)ee + 0.5f) * inv_k);
+    st.yo = y0 + r;
+    if (e < total) {
+      const int64_t i = (((int64_t)n * H + st.yo) * W + x0) * K + ee;
+      st.p = idxs[i];
+      st.gd = grad_dists[i];
+      st.gz = grad_zbuf[i];
+    }
+    return st;
+  };
+  auto fetch_point = [&](Step* st) {
+    if (st->p >= 0) {
+      st->qx = points[(int64_t)st->p * 3 + 0];
+      st->qy = points[(int64_t)st->p * 3 + 1];
+    }
+  };
+  Step s0 = fetch_idx(0);
+  Step s1 = fetch_idx(64);  // (past the end of the tile: no loads, p = -1)
+  fetch_point(&s0);
+  for (int base = 0; base < total; base += 64) {
+    const Step cur = s0;
+    fetch_point(&s1);
+    const Step s2 = fetch_idx(base + 128);
+    s0 = s1;
+    s1 = s2;
+    float g[3] = {0.f, 0.f, 0.f};
     // the pixel's centre from the lanes that hold the tile's eight column / row centres (two ds_bpermute instead of two
     // pix_to_ndc with an IEEE division each per entry); outside the branch: every lane takes part in the exchange, lanes
     // past the end of the tile read some lane of the table and never use it
-    const float xf = __int_as_float(__builtin_amdgcn_ds_bpermute(((xo - x0) & 7) << 2, __float_as_int(centres)));
-    const float yf = __int_as_float(__builtin_amdgcn_ds_bpermute((8 + ((yo - y0) & 7)) << 2, __float_as_int(centres)));
-    if (e < total) {
-      const int64_t i = (((int64_t)n * H + yo) * W + x0) * K + ee;
-      p = idxs[i];
-      if (p >= 0) {
-        const float gd = grad_dists[i];
-        const float dx = points[(int64_t)p * 3 + 0] - xf;
-        const float dy = points[(int64_t)p * 3 + 1] - yf;
-        g[0] = 2.0f * gd * dx;
-        g[1] = 2.0f * gd * dy;
-        g[2] = grad_zbuf[i];
-      }
+    const float xf = __int_as_float(__builtin_amdgcn_ds_bpermute(((cur.xo - x0) & 7) << 2, __float_as_int(centres)));
+    const float yf = __int_as_float(__builtin_amdgcn_ds_bpermute((8 + ((cur.yo - y0) & 7)) << 2, __float_as_int(centres)));
+    if (cur.p >= 0) {
+      const float dx = cur.qx - xf;
+      const float dy = cur.qy - yf;
+      g[0] = 2.0f * cur.gd * dx;
+      g[1] = 2.0f * cur.gd * dy;
+      g[2] = cur.gz;
     }
-    tab.add(grad_points, lane, p, g);
+    tab.add(grad_points, lane, cur.p, g);
   }
   if (tab.used > 0) tab.flush(grad_points, lane);
 }

@@ -40,6 +40,8 @@ def test_single_rank_line_small():
     assert j["scaling"] == "weak" and "other_configs" in j
     oc = j["other_configs"]
     assert "wall_ms" in oc["config2_cow_256_k8_fwd"], oc
+    hg = oc["config2_cow_256_k8_fwd"]["hip_graph"]  # round 5: the same operator call replayed from a HIP graph
+    assert hg.get("identical_outputs") is True and hg["graph_replay_ms"] > 0 and hg["eager_C_call_ms"] > 0, hg
     assert "wall_ms" in oc["config4_points_1m_512_k10_fwd_bwd"], oc
     # the unmodified reference MeshRasterizer through the shim, both modes (or a reason where the reference is not staged)
     dr = j["dropin"]
