@@ -271,6 +271,20 @@ int p3d_composite_backward(int mode, const float* grad_outputs, const float* fea
                            const int64_t alphas_strides[4], const int64_t idx_strides[4], float* grad_features,
                            float* grad_alphas, p3d_stream_t stream);
 
+/* The same operators with the FEATURES addressed through element strides (channel, point): (P, 1) is the contiguous (C,P) tensor
+ * above, (1, C) the transposed view of a (P, C) tensor -- what PointsRenderer passes (renderer/points/renderer.py:67:
+ * `features_packed().permute(1, 0)`; the reference's launchers copy it to (C,P) first, compositing/alpha_composite.h:63-65).
+ * With (1, C) a point's channels share a cache line: the gathers of a pixel cost one memory request per entry instead of C.
+ * grad_features: C * P floats of one allocation in the layout grad_feature_strides names, fully written. */
+int p3d_composite_forward_strided(int mode, const float* features, const int64_t feature_strides[2], const float* alphas,
+                                  const int64_t* points_idx, int N, int C, int64_t P, int K, int H, int W,
+                                  const int64_t alphas_strides[4], const int64_t idx_strides[4], float* result,
+                                  p3d_stream_t stream);
+int p3d_composite_backward_strided(int mode, const float* grad_outputs, const float* features, const int64_t feature_strides[2],
+                                   const float* alphas, const int64_t* points_idx, int N, int C, int64_t P, int K, int H, int W,
+                                   const int64_t alphas_strides[4], const int64_t idx_strides[4], float* grad_features,
+                                   const int64_t grad_feature_strides[2], float* grad_alphas, p3d_stream_t stream);
+
 /* ---- interpolate_face_attributes ----------------------------------------------------- */
 
 /* replaces InterpFaceAttrsForward/Backward, pytorch3d/csrc/interp_face_attrs/interp_face_attrs.h:46-116.

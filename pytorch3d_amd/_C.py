@@ -582,9 +582,26 @@ def _composite_check(features, alphas, points_idx):
     return dev
 
 
+def _feature_layout(features):
+    """(tensor to hand over, its (channel, point) element strides, interleaved?).  Two layouts go to the kernels as they are: the
+    contiguous (C, P) tensor of the reference's operators, and the transposed view of a contiguous (P, C) tensor -- what
+    PointsRenderer passes (renderer/points/renderer.py:67); there a point's channels are adjacent and the gathers of a pixel cost
+    one memory request per entry instead of C (include/p3d_amd.h: p3d_composite_forward_strided).  Anything else is copied."""
+    C, P = features.shape
+    st = features.stride()
+    if C > 1 and P > 1 and st[0] == 1 and st[1] == C:
+        return features, (1, C), True
+    f = features.contiguous()
+    return f, (P, 1), False
+
+
+def _strides2(st):
+    return (ctypes.c_int64 * 2)(int(st[0]), int(st[1]))
+
+
 def _composite_forward(mode, name, features, alphas, points_idx):
     dev = _composite_check(features, alphas, points_idx)
-    feats = features.contiguous()
+    feats, fst, _ = _feature_layout(features)
     N, K, H, W = alphas.shape
     C, P = feats.shape
     lib = _lib.load()
@@ -592,8 +609,8 @@ def _composite_forward(mode, name, features, alphas, points_idx):
         out = torch.empty((N, C, H, W), dtype=torch.float32, device=dev)
         if out.numel() == 0:
             return out
-        rc = lib.p3d_composite_forward(mode, _ptr(feats), _ptr(alphas), _ptr(points_idx), N, C, P, K, H, W,
-                                       _strides4(alphas), _strides4(points_idx), _ptr(out), _stream(dev))
+        rc = lib.p3d_composite_forward_strided(mode, _ptr(feats), _strides2(fst), _ptr(alphas), _ptr(points_idx), N, C, P, K, H, W,
+                                               _strides4(alphas), _strides4(points_idx), _ptr(out), _stream(dev))
         _lib.check(rc, name)
     return out
 
@@ -601,16 +618,22 @@ def _composite_forward(mode, name, features, alphas, points_idx):
 def _composite_backward(mode, name, grad_outputs, features, alphas, points_idx):
     dev = _composite_check(features, alphas, points_idx)
     _need_gpu(grad_outputs, "grad_outputs")
-    feats = features.contiguous()
+    feats, fst, interleaved = _feature_layout(features)
     go = _c(grad_outputs, torch.float32)
     N, K, H, W = alphas.shape
     C, P = feats.shape
     lib = _lib.load()
     with torch.cuda.device(dev):
-        gf = torch.empty((C, P), dtype=torch.float32, device=dev)
+        # grad_features in the layout of the features: (C, P) planes, or -- for the renderers' transposed (P, C) view -- the
+        # transposed view of a (P, C) tensor (the permute in front of the operator then hands autograd a contiguous gradient)
+        if interleaved:
+            gf = torch.empty((P, C), dtype=torch.float32, device=dev).t()
+        else:
+            gf = torch.empty((C, P), dtype=torch.float32, device=dev)
         ga = torch.empty((N, K, H, W), dtype=torch.float32, device=dev)
-        rc = lib.p3d_composite_backward(mode, _ptr(go), _ptr(feats), _ptr(alphas), _ptr(points_idx), N, C, P, K, H, W,
-                                        _strides4(alphas), _strides4(points_idx), _ptr(gf), _ptr(ga), _stream(dev))
+        rc = lib.p3d_composite_backward_strided(mode, _ptr(go), _ptr(feats), _strides2(fst), _ptr(alphas), _ptr(points_idx), N, C, P, K,
+                                                H, W, _strides4(alphas), _strides4(points_idx), _ptr(gf), _strides2(fst), _ptr(ga),
+                                                _stream(dev))
         _lib.check(rc, name)
     return gf, ga
 

@@ -75,6 +75,11 @@ _SIGNATURES = {
                                       ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_ptr, c_ptr]),
     "p3d_composite_backward": (c_int, [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_i64, c_int, c_int, c_int,
                                        ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_ptr, c_ptr, c_ptr]),
+    "p3d_composite_forward_strided": (c_int, [c_int, c_ptr, ctypes.POINTER(c_i64), c_ptr, c_ptr, c_int, c_int, c_i64, c_int, c_int, c_int,
+                                              ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_ptr, c_ptr]),
+    "p3d_composite_backward_strided": (c_int, [c_int, c_ptr, c_ptr, ctypes.POINTER(c_i64), c_ptr, c_ptr, c_int, c_int, c_i64, c_int, c_int,
+                                               c_int, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_ptr, ctypes.POINTER(c_i64), c_ptr,
+                                               c_ptr]),
     "p3d_interp_face_attrs_forward": (c_int, [c_int, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr]),
     "p3d_interp_face_attrs_backward": (c_int, [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr,
                                                c_ptr]),

@@ -58,6 +58,7 @@ struct WaveTable {
   int used;             // occupied slots (wave-uniform)
   int gen;              // step counter (wave-uniform), > 0
   int64_t plane = 0;        // kPlanar: floats per output plane; kChunk: floats per primitive record
+  int64_t fstride = 1;      // kPlanar: floats between the entries of consecutive primitives inside a plane (interleaved outputs: plane 1, fstride NV)
   int pitch = 0;            // kChunk: floats between the NV/4 sub-rows of a record
   int nlive = NV;           // kPlanar: planes that exist; kChunk: live columns of the chunk (others are never flushed)
   const int64_t* index = nullptr;  // kCorners: (P, NV/3) vertex ids
@@ -66,7 +67,7 @@ struct WaveTable {
 
   // address of value j of primitive f, or nullptr when that value has no destination
   __device__ __forceinline__ float* dest(float* __restrict__ out, int f, int j) const {
-    if constexpr (LAYOUT == kPlanar) return j < nlive ? out + j * plane + f : nullptr;
+    if constexpr (LAYOUT == kPlanar) return j < nlive ? out + j * plane + (int64_t)f * fstride : nullptr;
     if constexpr (LAYOUT == kChunk) return (j & 3) < nlive ? out + (int64_t)f * plane + (j >> 2) * pitch + (j & 3) : nullptr;
     if constexpr (LAYOUT == kCorners) {
       int64_t v = index[(int64_t)f * (NV / 3) + j / 3];

@@ -32,7 +32,8 @@ def test_header_declares_the_operator_surface():
     for want in ("p3d_rasterize_meshes", "p3d_rasterize_meshes_naive", "p3d_rasterize_meshes_coarse",
                  "p3d_rasterize_meshes_fine", "p3d_rasterize_meshes_backward", "p3d_rasterize_points",
                  "p3d_rasterize_points_naive", "p3d_rasterize_points_coarse", "p3d_rasterize_points_fine",
-                 "p3d_rasterize_points_backward", "p3d_composite_forward", "p3d_composite_backward",
+                 "p3d_rasterize_points_backward", "p3d_composite_forward", "p3d_composite_backward", "p3d_composite_forward_strided",
+                 "p3d_composite_backward_strided",
                  "p3d_interp_face_attrs_forward", "p3d_interp_face_attrs_backward", "p3d_sigmoid_alpha_blend_forward",
                  "p3d_sigmoid_alpha_blend_backward", "p3d_softmax_rgb_blend_forward", "p3d_softmax_rgb_blend_backward",
                  "p3d_gather_face_verts", "p3d_scatter_face_grads", "p3d_clip_faces_plan", "p3d_clip_faces_emit",

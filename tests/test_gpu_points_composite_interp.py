@@ -192,7 +192,9 @@ def test_compositors(mode, K, permuted):
     gen = torch.Generator().manual_seed(K)
     N, C, P, H, W = 2, (5 if K != 10 else 9), 300, 13, 17  # C = 9: three channel passes through the table, the last partial
     feat = torch.rand(C, P, generator=gen)
-    if permuted:  # what the renderers pass: permuted views of (N,H,W,K) tensors
+    if permuted:  # what the renderers pass: the transposed view of (P, C) features (round 5: read through their strides) ...
+        feat = torch.rand(P, C, generator=gen).t()
+    if permuted:  # ... and permuted views of (N,H,W,K) tensors
         alphas = torch.rand(N, H, W, K, generator=gen).permute(0, 3, 1, 2)
         idx = torch.randint(-1, P, (N, H, W, K), generator=gen).permute(0, 3, 1, 2)
     else:
@@ -204,6 +206,7 @@ def test_compositors(mode, K, permuted):
     assert torch.equal(fwd, ref), f"forward not bit-exact: {(fwd - ref).abs().max().item()}"
     rgf, rga = orc.composite_backward(mode, go, feat, alphas, idx)
     gf, ga = getattr(_C, "accum_" + mode + "_backward")(go.to(d), feat.to(d), alphas.to(d), idx.to(d))
+    assert tuple(gf.shape) == (C, P) and (gf.stride() == ((1, C) if permuted else (P, 1)))  # the gradient in the features' layout
     assert torch.allclose(gf.cpu(), rgf, atol=2e-5, rtol=1e-4)
     assert torch.allclose(ga.cpu(), rga, atol=2e-5 * max(1.0, rga.abs().max().item()), rtol=1e-4)
     ref_mod = orc.ref_module()

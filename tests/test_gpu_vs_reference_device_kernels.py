@@ -292,8 +292,10 @@ def test_points_and_compositors_vs_reference_device_code():
         assert torch.allclose(gf, tf, atol=1e-4, rtol=1e-4) and torch.allclose(ga, ta, atol=1e-5, rtol=1e-4), name
 
 
-def test_config4_at_full_size_vs_reference_device_code():
-    """BASELINE configs[3] exactly as `bench.py` times it (other_configs: 1M points xy ~ U(-1,1), z ~ U(0.5,2.5), seed 0,
+@pytest.mark.parametrize("K", [10, 24])
+def test_config4_at_full_size_vs_reference_device_code(K):
+    """K = 10: the register queues behind the tile pre-sort; K = 24 (round 5): the sorted kernel with its queues in LDS, at the same
+    size.  BASELINE configs[3] exactly as `bench.py` times it (other_configs: 1M points xy ~ U(-1,1), z ~ U(0.5,2.5), seed 0,
     radius 0.01, 512^2, K = 10, bin_size 32, features (3, P)): rasterizer + alpha compositor, forward and
     backward, against the reference's device kernels (rasterize_points.cu:87-217, 366-462; alpha_composite.cu:24-233; the
     reference takes ~96 ms for it on this GPU).  zbuf bit-equal; idx differences only at exact depth ties; dists bit-equal where
@@ -305,7 +307,7 @@ def test_config4_at_full_size_vs_reference_device_code():
 
     d = _d()
     gen = torch.Generator().manual_seed(0)
-    P, H, K, r, C = 1_000_000, 512, 10, 0.01, 3
+    P, H, r, C = 1_000_000, 512, 0.01, 3
     pts = torch.cat([torch.rand(P, 2, generator=gen) * 2 - 1, torch.rand(P, 1, generator=gen) * 2 + 0.5], 1).to(d)
     feats = torch.rand(C, P, generator=gen).to(d)
     first = torch.zeros(1, dtype=torch.int64, device=d)
@@ -324,7 +326,7 @@ def test_config4_at_full_size_vs_reference_device_code():
     tie[..., :-1] |= z[..., :-1] == z[..., 1:]
     tie[..., K - 1] = True
     n_idx = int((~same).sum())
-    print(f"[config 4, 1M points 512^2 K=10] idx differences {n_idx} / {same.numel()}, not at an exact depth tie: "
+    print(f"[config 4, 1M points 512^2 K={K}] idx differences {n_idx} / {same.numel()}, not at an exact depth tie: "
           f"{int((~same & ~tie).sum())}; slot fill {float((a[0] >= 0).float().mean()):.3f}")
     assert bool((same | tie).all()) and n_idx <= 1e-4 * same.numel()
     assert torch.equal(a[2].view(torch.int32)[same], b[2].view(torch.int32)[same]), "dists differ where the index agrees"
