@@ -74,6 +74,10 @@ def parse():
     ap.add_argument("--image-size", type=int, default=512)
     ap.add_argument("--faces-per-pixel", type=int, default=8)
     ap.add_argument("--jobs", type=int, default=0, help="BASELINE configs[4]: a fixed number of jobs (multiple of --batch), strong scaling")
+    ap.add_argument("--prewarm-s", type=float, default=0.4,
+                    help="seconds of the same step, untimed, BEFORE the --warmup steps: a fresh box reaches its steady clocks and a warm "
+                         "allocator only after some tenths of a second of work, and the driver's `--steps 20 --warmup 5` is 65 ms in all "
+                         "(round 4: 6456 Mpix/s in that form against 6648 over 200 steps).  Reported in the line as `prewarm_s`; 0 turns it off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the timing of the unmodified reference MeshRasterizer through the shim")
@@ -574,6 +578,15 @@ def main():
                 gather_state.update(ok=False, how="none", error=f"{type(e2).__name__}: {str(e2)[:300]}")
                 return None
 
+    prewarm_steps = 0
+    if args.prewarm_s > 0:
+        # untimed, ahead of the W warm-up steps (see --prewarm-s): never inside the timed region, never counted as steps
+        t_pw = time.perf_counter()
+        while time.perf_counter() - t_pw < args.prewarm_s:
+            for i in range(8):
+                p2f, zbuf = step(i)
+            torch.cuda.synchronize()
+            prewarm_steps += 8
     for i in range(args.warmup):
         p2f, zbuf = step(i)
     if dist_on and args.warmup > 0:
@@ -697,6 +710,7 @@ def main():
             "n_gpus": world,
             "steps": steps,
             "warmup": args.warmup,
+            "prewarm_s": args.prewarm_s, "prewarm_steps": prewarm_steps,
             "ms_per_step": elapsed / steps * 1e3,
             "ms_per_step_median": median_ms,
             "gather_ms": gather_ms,

@@ -27,6 +27,7 @@ def _check_common(j, n_gpus, steps):
     assert j["metric"].startswith("rasterized Mpix/s") and j["unit"] == "Mpix/s" and j["dtype"] == "f32"
     assert j["n_gpus"] == n_gpus and j["steps"] == steps and j["higher_is_better"] is True and j["vs_baseline"] is None
     assert j["value"] > 0 and j["ms_per_step"] > 0 and "workload" in j["config"]
+    assert j["prewarm_s"] >= 0 and j["prewarm_steps"] >= 0  # untimed steps ahead of the warm-up: disclosed in the line
     r = j["roofline"]
     assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     for k, v in r["per_kernel"].items():
