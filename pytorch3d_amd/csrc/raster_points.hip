@@ -701,14 +701,13 @@ int launch_point_raster(const PointArgs& a, hipStream_t stream) {
   const size_t grid = (size_t)tile_grid(a.tm) * 4;  // one single-wave workgroup per 8x8 sub-tile
   if (grid > 0x7fffffffull) return P3D_ERR_INVALID_ARG;
   const size_t dyn = (size_t)a.K * kWave * sizeof(unsigned long long);
-  if (dyn > 48 * 1024) {  // K > 96: past the default dynamic-LDS limit (gfx950 has 160 KB per CU)
-    static bool raised[2] = {false, false};
-    if (!raised[BINNED ? 1 : 0]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&point_sorted_kernel<BINNED>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              P3D_MAX_K * kWave * (int)sizeof(unsigned long long)) != hipSuccess)
-        return P3D_ERR_LAUNCH;
-      raised[BINNED ? 1 : 0] = true;
-    }
+  if (dyn > 48 * 1024) {
+    // K > 96: past the default dynamic-LDS limit (gfx950 has 160 KB per CU).  Set on every such launch, not cached: the attribute
+    // belongs to the function ON THE CURRENT DEVICE, and launchers are called from several host threads / devices
+    // (nn.DataParallel, tests/test_render_multigpu.py:171) -- no global mutable state in this library (INTEGRATION.md "Contract")
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&point_sorted_kernel<BINNED>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            P3D_MAX_K * kWave * (int)sizeof(unsigned long long)) != hipSuccess)
+      return P3D_ERR_LAUNCH;
   }
   LaunchScope ls(BINNED ? "points_fine" : "points_naive", stream);
   point_sorted_kernel<BINNED><<<(unsigned)grid, kWave, dyn, stream>>>(a);
