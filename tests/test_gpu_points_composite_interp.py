@@ -67,7 +67,7 @@ def test_points_queues_overflow_vs_oracle(K):
 
 
 @pytest.mark.parametrize("K", [1, 5, 10, 16, 60, 150])
-@pytest.mark.parametrize("depths", ["uniform", "quantised", "one_depth"])
+@pytest.mark.parametrize("depths", ["uniform", "quantised", "one_depth", "uniform_5200"])
 def test_points_lists_longer_than_one_sort_round(K, depths):
     """raster_points.hip: point_sorted_kernel sorts at most 768 candidates of a sub-tile per round (round 5).  One cloud of 3300
     points, every splat wider than the image: each sub-tile's list takes five rounds -- the first APPENDS to the queues, the
@@ -78,20 +78,22 @@ def test_points_lists_longer_than_one_sort_round(K, depths):
 
     d = _dev()
     gen = torch.Generator().manual_seed(7000 + K)
-    P = 3400
+    # 3300 points in the first cloud: every tile's list fits the pre-sort's LDS copy (4096); 5100: it does not -- the register-queue
+    # kernels then walk the list in list order as in round 4, the sorted kernel takes seven rounds
+    P = 5200 if depths == "uniform_5200" else 3400
     pts = _cloud(P, gen, zlo=0.1, zhi=2.0)
     if depths == "quantised":
         pts[:, 2] = (pts[:, 2] * 4).round() / 4 + 0.25
     elif depths == "one_depth":
         pts[:, 2] = 1.25
     pts[::97, 2] = -0.5  # behind the camera: dropped
-    first = torch.tensor([0, 3300])
-    count = torch.tensor([3300, 100])
+    first = torch.tensor([0, P - 100])
+    count = torch.tensor([P - 100, 100])
     radius = torch.rand(P, generator=gen) * 0.5 + 2.5
     size = (24, 40)
     ref = orc.rasterize_points_naive(pts, first, count, size, radius, K)
     for bin_size in (0, 8, 32):
-        ours = _C.rasterize_points(pts.to(d), first.to(d), count.to(d), size, radius.to(d), K, bin_size, 4000)
+        ours = _C.rasterize_points(pts.to(d), first.to(d), count.to(d), size, radius.to(d), K, bin_size, 6000)
         ours = [o.cpu() for o in ours]
         assert torch.equal(ours[0], ref[0]), f"idx differs K={K} bin={bin_size}: {(ours[0] != ref[0]).sum().item()}"
         assert torch.equal(ours[1], ref[1]) and torch.equal(ours[2], ref[2])
