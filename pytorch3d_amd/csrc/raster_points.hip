@@ -39,119 +39,6 @@ struct PointArgs {
   const int* overflow;
 };
 
-// Tile pre-sort (round 5).  The chunk loop below visits each 256-point chunk of the tile's list front to back, but the chunks
-// themselves come in list order: on a dense cloud (BASELINE configs[3]: ~1700 points per tile, seven chunks, ~80 splats over
-// every pixel) every chunk holds points that displace queued ones, so all seven are staged and walked and the insertion network
-// runs for most candidates.  The K nearest do not depend on the visiting order, so the workgroup first deals the WHOLE list into
-// 256 depth buckets (one pass: every thread requests its <= 16 list entries and their depths at once -- two memory round trips
-// for the list -- then one integer LDS atomic per point, a workgroup scan, a scatter of the point indices) and the chunk loop
-// reads the bucket-ordered copy: chunk c then holds nearer points than chunk c + 1 (up to bucket granularity), queues fill from
-// the first chunks, and the loop ends as soon as the smallest depth of the chunks still to come (`cmin`, suffix minima) lies
-// behind every pixel's K-th entry in all four waves.  Exactness is the queues' business, as before: the order is only a schedule.
-constexpr int kPreCap = 4096;                 // list entries ordered ahead of the chunk loop (longer lists: list order, as before)
-constexpr int kPreSlots = kPreCap / kStage;   // per thread
-
-struct PreSortLds {
-  int sorted[kPreCap];
-  int hist[kStage];
-  int start[kStage];
-  unsigned cmin[kPreSlots + 1];
-  unsigned range[2];
-  int wsum[kStage / kWave];
-};
-
-// All 256 threads.  list[0 .. count): the tile's points, kStage < count <= kPreCap.  Ends with a barrier.
-__device__ __forceinline__ void presort_tile(const float* __restrict__ points, const int* __restrict__ list, int count, PreSortLds& L,
-                                             int tid) {
-  const int lane = tid & 63, w = tid >> 6;
-  const unsigned kBehind = 0x7f800000u;  // +inf: points behind the camera (dropped at staging) go last
-  int pid[kPreSlots];
-  unsigned zb[kPreSlots];
-#pragma unroll
-  for (int s = 0; s < kPreSlots; ++s) {
-    const int i = s * kStage + tid;
-    pid[s] = i < count ? list[i] : -1;
-  }
-  unsigned lo = 0xffffffffu, hi = 0u;
-#pragma unroll
-  for (int s = 0; s < kPreSlots; ++s) {
-    zb[s] = kBehind;
-    if (pid[s] >= 0) {
-      const float z = points[(int64_t)pid[s] * 3 + 2];
-      if (z >= 0.0f && z < INFINITY) {
-        zb[s] = __float_as_uint(z + 0.0f);
-        lo = zb[s] < lo ? zb[s] : lo;
-        hi = zb[s] > hi ? zb[s] : hi;
-      }
-    }
-  }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    const unsigned lo2 = (unsigned)__shfl_xor((int)lo, d), hi2 = (unsigned)__shfl_xor((int)hi, d);
-    lo = lo2 < lo ? lo2 : lo;
-    hi = hi2 > hi ? hi2 : hi;
-  }
-  L.hist[tid] = 0;
-  if (tid <= kPreSlots) L.cmin[tid] = kBehind;
-  if (tid == 0) {
-    L.range[0] = 0xffffffffu;
-    L.range[1] = 0u;
-  }
-  __syncthreads();
-  if (lane == 0) {
-    atomicMin(&L.range[0], lo);
-    atomicMax(&L.range[1], hi);
-  }
-  __syncthreads();
-  const float zlo = __uint_as_float(L.range[0]);
-  const float span = __uint_as_float(L.range[1]) - zlo;
-  const float scale = span > 0.0f && span < INFINITY ? 255.0f / span : 0.0f;
-  int tag[kPreSlots];
-#pragma unroll
-  for (int s = 0; s < kPreSlots; ++s) {
-    tag[s] = 0;
-    if (pid[s] >= 0) {
-      int b = kStage - 1;
-      if (zb[s] != kBehind) {
-        b = (int)((__uint_as_float(zb[s]) - zlo) * scale);  // monotone in z
-        b = b < 0 ? 0 : (b > kStage - 1 ? kStage - 1 : b);
-      }
-      tag[s] = (b << 16) | atomicAdd(&L.hist[b], 1);
-    }
-  }
-  __syncthreads();
-  {
-    const int c = L.hist[tid];
-    int x = c;
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-      const int y = __shfl_up(x, d);
-      if (lane >= d) x += y;
-    }
-    if (lane == kWave - 1) L.wsum[w] = x;
-    __syncthreads();
-    int before = 0;
-#pragma unroll
-    for (int j = 0; j < kStage / kWave; ++j)
-      if (j < w) before += L.wsum[j];
-    L.start[tid] = before + x - c;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int s = 0; s < kPreSlots; ++s) {
-    if (pid[s] >= 0) {
-      const int at = L.start[tag[s] >> 16] + (tag[s] & 0xffff);
-      L.sorted[at] = pid[s];
-      atomicMin(&L.cmin[at >> 8], zb[s]);
-    }
-  }
-  __syncthreads();
-  if (tid == 0) {  // suffix minima: cmin[c] = the smallest depth of chunks c, c + 1, ...
-    for (int c = kPreSlots - 1; c >= 0; --c) L.cmin[c] = L.cmin[c] < L.cmin[c + 1] ? L.cmin[c] : L.cmin[c + 1];
-  }
-  __syncthreads();
-}
-
 // PAYLOAD: the queue carries dist2 next to (z, idx).  Without it (long queues: 2 registers per entry instead of 3) the
 // distance is recomputed from the point's coordinates when the pixel is written -- the same two subtractions, two
 // products and one sum as in the test (rasterize_points.cu:55-60), so the same bits.
@@ -167,7 +54,6 @@ __global__ __launch_bounds__(kStage, WAVES) void point_raster_kernel(PointArgs a
   __shared__ int s_order[kStage];
   __shared__ ChunkOrderScratch s_ord;
   __shared__ int s_wcnt[kStage / kWave];
-  __shared__ PreSortLds s_pre;
 
   if (a.overflow != nullptr && (*a.overflow != 0) == BINNED) return;  // uniform (scalar load)
   TileCoord tc;
@@ -214,27 +100,17 @@ __global__ __launch_bounds__(kStage, WAVES) void point_raster_kernel(PointArgs a
     count = (int)a.count[n];
   }
 
-  // more than one chunk (a single one is ordered by chunk_bucket_order anyway) and short enough for the LDS copy: uniform
-  const bool presorted = BINNED && count > kStage && count <= kPreCap;
-  if (presorted) presort_tile(a.points, a.csr.list + src_base, count, s_pre, tid);
-
   Queue q;
   q.init();
   const int K = EXACTK ? KT : a.K;
 
   for (int base = 0; base < count; base += kStage) {
-    if (presorted && base > 0) {
-      // every point of this and the later chunks is at least this deep: done when that is behind every pixel's K-th entry
-      const float low = __uint_as_float(s_pre.cmin[base >> 8]);
-      const bool done = !wave_ok || __ballot(pix_ok && !(low > q.kth_z(K))) == 0;
-      if (__syncthreads_and(done ? 1 : 0)) break;  // uniform
-    }
     const int i = base + tid;
     bool keep = false;
     float px = 0.f, py = 0.f, pz = 0.f, r = 0.f;
     int pid = -1;
     if (i < count) {
-      pid = !BINNED ? (int)(src_base + i) : (presorted ? s_pre.sorted[i] : a.csr.list[src_base + i]);
+      pid = BINNED ? a.csr.list[src_base + i] : (int)(src_base + i);
       const float* g = a.points + (int64_t)pid * 3;
       px = g[0];
       py = g[1];
@@ -655,10 +531,366 @@ __global__ __launch_bounds__(kWave, 2) void point_sorted_kernel(PointArgs a) {
   }
 }
 
-// Which kernel (1M points, 512^2, r = 0.01, points_fine ms; profiles/r05/c5): register queues + tile pre-sort / sorted kernel
+// ---------------------------------------------------------------------------------------------------------------------
+// Tile-sorted kernel (round 5, binned launches with K <= kTileSortedMaxK): the cooperative four-wave workgroup of
+// point_raster_kernel (one staging per 16x16 tile, shared by its four 8x8 waves) with the EXACT front-to-back order and the
+// append-only LDS queues of point_sorted_kernel.  Why: with the tile pre-sort point_raster_kernel visits ~250 candidates per wave on
+// BASELINE configs[3], and for every one that ANY of the wave's 64 pixels admits the whole wave runs the sorted-insertion network of
+// its register queue (~5 VALU per entry).  A stream in exact (depth, index) order needs no network -- a hit is appended -- but the
+// pre-sort orders by depth BUCKET only.  So:
+//   * the tile's list is pre-sorted into 256 depth buckets (bucket_sort_tile) and cut into chunks at bucket boundaries (the
+//     buckets that fit 256 entries), so that every key of chunk c + 1 sorts after every key of chunk c;
+//   * a staged chunk is put in exact order by rank: same-bucket entries are adjacent after the ordered compaction, and an
+//     entry moves by (same-bucket entries behind it with a smaller key) - (those ahead of it with a larger key), a window scan of
+//     the bucket's population (~7);
+//   * a wave visits the chunk in that order and appends hits to its pixels' queues ([k][lane] in LDS, as point_sorted_kernel);
+//     a pixel is done at K entries, a wave when its pixels are, the workgroup when its waves are.
+// A bucket of more than 256 points (many equal depths), or a list longer than the pre-sort's LDS copy, makes the stream of that
+// tile non-monotone from there on: its hits are INSERTED (per-lane shift in LDS), exact as ever.
+// Measured (1M points, 512^2, profiles/r05/c16/, c17/): 3976 VALU per wave against 5333 (register queues + pre-sort; 11 531 in round
+// 4), points_fine K = 10 0.108 against 0.114 ms, K = 16 0.229 against 0.251 -- both kernels wait 65-69 % of their wave cycles (seven
+// barriers and a memory round trip per chunk, one image = one round of workgroups): instructions are no longer what binds them.
+// (Tried on top, no gain and dropped: a chunk table computed once + the next chunk's loads requested a chunk ahead.)
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kTileCap = 2048;  // list entries pre-sorted per tile by this kernel (LDS: 8 KB); longer lists: list order + insertion
+
+struct TileSortLds {
+  int sorted[kTileCap];
+  int hist[kStage];
+  int start[kStage];
+  unsigned range[2];
+  int wsum[kStage / kWave];
+};
+
+// The bucket pass: every thread requests its <= 8 list entries and their depths at once (two memory round trips for the list), one
+// integer LDS atomic per point, a workgroup scan, a scatter: sorted[] = the list's point ids in bucket order; hist / start / range
+// stay valid for the caller.  All 256 threads; count <= kTileCap.  Ends with a barrier.
+__device__ __forceinline__ void bucket_sort_tile(const float* __restrict__ points, const int* __restrict__ list, int count,
+                                                 TileSortLds& L, int tid) {
+  constexpr int kSlots = kTileCap / kStage;
+  const int lane = tid & 63, w = tid >> 6;
+  const unsigned kBehind = 0x7f800000u;
+  int pid[kSlots];
+  unsigned zb[kSlots];
+#pragma unroll
+  for (int s = 0; s < kSlots; ++s) {
+    const int i = s * kStage + tid;
+    pid[s] = i < count ? list[i] : -1;
+  }
+  unsigned lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+  for (int s = 0; s < kSlots; ++s) {
+    zb[s] = kBehind;
+    if (pid[s] >= 0) {
+      const float z = points[(int64_t)pid[s] * 3 + 2];
+      if (z >= 0.0f && z < INFINITY) {
+        zb[s] = __float_as_uint(z + 0.0f);
+        lo = zb[s] < lo ? zb[s] : lo;
+        hi = zb[s] > hi ? zb[s] : hi;
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const unsigned lo2 = (unsigned)__shfl_xor((int)lo, d), hi2 = (unsigned)__shfl_xor((int)hi, d);
+    lo = lo2 < lo ? lo2 : lo;
+    hi = hi2 > hi ? hi2 : hi;
+  }
+  L.hist[tid] = 0;
+  if (tid == 0) {
+    L.range[0] = 0xffffffffu;
+    L.range[1] = 0u;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    atomicMin(&L.range[0], lo);
+    atomicMax(&L.range[1], hi);
+  }
+  __syncthreads();
+  const float zlo = __uint_as_float(L.range[0]);
+  const float span = __uint_as_float(L.range[1]) - zlo;
+  const float scale = span > 0.0f && span < INFINITY ? 255.0f / span : 0.0f;
+  int tag[kSlots];
+#pragma unroll
+  for (int s = 0; s < kSlots; ++s) {
+    tag[s] = 0;
+    if (pid[s] >= 0) {
+      int b = kStage - 1;
+      if (zb[s] != kBehind) {
+        b = (int)((__uint_as_float(zb[s]) - zlo) * scale);
+        b = b < 0 ? 0 : (b > kStage - 1 ? kStage - 1 : b);
+      }
+      tag[s] = (b << 16) | atomicAdd(&L.hist[b], 1);
+    }
+  }
+  __syncthreads();
+  {
+    const int c = L.hist[tid];
+    int x = c;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const int y = __shfl_up(x, d);
+      if (lane >= d) x += y;
+    }
+    if (lane == kWave - 1) L.wsum[w] = x;
+    __syncthreads();
+    int before = 0;
+#pragma unroll
+    for (int j = 0; j < kStage / kWave; ++j)
+      if (j < w) before += L.wsum[j];
+    L.start[tid] = before + x - c;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < kSlots; ++s)
+    if (pid[s] >= 0) L.sorted[L.start[tag[s] >> 16] + (tag[s] & 0xffff)] = pid[s];
+  __syncthreads();
+}
+
+// the bucket a depth falls into under bucket_sort_tile's scale (the same expression: the same bucket)
+__device__ __forceinline__ int tile_bucket_of(unsigned zbits, float zlo, float scale) {
+  const int b = (int)((__uint_as_float(zbits) - zlo) * scale);
+  return b < 0 ? 0 : (b > kStage - 1 ? kStage - 1 : b);
+}
+
+template <bool BINNED>
+__global__ __launch_bounds__(kStage, 2) void point_tile_sorted_kernel(PointArgs a) {
+  extern __shared__ __align__(16) unsigned long long s_queues[];  // [wave][k][lane]
+  __shared__ TileSortLds s_ts;
+  __shared__ float4 s_pt[kStage];               // staged point: x, y, z, r (compaction order = bucket order)
+  __shared__ unsigned long long s_key[kStage];  // its key (z bits | index)
+  __shared__ int s_bk[kStage];                  // its bucket
+  __shared__ int s_ord[kStage];                 // staged index of the entry at exact position i
+  __shared__ int s_wcnt[kStage / kWave];
+  __shared__ int s_cut[2];                      // [0] end of the chunk (list position), [1] largest bucket population of the tile
+
+  if (a.overflow != nullptr && (*a.overflow != 0) == BINNED) return;  // uniform (scalar load)
+  TileCoord tc;
+  if (!tile_of_block(a.tm, blockIdx.x, &tc)) return;
+  const int n = tc.n, by = tc.by, bx = tc.bx, H = a.H, W = a.W, K = a.K;
+  const int y_end = min(H, (by + 1) * a.tm.bin_size), x_end = min(W, (bx + 1) * a.tm.bin_size);
+  const int ty0 = by * a.tm.bin_size + tc.ty * kTile, tx0 = bx * a.tm.bin_size + tc.tx * kTile;
+  if (ty0 >= y_end || tx0 >= x_end) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int sy0 = ty0 + (w >> 1) * 8, sx0 = tx0 + (w & 1) * 8;
+  const int yi = sy0 + (lane >> 3), xi = sx0 + (lane & 7);
+  const bool pix_ok = yi < y_end && xi < x_end;
+  const bool wave_ok = sy0 < y_end && sx0 < x_end;
+  const float pxy = (lane & 16) ? pix_to_ndc(ty0 + (lane & 15), H, W) : pix_to_ndc(tx0 + (lane & 15), W, H);
+  auto col_centre = [&](int x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pxy), x - tx0)); };
+  auto row_centre = [&](int y) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pxy), 16 + y - ty0)); };
+  const float xf = __int_as_float(__builtin_amdgcn_ds_bpermute((xi - tx0) << 2, __float_as_int(pxy)));
+  const float yf = __int_as_float(__builtin_amdgcn_ds_bpermute((16 + yi - ty0) << 2, __float_as_int(pxy)));
+  const float tile_x0 = col_centre(tx0), tile_x1 = col_centre(min(tx0 + kTile, x_end) - 1);
+  const float tile_y0 = row_centre(ty0), tile_y1 = row_centre(min(ty0 + kTile, y_end) - 1);
+  const float sub_x0 = col_centre(min(sx0, x_end - 1)), sub_x1 = col_centre(max(min(sx0 + 8, x_end) - 1, tx0));
+  const float sub_y0 = row_centre(min(sy0, y_end - 1)), sub_y1 = row_centre(max(min(sy0 + 8, y_end) - 1, ty0));
+
+  int64_t src_base;
+  int count;
+  if (BINNED) {
+    const int64_t row = ((int64_t)n * a.tm.BH + by) * a.tm.BW + bx;
+    src_base = a.csr.offset[row];
+    count = a.csr.total[row];
+  } else {
+    src_base = a.first[n];
+    count = (int)a.count[n];
+  }
+  unsigned long long* queue = s_queues + (size_t)w * K * kWave;
+  int cnt = 0;
+  unsigned long long kth = ~0ull;
+  // the stream is in queue order (hits can be appended) while every chunk's keys sort after the previous chunk's
+  const bool sorted_list = BINNED && count <= kTileCap;
+  bool monotone = sorted_list;
+  float zlo = 0.0f, scale = 0.0f;
+  if (sorted_list && count > 0) {
+    bucket_sort_tile(a.points, a.csr.list + src_base, count, s_ts, tid);
+    zlo = __uint_as_float(s_ts.range[0]);
+    const float span = __uint_as_float(s_ts.range[1]) - zlo;
+    scale = span > 0.0f && span < INFINITY ? 255.0f / span : 0.0f;
+    int hmax = s_ts.hist[tid];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) hmax = max(hmax, __shfl_xor(hmax, d));
+    if (tid == 0) s_cut[1] = 0;
+    __syncthreads();
+    if (lane == 0) atomicMax(&s_cut[1], hmax);
+    __syncthreads();
+  }
+  const int window = sorted_list && count > 0 ? s_cut[1] : kStage;  // same-bucket entries sit within this distance of each other
+
+  int lo_pos = 0;
+  while (lo_pos < count) {  // uniform
+    // ---- the chunk [lo_pos, hi_pos): whole buckets that fit 256 entries ----
+    int hi_pos = min(lo_pos + kStage, count);
+    if (sorted_list && hi_pos < count) {
+      if (tid == 0) s_cut[0] = lo_pos;
+      __syncthreads();
+      const int st = s_ts.start[tid];  // bucket tid begins here: a legal cut if inside (lo_pos, lo_pos + 256]
+      if (st > lo_pos && st <= lo_pos + kStage) atomicMax(&s_cut[0], st);
+      __syncthreads();
+      const int cut = s_cut[0];
+      if (cut > lo_pos)
+        hi_pos = cut;
+      else
+        monotone = false;  // one bucket holds more than 256 points: it is cut in two, in arrival order
+      __syncthreads();
+    }
+    // ---- stage it: tile cull, ordered compaction ----
+    const int i = lo_pos + tid;
+    bool keep = false;
+    float px = 0.f, py = 0.f, pz = 0.f, r = 0.f;
+    int pid = -1;
+    if (i < hi_pos) {
+      pid = !BINNED ? (int)(src_base + i) : (sorted_list ? s_ts.sorted[i] : a.csr.list[src_base + i]);
+      const float* g = a.points + (int64_t)pid * 3;
+      px = g[0];
+      py = g[1];
+      pz = g[2];
+      r = a.radius[pid];
+      const bool off_tile = tile_x0 > px + r || tile_x1 < px - r || tile_y0 > py + r || tile_y1 < py - r;
+      keep = !(pz < 0.0f) && !off_tile;
+    }
+    const unsigned long long km = __ballot(keep);
+    if (lane == 0) s_wcnt[w] = __popcll(km);
+    __syncthreads();
+    int pos = mask_rank(km);
+    int staged = 0;
+#pragma unroll
+    for (int j = 0; j < kStage / kWave; ++j) {
+      const int c = s_wcnt[j];
+      if (j < w) pos += c;
+      staged += c;
+    }
+    unsigned long long key = 0;
+    int bk = 0;
+    if (keep) {
+      const unsigned zb = __float_as_uint(pz + 0.0f);  // +0.0: a zero depth's key orders by its bits
+      key = ((unsigned long long)zb << 32) | (unsigned)pid;
+      bk = sorted_list ? tile_bucket_of(zb, zlo, scale) : 0;
+      s_pt[pos] = make_float4(px, py, pz + 0.0f, r);
+      s_key[pos] = key;
+      s_bk[pos] = bk;
+    }
+    __syncthreads();
+    // ---- exact order inside the chunk: move by the same-bucket inversions around the entry ----
+    if (keep) {
+      int fin = pos;
+      const int reach = window < staged ? window : staged;
+      for (int t = 1; t < reach; ++t) {  // (a bucket's entries are adjacent; its population bounds the distance)
+        const int jb = pos - t, ja = pos + t;
+        if (jb >= 0 && s_bk[jb] == bk && s_key[jb] > key) --fin;
+        if (ja < staged && s_bk[ja] == bk && s_key[ja] < key) ++fin;
+      }
+      s_ord[fin] = pos;
+    }
+    __syncthreads();
+    // ---- visit: front to back ----
+    if (wave_ok) {
+      for (int jb = 0; jb < staged; jb += kWave) {
+        const int j = jb + lane;
+        int oj = 0;
+        unsigned long long ck = ~0ull;
+        bool touch = false;
+        if (j < staged) {
+          oj = s_ord[j];
+          ck = s_key[oj];
+          const float4 b = s_pt[oj];
+          touch = !(sub_x0 > b.x + b.w || sub_x1 < b.x - b.w || sub_y0 > b.y + b.w || sub_y1 < b.y - b.w);
+        }
+        if (monotone) {
+          // the block's first key is its smallest, and everything later in the tile sorts after it
+          const unsigned long long k0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ck >> 32)) << 32) |
+                                        (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ck);
+          if (__ballot(pix_ok && k0 < kth) == 0) break;  // uniform
+        }
+        unsigned long long cand = __ballot(touch);
+        while (cand) {  // uniform
+          const int cl = __builtin_ctzll(cand);
+          cand &= cand - 1;
+          const int jj = __builtin_amdgcn_readlane(oj, cl);
+          const unsigned long long ckey = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(ck >> 32), cl) << 32) |
+                                          (unsigned)__builtin_amdgcn_readlane((int)(unsigned)ck, cl);
+          const bool live = pix_ok && ckey < kth;
+          if (__ballot(live) == 0) {
+            if (monotone) break;  // keys ascend: so do the misses
+            continue;
+          }
+          const float4 pt = s_pt[jj];
+          const float dx = xf - pt.x;
+          const float dy = yf - pt.y;
+          const float dist2 = dx * dx + dy * dy;
+          if (live && dist2 < pt.w * pt.w) {
+            if (monotone) {  // uniform
+              queue[cnt * kWave + lane] = ckey;
+              ++cnt;
+              if (cnt == K) kth = ckey;
+            } else {
+              int at = cnt < K ? cnt : K - 1;
+              while (at > 0) {
+                const unsigned long long prev = queue[(at - 1) * kWave + lane];
+                if (!(prev > ckey)) break;
+                queue[at * kWave + lane] = prev;
+                --at;
+              }
+              queue[at * kWave + lane] = ckey;
+              if (cnt < K) ++cnt;
+              if (cnt == K) kth = queue[(K - 1) * kWave + lane];
+            }
+          }
+        }
+      }
+    }
+    lo_pos = hi_pos;
+    // done when every pixel of the tile is: in a monotone stream a full queue takes nothing more
+    const bool wave_done = !wave_ok || __ballot(pix_ok && kth == ~0ull) == 0;
+    if (__syncthreads_and((monotone && wave_done) ? 1 : 0)) break;  // uniform (also the barrier before the next staging)
+  }
+
+  if (pix_ok) {
+    const int64_t base = (((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi)) * K;
+    auto entry = [&](int k, int* id, float* z, float* d2) {
+      *id = -1;
+      *z = -1.0f;
+      *d2 = -1.0f;
+      if (k < cnt) {
+        const unsigned long long ekey = queue[k * kWave + lane];
+        *id = (int)(unsigned)ekey;
+        *z = __uint_as_float((unsigned)(ekey >> 32));
+        const float* g = a.points + (int64_t)*id * 3;
+        const float dx = xf - g[0];
+        const float dy = yf - g[1];
+        *d2 = dx * dx + dy * dy;
+      }
+    };
+    if ((K & 1) == 0) {
+      for (int k = 0; k < K; k += 2) {
+        int id[2];
+        float z[2], d2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) entry(k + j, &id[j], &z[j], &d2[j]);
+        *reinterpret_cast<int2*>(a.idxs + base + k) = make_int2(id[0], id[1]);
+        *reinterpret_cast<float2*>(a.zbuf + base + k) = make_float2(z[0], z[1]);
+        *reinterpret_cast<float2*>(a.dists + base + k) = make_float2(d2[0], d2[1]);
+      }
+    } else {
+      for (int k = 0; k < K; ++k) {
+        int id;
+        float z, d2;
+        entry(k, &id, &z, &d2);
+        a.idxs[base + k] = id;
+        a.zbuf[base + k] = z;
+        a.dists[base + k] = d2;
+      }
+    }
+  }
+}
+
+// Which kernel (1M points, 512^2, r = 0.01, points_fine ms; profiles/r05/c5, c16): register queues + a whole-tile depth pre-sort (the
+// form of mid-round 5, superseded by the tile-sorted kernel: K = 10 0.112 -> 0.108, K = 16 0.259 -> 0.229) / sorted kernel
 //   K = 1 0.045 / 0.136, 4 0.067 / 0.156, 8 0.098 / 0.186, 10 0.112 / 0.208, 12 0.186 / 0.213, 16 0.259 / 0.291, 24 0.656 / 0.361,
 //   32 0.603 / 0.481 -- and beyond 32 (round-4 register / private-memory queues) 50 1.57 / 0.73, 64 2.01 / 0.97, 100 3.0 / 1.35,
-//   150 15.4 / 2.63.  (Round 4 without the pre-sort: K = 1 0.079, 8 0.152, 10 0.180, 16 0.334.)
+//   150 15.4 / 2.63.  (Round 4, no pre-sort: K = 1 0.079, 8 0.152, 10 0.180, 16 0.334.)  The register queues below now serve the
+// NAIVE launch only (K <= 16; one list per image: test sizes, and the stand-by of short workspaces).
 constexpr int kQueueMaxK = 16;
 
 #define P3D_COMMA ,
@@ -695,9 +927,30 @@ int launch_point_raster_queues(const PointArgs& a, hipStream_t stream) {
   return launch_status();
 }
 
+// Binned launches with K <= 28 run the tile-sorted kernel, above that the single-wave sorted kernel: the tile-sorted kernel's four
+// queues cost K x 2 KB of LDS per workgroup, and one image needs four workgroups per CU to run as one round (1M points, 512^2,
+// points_fine ms, tile-sorted / sorted, profiles/r05/c20/): K = 16 0.227 / 0.291, 20 0.257 / 0.337, 24 0.301 / 0.367, 28 0.352 / 0.452,
+// 32 0.604 / 0.485, 48 0.82 / 0.64, 64 1.00 / 0.97.  The naive launch (one list per image, far beyond the pre-sort's LDS copy)
+// keeps the register queues up to K = 16.
+constexpr int kTileSortedMaxK = 28;
+
 template <bool BINNED>
 int launch_point_raster(const PointArgs& a, hipStream_t stream) {
-  if (a.K <= kQueueMaxK) return launch_point_raster_queues<BINNED>(a, stream);
+  if constexpr (BINNED) {
+    if (a.K <= kTileSortedMaxK) {
+      LaunchScope ls("points_fine", stream);
+      const size_t dyn = (size_t)(kStage / kWave) * a.K * kWave * sizeof(unsigned long long);
+      if (dyn > 48 * 1024 &&
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&point_tile_sorted_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)dyn) != hipSuccess)
+        return P3D_ERR_LAUNCH;
+      point_tile_sorted_kernel<true><<<tile_grid(a.tm), kStage, dyn, stream>>>(a);
+      return launch_status();
+    }
+  }
+  if constexpr (!BINNED) {
+    if (a.K <= kQueueMaxK) return launch_point_raster_queues<false>(a, stream);
+  }
   const size_t grid = (size_t)tile_grid(a.tm) * 4;  // one single-wave workgroup per 8x8 sub-tile
   if (grid > 0x7fffffffull) return P3D_ERR_INVALID_ARG;
   const size_t dyn = (size_t)a.K * kWave * sizeof(unsigned long long);
