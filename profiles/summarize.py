@@ -19,7 +19,7 @@ import sys
 OURS = {"mesh_raster_kernel": "mesh_fine", "area_list_kernel": "mesh_backward_areas", "mesh_backward": "mesh_backward", "points_raster": "points_fine",
         "bin_count": "bin_count", "bin_fill": "bin_fill", "bin_scan_offsets": "bin_scan_offsets",
         "bin_scan_rows": "bin_scan_rows", "bin_scan_small": "bin_scan_small", "bin_plan": "bin_plan", "gather_faces": "gather_face_verts",
-        "scatter_face": "scatter_face_grads", "point_raster_kernel": "points_fine (register queues + tile pre-sort)",
+        "scatter_face": "scatter_face_grads", "point_raster_kernel": "points_fine (register queues, naive launch)", "point_tile_sorted": "points_fine (tile-sorted kernel, LDS queues)",
         "point_sorted_kernel": "points_fine (sorted kernel, LDS queues)", "point_backward": "points_backward",
         "composite_fwd": "composite_fwd", "composite_bwd": "composite_bwd", "transform_verts": "transform_verts",
         "interp_fwd": "interp_fwd", "interp_bwd": "interp_bwd", "softmax_blend": "softmax_blend", "phong": "phong", "soft_phong": "soft_phong"}

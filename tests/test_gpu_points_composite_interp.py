@@ -42,7 +42,7 @@ def test_points_naive_and_binned_vs_oracle(size, K):
         assert all(torch.equal(a, b) for a, b in zip(ours, r))
 
 
-@pytest.mark.parametrize("K", [1, 2, 4, 5, 8, 10, 12, 16, 24, 32, 33, 40, 50, 64, 65, 80, 99, 100, 101, 150])
+@pytest.mark.parametrize("K", [1, 2, 4, 5, 8, 10, 12, 16, 17, 24, 25, 28, 29, 32, 33, 40, 50, 64, 65, 80, 99, 100, 101, 150])
 def test_points_queues_overflow_vs_oracle(K):
     """A cloud dense enough that EVERY queue overflows (~200 splats over each pixel; the sparse cloud above never fills a
     queue beyond 8 entries): all capacities of the launcher, the pair queue of 100 entries with 65..99 live ones
@@ -66,7 +66,7 @@ def test_points_queues_overflow_vs_oracle(K):
         assert torch.equal(ours[1], ref[1]) and torch.equal(ours[2], ref[2])
 
 
-@pytest.mark.parametrize("K", [1, 5, 10, 16, 60, 150])
+@pytest.mark.parametrize("K", [1, 5, 10, 16, 28, 60, 150])
 @pytest.mark.parametrize("depths", ["uniform", "quantised", "one_depth", "uniform_5200"])
 def test_points_lists_longer_than_one_sort_round(K, depths):
     """raster_points.hip: point_sorted_kernel sorts at most 768 candidates of a sub-tile per round (round 5).  One cloud of 3300
@@ -78,8 +78,8 @@ def test_points_lists_longer_than_one_sort_round(K, depths):
 
     d = _dev()
     gen = torch.Generator().manual_seed(7000 + K)
-    # 3300 points in the first cloud: every tile's list fits the pre-sort's LDS copy (4096); 5100: it does not -- the register-queue
-    # kernels then walk the list in list order as in round 4, the sorted kernel takes seven rounds
+    # 3300 points in the first cloud: every tile's list fits the tile-sorted kernel's LDS copy (2048 entries); 5100: it does not --
+    # that kernel then inserts the hits of the unsorted tail, the single-wave sorted kernel (K > 28) takes seven rounds
     P = 5200 if depths == "uniform_5200" else 3400
     pts = _cloud(P, gen, zlo=0.1, zhi=2.0)
     if depths == "quantised":

@@ -294,8 +294,7 @@ def test_points_and_compositors_vs_reference_device_code():
 
 @pytest.mark.parametrize("K", [10, 24])
 def test_config4_at_full_size_vs_reference_device_code(K):
-    """K = 10: the register queues behind the tile pre-sort; K = 24 (round 5): the sorted kernel with its queues in LDS, at the same
-    size.  BASELINE configs[3] exactly as `bench.py` times it (other_configs: 1M points xy ~ U(-1,1), z ~ U(0.5,2.5), seed 0,
+    """K = 10 and K = 24 (round 5): `point_tile_sorted_kernel`, queues in LDS (K = 24: 48 KB per workgroup), at the same size.  BASELINE configs[3] exactly as `bench.py` times it (other_configs: 1M points xy ~ U(-1,1), z ~ U(0.5,2.5), seed 0,
     radius 0.01, 512^2, K = 10, bin_size 32, features (3, P)): rasterizer + alpha compositor, forward and
     backward, against the reference's device kernels (rasterize_points.cu:87-217, 366-462; alpha_composite.cu:24-233; the
     reference takes ~96 ms for it on this GPU).  zbuf bit-equal; idx differences only at exact depth ties; dists bit-equal where
