@@ -102,6 +102,60 @@ struct WaveTable {
 
   // out[f * NV + j] += vals[slot][j] for every occupied slot; empties the table.
   __device__ __forceinline__ void flush(float* __restrict__ out, int lane) {
+#ifndef P3D_FLUSH_LANE_PER_ROW
+    // The NV values of an entry leave from ADJACENT lanes (lane = entry * NV + value).  Global float atomics are served per
+    // REQUEST, not per lane (profiles/microbench/global_atomic_mi355x.txt: a lane per row 20 G lane-atomics/s whatever NV; the
+    // values of a row in adjacent lanes 56 / 84 / 126 G for NV = 3 / 4 / 9), and until round 5 instruction j carried value j of
+    // 64 different rows.  Occupied slots are compacted first (a permutation through ds_permute), so a sparse table issues
+    // ceil(used * NV / 64) atomic instructions.  No memory read sits between the atomics (kCorners: the vertex ids are loaded
+    // by the slots' own lanes up front): a wait for a load would also wait for the atomics before it.
+    constexpr int G = 64 / NV;
+    constexpr int NC = LAYOUT == kCorners ? NV / 3 : 1;
+    const int sub = lane / NV, j = lane - sub * NV;
+    for (int s0 = 0; s0 < SLOTS; s0 += 64) {
+      const int s = s0 + lane;
+      const int f = s < SLOTS ? keys[s] : kEmptyKey;
+      const bool occ = f != kEmptyKey;
+      const unsigned long long m = __ballot(occ);
+      if (m == 0) continue;  // uniform
+      const int n = __popcll(m);
+      int vid[NC];
+      if constexpr (LAYOUT == kCorners) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          int64_t v = occ ? index[(int64_t)f * NC + c] : -1;
+          if (index_limit >= 0) {
+            if (v < 0) v += index_limit;
+            if (v < 0 || v >= index_limit) v = -1;
+          }
+          vid[c] = (int)v;
+        }
+      }
+      // lane r of `holder` = the lane whose slot is the r-th occupied one (the others fill the tail: a full permutation)
+      const int dst = occ ? mask_rank(m) : n + mask_rank(~m);
+      const int holder = __builtin_amdgcn_ds_permute(dst << 2, lane);
+      for (int e0 = 0; e0 < n; e0 += G) {
+        const int r = e0 + sub;
+        const int sl = __builtin_amdgcn_ds_bpermute((r & 63) << 2, holder);
+        float* o = nullptr;
+        if constexpr (LAYOUT == kCorners) {
+          int v = __builtin_amdgcn_ds_bpermute(sl << 2, vid[0]);
+#pragma unroll
+          for (int c = 1; c < NC; ++c) {
+            const int t = __builtin_amdgcn_ds_bpermute(sl << 2, vid[c]);
+            v = j / 3 == c ? t : v;
+          }
+          if (v >= 0 || index_limit < 0) o = out + (int64_t)v * 3 + j % 3;
+        } else {
+          o = dest(out, __builtin_amdgcn_ds_bpermute(sl << 2, f), j);
+        }
+        if (sub < G && r < n && o) unsafeAtomicAdd(o, vals[(s0 + sl) * kStride + j]);
+      }
+      if (occ) keys[s] = kEmptyKey;
+    }
+    used = 0;
+    return;
+#endif
     for (int s = lane; s < SLOTS; s += 64) {
       const int f = keys[s];
       if (f != kEmptyKey) {
