@@ -148,9 +148,14 @@ int p3d_rasterize_meshes_with_cover(const float* face_verts, const int64_t* mesh
  * (rasterize_meshes_cpu.cpp:263-288, rasterize_meshes.py); its CUDA kernels keep an unsorted array and replace "the" farthest entry
  * only by a strictly nearer candidate (RasterizeMeshesFineCudaKernel / CheckPixelInsideFace, rasterize_meshes.cu:112-237): the
  * same depths, but among faces of exactly the K-th depth possibly other survivors, depending on array positions, i.e. on the
- * pixel's whole history (2 in 10^4 entries of the bench launch; zbuf is bit-equal either way).  The replay re-runs that
- * procedure, faces in ascending index, for every pixel whose K slots are full.  A validation mode for users who diff against CUDA
- * renders: every pixel of a full tile evaluates the tile's whole list (~10 x the time of p3d_rasterize_meshes). */
+ * pixel's whole history (2 in 10^4 entries of the bench launch; zbuf is bit-equal either way).  The fine kernel marks the
+ * pixels in which the two procedures can differ (an entry dropped at the depth of the last survivor while a nearer survivor has
+ * a larger face index; or the clipped-face neighbour rule in play: 2 in 10^3 pixels of the bench launch) and the replay re-runs
+ * the reference's procedure, faces in ascending index, for those: 1.2 x the time of p3d_rasterize_meshes on the bench batch
+ * (round 4: ~10 x).  The marks take the LAST N * ceil(H/8) * ceil(W/8) * 8 bytes (rounded up to 256) of the workspace when it
+ * is at least that much larger than the binning needs (p3d_rasterize_meshes_workspace_bytes counts them in; a caller of the
+ * short-workspace size adds them); without that room the replay finds the marks in the output itself (one pix_to_face entry of
+ * every pixel is read). */
 int p3d_rasterize_meshes_cuda_order(const float* face_verts, const int64_t* mesh_to_face_first_idx,
                                     const int64_t* num_faces_per_mesh, const int64_t* clipped_faces_neighbor_idx, int64_t F,
                                     int N, int H, int W, float blur_radius, int faces_per_pixel, int bin_size,

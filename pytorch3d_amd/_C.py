@@ -165,12 +165,13 @@ class _Need:
             self.capacity = int(capacity)
 
 
-def _mesh_workspace(lib, F, N, H, W, bin_size, M, dev, what="meshes"):
-    """(workspace, _Need or None, byte offset of the call's needed-entries word); what: "meshes" (F faces) or "points"."""
+def _mesh_workspace(lib, F, N, H, W, bin_size, M, dev, what="meshes", extra=0):
+    """(workspace, _Need or None, byte offset of the call's needed-entries word); what: "meshes" (F faces) or "points";
+    extra: bytes the entry point takes off the END of the workspace (the marks of the CUDA tie order)."""
     worst_fn = getattr(lib, f"p3d_rasterize_{what}_workspace_bytes")
     short_fn = getattr(lib, f"p3d_rasterize_{what}_short_workspace_bytes")
     at_fn = getattr(lib, f"p3d_rasterize_{what}_workspace_need_offset")
-    worst = worst_fn(F, N, H, W, bin_size, M)
+    worst = worst_fn(F, N, H, W, bin_size, M) + extra
     if SHORT_WORKSPACE == "never" or (SHORT_WORKSPACE != "always" and worst <= SHORT_WORKSPACE_ABOVE):
         WORKSPACE_STATS["last_bytes"], WORKSPACE_STATS["last_entries"] = worst, None
         return _workspace(worst, dev), None, 0
@@ -186,7 +187,7 @@ def _mesh_workspace(lib, F, N, H, W, bin_size, M, dev, what="meshes"):
         entries = need.entries + need.entries // 4 + 4096
     else:
         entries = SHORT_WORKSPACE_FIRST_GUESS if SHORT_WORKSPACE_FIRST_GUESS is not None else 32 * F + (1 << 18)
-    nbytes = min(short_fn(F, N, H, W, bin_size, M, int(entries)), worst)
+    nbytes = min(short_fn(F, N, H, W, bin_size, M, int(entries)) + extra, worst)
     WORKSPACE_STATS["short_calls"] += 1
     WORKSPACE_STATS["last_bytes"], WORKSPACE_STATS["last_entries"] = nbytes, int(entries)
     return _workspace(nbytes, dev), need, at_fn(F, N, H, W, bin_size, M)
@@ -197,8 +198,8 @@ def _mesh_workspace(lib, F, N, H, W, bin_size, M, dev, what="meshes"):
 # ----------------------------------------------------------------------------------------------
 # CUDA tie order (include/p3d_amd.h: p3d_rasterize_meshes_cuda_order).  False: the K nearest faces of a pixel under the total
 # order (depth, face index), as the reference's CPU and Python implementations return them.  True: where faces tie EXACTLY in
-# depth at the K-th place, the survivors the reference's CUDA kernels keep (bit-identical pix_to_face to a CUDA render; ~10 x
-# the forward's time -- a validation mode).  rasterize_points obeys it too (there the reference's CUDA kernels also ORDER tied
+# depth at the K-th place, the survivors the reference's CUDA kernels keep (bit-identical pix_to_face to a CUDA render; the fine
+# kernel marks the pixels concerned and a replay kernel rewrites those: profiles/tie_order_timing.py).  rasterize_points obeys it too (there the reference's CUDA kernels also ORDER tied
 # entries by array position: rasterize_points.cu:26-28).  Also: P3D_CUDA_TIE_ORDER=1 in the environment.
 CUDA_TIE_ORDER = os.environ.get("P3D_CUDA_TIE_ORDER", "0") not in ("", "0")
 
@@ -314,7 +315,10 @@ def _rasterize_meshes_covered(face_verts, mesh_to_face_first_idx, num_faces_per_
         out = _mesh_outputs(N, H, W, K, dev)
         if out[0].numel() == 0:
             return out, None
-        ws, need, need_at = _mesh_workspace(lib, F, N, H, W, bin_size, M, dev) if binned else (_workspace(0, dev), None, 0)
+        # (the naive launch needs no workspace; with the CUDA tie order it takes one for the lane masks of the marked pixels --
+        # without it the replay finds its pixels by reading a pix_to_face entry of every pixel)
+        marks = N * ((H + 7) // 8) * ((W + 7) // 8) * 8 + 1024 if CUDA_TIE_ORDER else 0
+        ws, need, need_at = _mesh_workspace(lib, F, N, H, W, bin_size, M, dev, extra=marks) if binned else (_workspace(marks, dev), None, 0)
         cover = torch.empty((N, (H + 15) // 16, (W + 15) // 16), dtype=torch.int32, device=dev) if want_cover else None
         entry = lib.p3d_rasterize_meshes_cuda_order if CUDA_TIE_ORDER else lib.p3d_rasterize_meshes_with_cover
         rc = entry(

@@ -298,17 +298,27 @@ __global__ __launch_bounds__(256) void bin_scan_rows_kernel(int* __restrict__ co
   const int c0 = chunk_start[n];
   const int nch = chunk_start[n + 1] - c0;
   int carry = 0;
-  for (int base = 0; base < nch; base += kWave) {
-    const int i = base + lane;
-    int* p = counts + ((int64_t)(c0 + i)) * nbins + b;
-    const int v = i < nch ? *p : 0;
-    int x = v;
-    for (int d = 1; d < kWave; d <<= 1) {
-      const int y = __shfl_up(x, d);
-      if (lane >= d) x += y;
+  // four groups of 64 chunks per step: their loads are in flight together (a step per group waited out one memory round trip
+  // per 64 chunks, 16 in a row for a cloud of 1M points)
+  constexpr int U = 4;
+  for (int base = 0; base < nch; base += U * kWave) {
+    int v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * kWave + lane;
+      v[u] = i < nch ? counts[((int64_t)(c0 + i)) * nbins + b] : 0;
     }
-    if (i < nch) *p = carry + x - v;
-    carry += __shfl(x, kWave - 1);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * kWave + lane;
+      int x = v[u];
+      for (int d = 1; d < kWave; d <<= 1) {
+        const int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+      }
+      if (i < nch) counts[((int64_t)(c0 + i)) * nbins + b] = carry + x - v[u];
+      carry += __shfl(x, kWave - 1);
+    }
   }
   if (lane == 0) total[row] = carry < M ? carry : M;
 }
@@ -459,10 +469,16 @@ __global__ __launch_bounds__(1024) void bin_scan_offsets_kernel(const int* __res
     const int cls = v > 0 ? plan_class(v) : -1;
     if (cls >= 0) atomicAdd(&hist[cls], 1);
     __syncthreads();
+    // a single block (<= 1024 rows: one image of points) is its own class histogram: no block-sums launch before this one
+    const bool single = gridDim.x == 1;
+    int before = 0, mine = 0;
     if (tid < kPlanClasses) {
-      int before = 0;
-      for (int c = 0; c < tid; ++c) before += plan_hdr[kPlanHdr + c];  // (final: written by the kernel before this one)
-      start[tid] = before + (hist[tid] > 0 ? atomicAdd(&plan_hdr[kPlanHdr + kPlanClasses + tid], hist[tid]) : 0);
+      mine = hist[tid];
+      for (int c = 0; c < tid; ++c) before += single ? hist[c] : plan_hdr[kPlanHdr + c];  // (final: written by the kernel before this one)
+    }
+    __syncthreads();
+    if (tid < kPlanClasses) {
+      start[tid] = before + ((!single && mine > 0) ? atomicAdd(&plan_hdr[kPlanHdr + kPlanClasses + tid], mine) : 0);
       hist[tid] = 0;
     }
     __syncthreads();
@@ -725,7 +741,7 @@ int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t*
                                                                              ws.total);
     }
     LaunchScope ls("bin_scan_offsets", stream);
-    if (!thread_rows) bin_block_sums_kernel<<<nb, 1024, 0, stream>>>(ws.total, rows, ws.blocksum, ws.plan_hdr);
+    if (!thread_rows && nb > 1) bin_block_sums_kernel<<<nb, 1024, 0, stream>>>(ws.total, rows, ws.blocksum, ws.plan_hdr);
     bin_scan_offsets_kernel<<<nb, 1024, 0, stream>>>(ws.total, rows, ws.blocksum, ws.offset, ws.arank, ws.bg_list, ws.plan_hdr,
                                                      ws.order, ws.capacity);
   }
@@ -750,7 +766,7 @@ int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t*
 int exclusive_scan_i32(const int* in, int64_t n, long long* blocksum, int64_t* out, hipStream_t stream) {
   if (n <= 0) return P3D_OK;
   const unsigned nb = (unsigned)ceil_div(n, 1024);
-  bin_block_sums_kernel<<<nb, 1024, 0, stream>>>(in, n, blocksum, nullptr);
+  if (nb > 1) bin_block_sums_kernel<<<nb, 1024, 0, stream>>>(in, n, blocksum, nullptr);  // (one block reads no block sums)
   bin_scan_offsets_kernel<<<nb, 1024, 0, stream>>>(in, n, blocksum, out, nullptr, nullptr, nullptr, nullptr, 0);
   return launch_status();
 }

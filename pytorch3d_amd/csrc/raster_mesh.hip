@@ -69,6 +69,11 @@ struct MeshArgs {
   // short workspaces (binning.h): the device flag "the lists did not fit", or null.  A binned launch returns at once when
   // it is up, the naive launch that follows it returns at once when it is not: exactly one of the two writes the output.
   const int* overflow;
+  int ties;  // CUDA tie order (TIES kernels): pixels whose survivors may differ from the reference's CUDA procedure are marked for the replay
+  // ... in place (-2 in the pixel's first pix_to_face entry) and, when the workspace has room, as one 64-bit lane mask per 8 x 8
+  // sub-tile ((N, SY, SX) words, zeroed by the launcher): the replay then finds its pixels with one scalar load per wave
+  unsigned long long* tie_words;
+  int SY, SX;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -437,10 +442,23 @@ constexpr int kRecWords = 5;
 // (lane = 8 * row + column), built once per (face, sub-tile) by the face's lane in wave_chunk from the column / row masks of
 // stage_chunk: a visit reads it with two v_readlane and uses it as the execution mask as it is -- no box in LDS, no four
 // compares per visit, and a candidate that no pixel can see costs no LDS round trip at all.
-template <bool GENERAL, typename Queue, bool PC = false>
+// TIES (CUDA tie order, see mesh_cuda_order_kernel).  `tie_z` = the depth at which an entry was last dropped IN A TIE with the
+// queue's K-th entry -- a candidate at exactly that depth that is not admitted, or an insertion into a full queue that leaves
+// the K-th depth where it was (the entry pushed off the end tied with its successor) -- and `tie_drop` = the smallest face
+// index among the entries dropped at that depth.  Everything the culls discard lies strictly behind the K-th entry, and the
+// K-th depth only ever decreases, so at the end the entries dropped at the depth zK of the last survivor are known (tie_z ==
+// zK) or there are none.  Which pixels then differ from the reference's CUDA procedure (an unsorted array filled in ascending
+// face index; a newcomer replaces the first-placed largest entry iff it is STRICTLY nearer): with S = the hits nearer than zK
+// (all kept by both), T = the hits at zK, m = K - |S| places for them, the array is "full without an entry beyond zK" from
+// the moment K hits with z <= zK have arrived; members of T arriving before that moment enter, later ones are turned away, and
+// every member of S arriving after it evicts the first-placed member of T.  If all of S precedes t* = the first member of T
+// that does not fit (the smallest index the total order drops), exactly the m first members of T enter and stay: the total
+// order's choice.  Otherwise the pixel is marked: max index over S > tie_drop (mesh_raster_kernel's epilogue).  Under the
+// neighbour rule (GENERAL) every evaluated pixel is replayed (tie_z = +inf).
+template <bool GENERAL, typename Queue, bool PC = false, bool TIES = false>
 __device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue& q, unsigned long long cand, int oj, unsigned mlo,
                                                 unsigned mhi, float zcv, f2 p, bool pix_ok, bool persp, bool clip,
-                                                const float4 (*s_rec)[kRecWords]) {
+                                                const float4 (*s_rec)[kRecWords], float& tie_z, int& tie_drop) {
   while (cand) {
     const int ci = __builtin_ctzll(cand);
     cand &= cand - 1;
@@ -474,6 +492,9 @@ __device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue&
     const bool in_box = __builtin_amdgcn_inverse_ballot_w64(inside);  // the mask IS the predicate: no VALU
     const bool too_deep = zc > q.kth_z(K);
     if (pix_ok && in_box && !too_deep) {
+      const float kz0 = TIES ? q.kth_z(K) : 0.0f;
+      const int ki0 = TIES ? q.kth_i(K) : 0;
+      if constexpr (TIES && GENERAL) tie_z = INFINITY;
       // all LDS reads of this candidate are issued together (one round trip instead of dependent ones)
       // (jj differs per lane when two candidates share the pass: the record address is a per-lane product -- a 24-bit multiply,
       // v_mul_u32_u24, instead of the quarter-rate v_mul_lo_u32 the plain index compiled to)
@@ -499,7 +520,16 @@ __device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue&
         // Depth first: a sample behind the camera or one that sorts after the K-th entry of a full queue is never
         // stored, whatever its distance -- half of the evaluations at the bench workload end here for every lane
         // (profiles/r03/probe_counts.txt).  Not under the neighbour rule: a face may replace its queued other half.
-        if (GENERAL || (!(h.z < 0.0f) && q.admits(K, h.z, f))) hit = face_dist_rec(fr, p, a.blur, bp, &h);
+        const bool adm = !(h.z < 0.0f) && q.admits(K, h.z, f);
+        if constexpr (TIES && !GENERAL) {
+          // turned away at the depth of the K-th entry (whether it lies within the blur radius is not looked at); selects, not
+          // branches: control flow between the stages of the evaluation costs the kernel 60 registers
+          const bool ev = (h.z == kz0) & !adm;
+          const int d = kz0 == tie_z ? min(tie_drop, f) : f;
+          tie_drop = ev ? d : tie_drop;
+          tie_z = ev ? kz0 : tie_z;
+        }
+        if (GENERAL || adm) hit = face_dist_rec(fr, p, a.blur, bp, &h);
       }
       if (hit) {
         bool ins = true;
@@ -532,6 +562,13 @@ __device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue&
           } else {
             const float none[1] = {0.0f};  // (z, index) only: distance and barycentrics are recomputed when the pixel is written
             q.insert(K, h.z, f, none);
+          }
+          if constexpr (TIES && !GENERAL) {
+            // a full queue pushed its K-th entry off, and the new K-th entry ties with it
+            const bool ev = (kz0 < INFINITY) & (q.kth_z(K) == kz0);
+            const int d = kz0 == tie_z ? min(tie_drop, ki0) : ki0;
+            tie_drop = ev ? d : tie_drop;
+            tie_z = ev ? kz0 : tie_z;
           }
         }
       }
@@ -664,11 +701,11 @@ struct SubTile {
 // DEAL >= 0 (split mode, see the kernel): the four waves of the workgroup share ONE sub-tile and this wave (number DEAL)
 // takes positions 16*(4q + DEAL) .. +15 of the visiting order -- at most one group of 64 per chunk, dealt in blocks of
 // 16 so that every wave sees a front-to-back subsequence of about the same depth range.
-template <bool GENERAL, typename Queue, bool PC = false>
+template <bool GENERAL, typename Queue, bool PC = false, bool TIES = false>
 __device__ __forceinline__ void wave_chunk(const MeshArgs& a, int K, Queue& q, int staged, bool sorted, const SubTile& st, f2 p,
                                            bool pix_ok, int lane, bool persp, bool clip, bool prune, const unsigned* s_pm,
                                            const float4 (*s_rec)[kRecWords], const float* s_zc, const int* s_order,
-                                           const float* s_qlow, int cshift, int rshift, int deal = -1) {
+                                           const float* s_qlow, int cshift, int rshift, float& tie_z, int& tie_drop, int deal = -1) {
   for (int jb = 0; jb < staged; jb += kWave) {
     const int jfirst = deal >= 0 ? deal * 16 : jb;  // this wave's first position
     if (jfirst >= staged) break;
@@ -694,7 +731,7 @@ __device__ __forceinline__ void wave_chunk(const MeshArgs& a, int K, Queue& q, i
       zcv = s_zc[oj];
     }
     const unsigned long long cand = __ballot(touch);
-    eval_candidates<GENERAL, Queue, PC>(a, K, q, cand, oj, mlo, mhi, zcv, p, pix_ok, persp, clip, s_rec);
+    eval_candidates<GENERAL, Queue, PC, TIES>(a, K, q, cand, oj, mlo, mhi, zcv, p, pix_ok, persp, clip, s_rec, tie_z, tie_drop);
     if (deal >= 0) break;  // a chunk holds at most 256 positions: one group per wave
   }
 }
@@ -741,8 +778,9 @@ __device__ __forceinline__ void merge_absorb(Queue& q, int K, const float* slab,
 // configs[1]: 256 tiles for 256 CUs) the launch lasts as long as the longest such walk (~0.2 ms on the cow), while three
 // quarters of the CUs idle.
 template <typename Queue, int KT, bool IN_REGS, bool BINNED, bool EXACT, int WAVES = kFineWaves, bool PC = false,
-          bool SPLIT = false>
+          bool SPLIT = false, bool TIES = false>
 __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) {
+  static_assert(!(SPLIT && TIES), "the tie marks of four queues that merge are not tracked: CUDA tie order runs the plain kernels");
   __shared__ float s_merge[SPLIT ? 3 * kMergeWords * KT * kWave : 1];
   __shared__ unsigned s_pm[kStage];                 // pixel column | row masks of the staged faces (StageLds::pm)
   __shared__ float4 s_rec[kStage][kRecWords];       // see kRecWords
@@ -914,14 +952,16 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
   // tiles included -- then pays for scratch set-up: the pure fill ran 0.94 -> 1.7 ms).
   int base = 0;
   bool general = false;
+  float tie_z = -1.0f;  // TIES only (depths are >= 0)
+  int tie_drop = kEmptyIdx;
   int staged = 0;
   for (; base < count; base += kStage) {
     staged = stage_chunk<BINNED, PC>(a, lds, tile, src_base, count, base, tid, cull, clip, prune, &general);
     if (general) break;  // uniform
     chunk_bucket_order(s_zc, staged, s_order, s_qlow, s_ord, tid);
     if (run_waves)
-      wave_chunk<false, Queue, PC>(a, K, q, staged, true, st, p, pix_ok, lane, persp, clip, prune, s_pm, s_rec, s_zc, s_order, s_qlow,
-                                   SPLIT ? 0 : (sub & 1) * 8, SPLIT ? 0 : (sub >> 1) * 8, SPLIT ? w : -1);
+      wave_chunk<false, Queue, PC, TIES>(a, K, q, staged, true, st, p, pix_ok, lane, persp, clip, prune, s_pm, s_rec, s_zc, s_order,
+                                         s_qlow, SPLIT ? 0 : (sub & 1) * 8, SPLIT ? 0 : (sub >> 1) * 8, tie_z, tie_drop, SPLIT ? w : -1);
     __syncthreads();
   }
   if constexpr (SPLIT && Queue::kPayload > 0) {
@@ -940,8 +980,8 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
       if (tid < staged) s_order[tid] = tid;
       __syncthreads();
       if (run_waves && (!SPLIT || w == 0))
-        wave_chunk<true, Queue>(a, K, q, staged, false, st, p, pix_ok, lane, persp, clip, prune, s_pm, s_rec, s_zc, s_order, s_qlow,
-                                SPLIT ? 0 : (sub & 1) * 8, SPLIT ? 0 : (sub >> 1) * 8);
+        wave_chunk<true, Queue, false, TIES>(a, K, q, staged, false, st, p, pix_ok, lane, persp, clip, prune, s_pm, s_rec, s_zc, s_order,
+                                             s_qlow, SPLIT ? 0 : (sub & 1) * 8, SPLIT ? 0 : (sub >> 1) * 8, tie_z, tie_drop);
       __syncthreads();
       base += kStage;
       if (base >= count) break;
@@ -950,6 +990,18 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
     }
   }
 
+  // TIES: is the pixel a candidate for the replay (eval_candidates)?  The queue's part of the answer is taken here, while it
+  // is in registers (the writes below consume it); S's largest index is read back from the pixel's own rows after them -- by
+  // the few lanes that need it (reading the queue here as well cost 60 registers: the scheduler ran it into the row stores).
+  float tie_kz = 0.0f;
+  bool tie_cand = false, tie_gen = false;
+  if constexpr (TIES) {
+    tie_kz = q.kth_z(K);
+    tie_gen = tie_z == INFINITY;
+    // (K = 1: a one-entry array keeps the first of several equally deep faces in ascending index -- the total order's choice;
+    // only the neighbour rule can differ there)
+    tie_cand = K > 1 && tie_z == tie_kz && tie_kz < INFINITY;
+  }
   {
     if constexpr (Queue::kPayload == 0) {
       static_assert(!SPLIT, "queues without payload do not run in split mode");
@@ -974,6 +1026,29 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
       if (wave_ok) write_subtile_fill_patch<Queue, KT, IN_REGS>(a, q, true, n, sy0, sx0, y_end, x_end, lane, pix_ok, yi, xi);
       if (a.cover != nullptr && wave_ok && (!SPLIT || w == 0)) cover_mark(a, n, sy0, pix_ok && q.valid(0), H - 1 - yi, W - 1 - xi, lane);
     }
+  }
+  if constexpr (TIES) {
+    // the mark: -2 in the pixel's first pix_to_face entry, after its rows have been acknowledged (other lanes may have written
+    // them: write_subtile_fill_patch).  mesh_cuda_order_kernel rewrites every row of a marked pixel.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int l2;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l2));
+    const int yo = sy0 + (l2 >> 3), xo = sx0 + (l2 & 7);
+    const bool inside = yo < y_end && xo < x_end;
+    const int64_t tbase = (((int64_t)n * H + (H - 1 - yo)) * W + (W - 1 - xo)) * K;
+    bool tie = tie_gen && inside;
+    if (tie_cand && inside) {
+      int s_max = -1;  // S's largest face index: the survivors in front of the last survivor's depth
+      for (int k = 0; k < K; ++k) {  // (past the L1: rows other lanes may have filled)
+        const long long fi = __hip_atomic_load(a.p2f + tbase + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float fz = __int_as_float(__hip_atomic_load(reinterpret_cast<const int*>(a.zbuf + tbase + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (fi >= 0 && fz < tie_kz) s_max = max(s_max, (int)fi);
+      }
+      tie = s_max > tie_drop;
+    }
+    if (tie) a.p2f[tbase] = -2;
+    const unsigned long long tmask = __ballot(tie);
+    if (a.tie_words != nullptr && wave_ok && l2 == 0) a.tie_words[((int64_t)n * a.SY + (sy0 >> 3)) * a.SX + (sx0 >> 3)] = tmask;
   }
   if constexpr (BINNED && !SPLIT && EXACT && (KT & 3) == 0) {
     if (piggy && plan_b > 0) {
@@ -1005,36 +1080,30 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
 // "the" largest entry only by a strictly nearer candidate, and which of several equally far entries is "the" largest depends
 // on the array positions, i.e. on the whole history of the pixel (rasterize_meshes.cu:216-237; the final sort is by (z, index):
 // rasterize_meshes.cu:30-32, so only the survivors differ, never the order).  2 in 10^4 entries of the bench launch.  For users
-// who diff against CUDA renders this kernel REPLAYS the reference's procedure, faces in ascending index, for every pixel whose
-// queue came out full (a pixel with fewer than K hits has dropped nothing: both procedures return all of its hits) and
-// overwrites its rows.  Same per-(pixel, face) functions as everywhere else (p3d_geom.h: face_setup, face_hit): same bits.
-// A validation mode, not a fast path: every lane evaluates its tile's whole list (~10 x the fine kernel's time).
+// who diff against CUDA renders this kernel REPLAYS the reference's procedure, faces in ascending index, for the pixels the
+// TIES instantiations of the fine kernel marked (-2 in the pixel's first pix_to_face entry: an entry was dropped at the depth of
+// the last survivor, or the neighbour rule was in play) and rewrites their rows.  K = 1 needs none of this: a full one-entry
+// array keeps the first face in ascending index among equals, as the total order does.
+// Round 5: a WAVE per marked pixel.  Lanes are faces: 64 faces of the tile's list are set up and tested against the pixel at
+// once (p3d_geom.h: face_setup, face_hit -- the same functions as everywhere else, the same bits), the hits are then fed to the
+// reference's array one by one in list order (the array lives in LDS; finding "the" largest entry is a wave reduction), and
+// the survivors are ranked by (z, index), re-evaluated by one lane each and written.  Until round 5 every lane of a tile with
+// a full pixel walked the tile's whole list on its own: ~10 x the fine kernel's time; now `profiles/r05/c24/`.
 // ---------------------------------------------------------------------------------------------------------------------
+// One marked pixel, the whole wave on it (see above).  qz / qi: the wave's K-entry array in LDS.
 template <bool BINNED>
-__global__ __launch_bounds__(kStage) void mesh_cuda_order_kernel(MeshArgs a) {
-  if (a.overflow != nullptr && (*a.overflow != 0) == BINNED) return;  // short workspaces: as in mesh_raster_kernel
-  TileCoord tc;
-  if (!tile_of_block(a.tm, blockIdx.x, &tc)) return;
-  const int n = tc.n, H = a.H, W = a.W, K = a.K;
-  const int y_end = min(H, (tc.by + 1) * a.tm.bin_size), x_end = min(W, (tc.bx + 1) * a.tm.bin_size);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int yi = tc.by * a.tm.bin_size + tc.ty * kTile + (w >> 1) * 8 + (lane >> 3);
-  const int xi = tc.bx * a.tm.bin_size + tc.tx * kTile + (w & 1) * 8 + (lane & 7);
-  const bool pix_ok = yi < y_end && xi < x_end;
-  const int64_t opix = ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi);
-  const bool replay = pix_ok && K > 0 && a.p2f[opix * K + (K - 1)] >= 0;
-  if (__ballot(replay) == 0) return;  // uniform
+__device__ __forceinline__ void replay_pixel(const MeshArgs& a, int n, int yi, int xi, volatile float* qz, volatile int* qi, int lane) {
+  const int H = a.H, W = a.W, K = a.K;
   int64_t src;
   int count;
   if (BINNED) {
-    const int64_t row = ((int64_t)n * a.tm.BH + tc.by) * a.tm.BW + tc.bx;
+    const int64_t row = ((int64_t)n * a.tm.BH + yi / a.tm.bin_size) * a.tm.BW + xi / a.tm.bin_size;
     src = a.csr.offset[row];
     count = a.csr.total[row];
   } else {
     src = a.mesh_first[n];
     count = (int)a.mesh_count[n];
   }
-  const f2 p = mk2(pix_to_ndc(xi, W, H), pix_to_ndc(yi, H, W));
   const bool persp = a.persp != 0, clip = a.clip != 0, cull = a.cull != 0;
   auto verts = [&](int f, f3* v0, f3* v1, f3* v2) {
     const float* g = a.face_verts + (int64_t)f * 9;
@@ -1042,102 +1111,213 @@ __global__ __launch_bounds__(kStage) void mesh_cuda_order_kernel(MeshArgs a) {
     *v1 = mk3(g[3], g[4], g[5]);
     *v2 = mk3(g[6], g[7], g[8]);
   };
+  struct Batch {  // 64 faces of the list, one per lane
+    int f;
+    int nb;
+    f3 v0, v1, v2;
+  };
+  auto fetch = [&](int i0) {
+    Batch b;
+    b.f = -1;
+    b.nb = -1;
+    b.v0 = b.v1 = b.v2 = mk3(0.0f, 0.0f, 0.0f);
+    const int i = i0 + lane;
+    if (i < count) {
+      b.f = BINNED ? a.csr.list[src + i] : (int)(src + i);
+      verts(b.f, &b.v0, &b.v1, &b.v2);
+      b.nb = (int)a.neighbor[b.f];  // (face ids fit 31 bits; -1 stays -1)
+    }
+    return b;
+  };
+  const f2 p = mk2(pix_to_ndc(xi, W, H), pix_to_ndc(yi, H, W));
+  const int64_t opix = ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi);
   // the reference's array (rasterize_meshes.cu:291-294), depths and indices only: distance and barycentrics of the K
-  // survivors are recomputed at the end
-  float qz[P3D_MAX_K];
-  int qi[P3D_MAX_K];
+  // survivors are recomputed at the end.  qn, qmax_z, qmax_i are wave-uniform.
   int qn = 0, qmax_i = -1;
   float qmax_z = -1000.0f;
-  for (int i = 0; i < count; ++i) {
-    const int f = BINNED ? a.csr.list[src + i] : (int)(src + i);  // uniform
-    f3 v0, v1, v2;
-    verts(f, &v0, &v1, &v2);
-    const FaceSetup fs = face_setup(v0, v1, v2, a.sqrt_blur, cull);
-    if (fs.reject) continue;  // uniform
+  Batch nxt = fetch(0);
+  for (int i0 = 0; i0 < count; i0 += kWave) {
+    const Batch cur = nxt;
+    if (i0 + kWave < count) nxt = fetch(i0 + kWave);  // in flight while this batch's hits are fed to the array
     FaceHit h;
-    if (!replay || outside_box(fs, p) || !face_hit(v0, v1, v2, p, a.blur, persp, clip, &h)) continue;
-    const int64_t nb = a.neighbor[f];
-    int at = -1;
-    if (nb != -1) {
-      for (int j = 0; j < qn; ++j) {
-        if (qi[j] == (int)nb) {
-          at = j;
-          break;
-        }
-      }
+    bool hit = false;
+    if (cur.f >= 0) {
+      const FaceSetup fs = face_setup(cur.v0, cur.v1, cur.v2, a.sqrt_blur, cull);
+      if (!fs.reject && !outside_box(fs, p)) hit = face_hit(cur.v0, cur.v1, cur.v2, p, a.blur, persp, clip, &h);
     }
-    if (at != -1) {
-      // the clipped-face rule (rasterize_meshes.cu:186-213): the nearer of the two halves keeps the slot -- in place
-      f3 n0, n1, n2;
-      verts((int)nb, &n0, &n1, &n2);
-      FaceHit hn;
-      face_hit(n0, n1, n2, p, a.blur, persp, clip, &hn);
-      if (fabsf(h.dist) < fabsf(hn.dist)) {
-        qz[at] = h.z;
-        qi[at] = f;
-        if (h.z > qmax_z) {
-          qmax_z = h.z;
-          qmax_i = at;
+    unsigned long long hits = __ballot(hit);
+    while (hits) {  // in list order = ascending face index
+      const int c = __builtin_ctzll(hits);
+      hits &= hits - 1;
+      const int cf = __builtin_amdgcn_readlane(cur.f, c);
+      const float cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h.z), c));
+      const int cnb = __builtin_amdgcn_readlane(cur.nb, c);
+      int at = -1;
+      if (cnb != -1) {  // uniform
+        for (int j0 = 0; j0 < qn; j0 += kWave) {  // the first match in array order, as the reference's loop finds it
+          const unsigned long long is = __ballot(j0 + lane < qn && qi[j0 + lane] == cnb);
+          if (is) {
+            at = j0 + __builtin_ctzll(is);
+            break;
+          }
         }
       }
-    } else if (qn < K) {
-      qz[qn] = h.z;
-      qi[qn] = f;
-      if (h.z > qmax_z) {
-        qmax_z = h.z;
-        qmax_i = qn;
-      }
-      ++qn;
-    } else if (h.z < qmax_z) {
-      qz[qmax_i] = h.z;
-      qi[qmax_i] = f;
-      qmax_z = h.z;
-      for (int j = 0; j < K; ++j) {
-        if (qz[j] > qmax_z) {
-          qmax_z = qz[j];
-          qmax_i = j;
+      if (at != -1) {
+        // the clipped-face rule (rasterize_meshes.cu:186-213): the nearer of the two halves keeps the slot -- in place
+        f3 n0, n1, n2;
+        verts(cnb, &n0, &n1, &n2);
+        FaceHit hn;
+        face_hit(n0, n1, n2, p, a.blur, persp, clip, &hn);
+        const float cdist = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h.dist), c));
+        if (fabsf(cdist) < fabsf(hn.dist)) {  // uniform
+          if (lane == 0) {
+            qz[at] = cz;
+            qi[at] = cf;
+          }
+          if (cz > qmax_z) {
+            qmax_z = cz;
+            qmax_i = at;
+          }
+        }
+      } else if (qn < K) {
+        if (lane == 0) {
+          qz[qn] = cz;
+          qi[qn] = cf;
+        }
+        if (cz > qmax_z) {
+          qmax_z = cz;
+          qmax_i = qn;
+        }
+        ++qn;
+      } else if (cz < qmax_z) {
+        if (lane == 0) {
+          qz[qmax_i] = cz;
+          qi[qmax_i] = cf;
+        }
+        // "the" largest entry: the first one in array order that exceeds the newcomer, the newcomer's slot if none does
+        // (rasterize_meshes.cu:228-236: a scan with a strict comparison that starts from the newcomer)
+        qmax_z = cz;
+        __builtin_amdgcn_wave_barrier();
+        float m = -INFINITY;
+        for (int j = lane; j < K; j += kWave) m = fmaxf(m, qz[j]);
+        for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+        if (m > cz) {  // uniform
+          for (int j0 = 0; j0 < K; j0 += kWave) {
+            const unsigned long long is = __ballot(j0 + lane < K && qz[j0 + lane] == m);
+            if (is) {
+              qmax_i = j0 + __builtin_ctzll(is);
+              break;
+            }
+          }
+          qmax_z = m;
         }
       }
+      __builtin_amdgcn_wave_barrier();  // lane 0's LDS writes before the wave's next reads (same wave: program order)
     }
   }
-  if (!replay) return;
-  // ascending (z, index): insertion sort of the <= K entries (rasterize_meshes.cu:30-32, rasterization_utils.cuh:54-66)
-  for (int i = 1; i < qn; ++i) {
-    const float z = qz[i];
-    const int f = qi[i];
-    int j = i - 1;
-    while (j >= 0 && (qz[j] > z || (qz[j] == z && qi[j] > f))) {
-      qz[j + 1] = qz[j];
-      qi[j + 1] = qi[j];
-      --j;
-    }
-    qz[j + 1] = z;
-    qi[j + 1] = f;
-  }
-  for (int k = 0; k < K; ++k) {
-    const int64_t o = opix * K + k;
-    if (k < qn) {
-      f3 v0, v1, v2;
-      verts(qi[k], &v0, &v1, &v2);
-      FaceHit h;
-      face_hit(v0, v1, v2, p, a.blur, persp, clip, &h);
-      a.p2f[o] = qi[k];
-      a.zbuf[o] = h.z;
-      a.dists[o] = h.dist;
-      a.bary[3 * o] = h.bary.x;
-      a.bary[3 * o + 1] = h.bary.y;
-      a.bary[3 * o + 2] = h.bary.z;
-    } else {
+  // survivors in ascending (z, index) (rasterize_meshes.cu:30-32): entry j goes to place #{entries that sort before it}
+  for (int j = lane; j < K; j += kWave) {
+    const int64_t o = opix * K + j;
+    if (j >= qn) {
       a.p2f[o] = -1;
       a.zbuf[o] = a.dists[o] = a.bary[3 * o] = a.bary[3 * o + 1] = a.bary[3 * o + 2] = -1.0f;
     }
   }
+  for (int j = lane; j < qn; j += kWave) {
+    const float z = qz[j];
+    const int f = qi[j];
+    int rank = 0;
+    for (int t = 0; t < qn; ++t) {
+      const float zt = qz[t];
+      const int ft = qi[t];
+      rank += (zt < z || (zt == z && ft < f)) ? 1 : 0;
+    }
+    f3 v0, v1, v2;
+    verts(f, &v0, &v1, &v2);
+    FaceHit h;
+    face_hit(v0, v1, v2, p, a.blur, persp, clip, &h);
+    const int64_t o = opix * K + rank;
+    a.p2f[o] = f;
+    a.zbuf[o] = h.z;
+    a.dists[o] = h.dist;
+    a.bary[3 * o] = h.bary.x;
+    a.bary[3 * o + 1] = h.bary.y;
+    a.bary[3 * o + 2] = h.bary.z;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// With the lane masks of the TIES kernels (MeshArgs::tie_words): a workgroup of eight waves takes 16 of the (N, SY, SX) words --
+// scattered over the images by a multiplicative permutation: marks come in clusters (4.8 pixels per marked sub-tile at the
+// bench workload, some sub-tiles dozens, in neighbouring sub-tiles) and a pixel is one long chain of dependent round trips --
+// and its waves replay the marked pixels in turn.  Words without a mark (97 % at the bench workload) cost a sixteenth of a
+// load instruction per wave.
+constexpr int kTieWordsPerWave = 16;
+constexpr int kTieWaves = 8;
+template <bool BINNED>
+__global__ __launch_bounds__(kTieWaves * kWave) void mesh_cuda_order_words_kernel(MeshArgs a, unsigned nwords, unsigned mult) {
+  __shared__ float s_qzw[kTieWaves][P3D_MAX_K];
+  __shared__ int s_qiw[kTieWaves][P3D_MAX_K];
+  if (a.K <= 0) return;
+  if (a.overflow != nullptr && (*a.overflow != 0) == BINNED) return;  // short workspaces: as in mesh_raster_kernel
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  volatile float* s_qz = s_qzw[wv];
+  volatile int* s_qi = s_qiw[wv];
+  int turn = 0;
+  const unsigned slot = blockIdx.x * kTieWordsPerWave + lane;
+  unsigned wi = 0;
+  unsigned long long word = 0;
+  if (lane < kTieWordsPerWave && slot < nwords) {
+    wi = (unsigned)(((unsigned long long)slot * mult) % nwords);
+    word = a.tie_words[wi];
+  }
+  unsigned long long have = __ballot(word != 0);
+  while (have) {  // uniform
+    const int l = __builtin_ctzll(have);
+    have &= have - 1;
+    const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)wi, l);
+    unsigned long long todo = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(word >> 32), l) << 32) |
+                              (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)word, l);
+    const int sx = (int)(w % (unsigned)a.SX);
+    const unsigned t = w / (unsigned)a.SX;
+    const int sy = (int)(t % (unsigned)a.SY), n = (int)(t / (unsigned)a.SY);
+    while (todo) {
+      const int L = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      if (((turn++) & (kTieWaves - 1)) != wv) continue;  // uniform: another wave's pixel
+      replay_pixel<BINNED>(a, n, sy * 8 + (L >> 3), sx * 8 + (L & 7), s_qz, s_qi, lane);
+    }
+  }
+}
+
+// Without a workspace for the lane masks: every wave reads the marks of its own 8 x 8 sub-tile in place (a pix_to_face entry
+// of every pixel of the launch) and replays what they mark.
+template <bool BINNED>
+__global__ __launch_bounds__(kStage) void mesh_cuda_order_kernel(MeshArgs a) {
+  __shared__ float s_qz[kStage / kWave][P3D_MAX_K];
+  __shared__ int s_qi[kStage / kWave][P3D_MAX_K];
+  if (a.overflow != nullptr && (*a.overflow != 0) == BINNED) return;  // short workspaces: as in mesh_raster_kernel
+  TileCoord tc;
+  if (!tile_of_block(a.tm, blockIdx.x, &tc)) return;
+  const int n = tc.n, H = a.H, W = a.W, K = a.K;
+  if (K <= 0) return;
+  const int y_end = min(H, (tc.by + 1) * a.tm.bin_size), x_end = min(W, (tc.bx + 1) * a.tm.bin_size);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int sy0 = tc.by * a.tm.bin_size + tc.ty * kTile + (w >> 1) * 8, sx0 = tc.bx * a.tm.bin_size + tc.tx * kTile + (w & 1) * 8;
+  const int yi = sy0 + (lane >> 3), xi = sx0 + (lane & 7);
+  const bool pix_ok = yi < y_end && xi < x_end;
+  unsigned long long todo = __ballot(pix_ok && a.p2f[(((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi)) * K] == -2);
+  while (todo) {  // uniform (no workgroup barriers in this kernel)
+    const int L = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    replay_pixel<BINNED>(a, n, sy0 + (L >> 3), sx0 + (L & 7), s_qz[w], s_qi[w], lane);
+  }
 }
 
 // The instantiations one (Queue, K) pair can run as: split (few tiles), compile-time persp & clip, or plain.
-template <typename Q, int KT, bool REGS, bool BINNED, bool EXACT>
+template <typename Q, int KT, bool REGS, bool BINNED, bool EXACT, bool TIES>
 void launch_fine_variant(const MeshArgs& a, unsigned grid, bool split, size_t dyn_lds, hipStream_t stream) {
-  if constexpr (REGS && EXACT && BINNED) {
+  if constexpr (REGS && EXACT && BINNED && !TIES) {
     if (split) {
       // the merge slab (3 x 6 x KT x 64 floats beside the staging arrays) bounds the split kernel's occupancy: declare what
       // the LDS allows (K = 8: 66 KB -> 2 workgroups per CU, K = 4: 47 KB -> 3) instead of an unattainable 4
@@ -1148,40 +1328,40 @@ void launch_fine_variant(const MeshArgs& a, unsigned grid, bool split, size_t dy
   }
   if constexpr (REGS && EXACT) {
     if (a.persp && a.clip) {
-      mesh_raster_kernel<typename PcQueue<Q>::type, KT, REGS, BINNED, EXACT, kFineWaves, true><<<grid, kStage, dyn_lds, stream>>>(a);
+      mesh_raster_kernel<typename PcQueue<Q>::type, KT, REGS, BINNED, EXACT, kFineWaves, true, false, TIES><<<grid, kStage, dyn_lds, stream>>>(a);
       return;
     }
   }
-  mesh_raster_kernel<Q, KT, REGS, BINNED, EXACT><<<grid, kStage, dyn_lds, stream>>>(a);
+  mesh_raster_kernel<Q, KT, REGS, BINNED, EXACT, kFineWaves, false, false, TIES><<<grid, kStage, dyn_lds, stream>>>(a);
 }
 
 // Queues without payload (K <= KT live entries): the perspective + clip instantiation (64-bit key compares; depths are
 // >= +0 there: clipped barycentrics are >= +0 and faces with a vertex depth below 1e-8 never reach the queue, face_setup) when
 // both flags are set.
-template <int KT, bool BINNED, int WAVES>
+template <int KT, bool BINNED, int WAVES, bool TIES>
 void launch_long_variant(const MeshArgs& a, unsigned grid, hipStream_t stream) {
   if (a.persp && a.clip)
-    mesh_raster_kernel<TopKPairs<KT, true, 0>, KT, true, BINNED, false, WAVES, true><<<grid, kStage, 0, stream>>>(a);
+    mesh_raster_kernel<TopKPairs<KT, true, 0>, KT, true, BINNED, false, WAVES, true, false, TIES><<<grid, kStage, 0, stream>>>(a);
   else
-    mesh_raster_kernel<TopKPairs<KT, false, 0>, KT, true, BINNED, false, WAVES><<<grid, kStage, 0, stream>>>(a);
+    mesh_raster_kernel<TopKPairs<KT, false, 0>, KT, true, BINNED, false, WAVES, false, false, TIES><<<grid, kStage, 0, stream>>>(a);
 }
 
 #define P3D_COMMA ,
-template <bool BINNED>
-int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
+template <bool BINNED, bool TIES>
+int launch_mesh_raster_t(const MeshArgs& a0, hipStream_t stream) {
   MeshArgs a = a0;
   unsigned grid = tile_grid(a.tm);
   const char* name = BINNED ? "mesh_fine" : "mesh_naive";
   LaunchScope ls(name, stream);
   const int K = a.K;
   // few tiles (one image, a small batch): one workgroup per sub-tile with the candidate list dealt to its four waves
-  const bool split = BINNED && grid <= (unsigned)kSplitMaxTiles;
+  const bool split = BINNED && !TIES && grid <= (unsigned)kSplitMaxTiles;
   // tiles in the plan's order: when the lists carry a tile plan and a tile is a bin (grid = bins = active + background rows)
   a.walk_plan = BINNED && !split && a.csr.plan.hdr != nullptr && a.csr.plan.order != nullptr && a.tm.Ty == 1 && a.tm.Tx == 1;
   const size_t dyn_lds = 0;
-#define P3D_LAUNCH_FINE(KT_, REGS_, EXACT_, Q_) launch_fine_variant<Q_, KT_, REGS_, BINNED, EXACT_>(a, grid, split, dyn_lds, stream)
-#define P3D_LAUNCH_FINE_W(KT_, WAVES_, Q_) mesh_raster_kernel<Q_, KT_, true, BINNED, false, WAVES_><<<grid, kStage, 0, stream>>>(a)
-#define P3D_LAUNCH_LONG(KT_, WAVES_) launch_long_variant<KT_, BINNED, WAVES_>(a, grid, stream)
+#define P3D_LAUNCH_FINE(KT_, REGS_, EXACT_, Q_) launch_fine_variant<Q_, KT_, REGS_, BINNED, EXACT_, TIES>(a, grid, split, dyn_lds, stream)
+#define P3D_LAUNCH_FINE_W(KT_, WAVES_, Q_) mesh_raster_kernel<Q_, KT_, true, BINNED, false, WAVES_, false, false, TIES><<<grid, kStage, 0, stream>>>(a)
+#define P3D_LAUNCH_LONG(KT_, WAVES_) launch_long_variant<KT_, BINNED, WAVES_, TIES>(a, grid, stream)
   // Up to 8: queues WITH payload in registers.  K = 1, 2, 4, 8 have exact instantiations (vector-row epilogue, no
   // test on K left); 3 and 5..7 run the pair queue of the next capacity with K live entries (topk.h: TopKPairs::insert
   // skips the steps of the dead entries with scalar branches).  Until round 3 those K ran TopKReg queues of 8 / 12 entries
@@ -1227,6 +1407,11 @@ int launch_mesh_raster(const MeshArgs& a0, hipStream_t stream) {
   return launch_status();
 }
 
+template <bool BINNED>
+int launch_mesh_raster(const MeshArgs& a, hipStream_t stream) {
+  return a.ties ? launch_mesh_raster_t<BINNED, true>(a, stream) : launch_mesh_raster_t<BINNED, false>(a, stream);
+}
+
 void set_tiles(MeshArgs* a, int bin_size, int BH, int BW) { a->tm = make_tile_map(a->N, a->H, a->W, bin_size, BH, BW, true); }
 
 int check_common(int N, int H, int W, int K) {
@@ -1241,13 +1426,18 @@ int check_common(int N, int H, int W, int K) {
 
 using namespace p3d;
 
+// CUDA tie order: one 64-bit lane mask per 8 x 8 sub-tile (MeshArgs::tie_words)
+static size_t tie_marks_bytes(int N, int H, int W) {
+  return align_up((size_t)N * (size_t)((H + 7) / 8) * (size_t)((W + 7) / 8) * sizeof(unsigned long long), 256);
+}
+
 P3D_API size_t p3d_rasterize_meshes_workspace_bytes(int64_t F, int N, int H, int W, int bin_size,
                                                     int max_faces_per_bin) {
   if (bin_size <= 0 || max_faces_per_bin <= 0 || N <= 0 || H <= 0 || W <= 0) return 0;
   // enough for both the caller's geometry (_rasterize_meshes_coarse) and the internal one (rasterize_meshes)
   const size_t user = bin_workspace_bytes(F, N, make_geom(H, W, bin_size), max_faces_per_bin);
   const size_t internal = bin_workspace_bytes(F, N, make_internal_geom(H, W, bin_size), max_faces_per_bin);
-  return (user > internal ? user : internal) + 256;
+  return (user > internal ? user : internal) + 256 + tie_marks_bytes(N, H, W) + 256;  // (+ the marks of the CUDA tie order)
 }
 
 P3D_API size_t p3d_rasterize_meshes_short_workspace_bytes(int64_t F, int N, int H, int W, int bin_size, int max_faces_per_bin,
@@ -1287,10 +1477,16 @@ static int cover_begin(MeshArgs* a, int32_t* cover, hipStream_t s) {
   return (bytes == 0 || hipMemsetAsync(cover, 0, bytes, s) == hipSuccess) ? P3D_OK : P3D_ERR_LAUNCH;
 }
 
+// CUDA tie order: where the TIES kernels leave their lane masks (MeshArgs::tie_words), or words == null: marks in place only
+struct TieMarks {
+  unsigned long long* words = nullptr;
+  int SY = 0, SX = 0;
+};
+
 static int mesh_naive_impl(const float* face_verts, const int64_t* mesh_first, const int64_t* mesh_count,
                            const int64_t* neighbor, int64_t F, int N, int H, int W, float blur_radius, int K, int persp,
                            int clip, int cull, int64_t* p2f, float* zbuf, float* bary, float* dists, int32_t* cover,
-                           p3d_stream_t stream, const int* overflow = nullptr) {
+                           p3d_stream_t stream, const int* overflow = nullptr, bool ties = false, TieMarks marks = TieMarks()) {
   (void)F;
   const int rc = check_common(N, H, W, K);
   if (rc != P3D_OK) return rc;
@@ -1327,6 +1523,10 @@ static int mesh_naive_impl(const float* face_verts, const int64_t* mesh_first, c
   a.CY = (H + 15) / 16;
   a.CX = (W + 15) / 16;
   a.overflow = overflow;
+  a.ties = ties ? 1 : 0;
+  a.tie_words = marks.words;
+  a.SY = marks.SY;
+  a.SX = marks.SX;
   set_tiles(&a, H > W ? H : W, 1, 1);
   return launch_mesh_raster<false>(a, (hipStream_t)stream);
 }
@@ -1342,7 +1542,7 @@ P3D_API int p3d_rasterize_meshes_naive(const float* face_verts, const int64_t* m
 static int mesh_fine_from_csr(const float* face_verts, const int64_t* neighbor, const BinCSR& csr, int N, int H, int W,
                               const BinGeom& g, float blur_radius, int K, int persp, int clip, int cull, int64_t* p2f,
                               float* zbuf, float* bary, float* dists, hipStream_t stream, int32_t* cover = nullptr,
-                              const int* overflow = nullptr) {
+                              const int* overflow = nullptr, bool ties = false, TieMarks marks = TieMarks()) {
   MeshArgs a{};
   a.face_verts = face_verts;
   a.neighbor = neighbor;
@@ -1363,8 +1563,29 @@ static int mesh_fine_from_csr(const float* face_verts, const int64_t* neighbor, 
   const int st = cover_begin(&a, cover, stream);
   if (st != P3D_OK) return st;
   a.overflow = overflow;
+  a.ties = ties ? 1 : 0;
+  a.tie_words = marks.words;
+  a.SY = marks.SY;
+  a.SX = marks.SX;
   set_tiles(&a, g.bin_size, g.BH, g.BW);
   return launch_mesh_raster<true>(a, stream);
+}
+
+// b -> (b * multiplier) mod items is a bijection for an odd multiplier coprime to items; near items / golden ratio it spreads
+// neighbours far apart
+static unsigned scatter_multiplier(uint64_t items) {
+  if (items <= 1) return 1;
+  auto gcd = [](uint64_t x, uint64_t y) {
+    while (y) {
+      const uint64_t r = x % y;
+      x = y;
+      y = r;
+    }
+    return x;
+  };
+  uint64_t m = (uint64_t)((double)items * 0.6180339887) | 1u;
+  while (gcd(m, items) != 1) m += 2;
+  return (unsigned)(m % items);
 }
 
 // the replay of p3d_rasterize_meshes_cuda_order over the outputs of the launches before it; csr: the bin lists (null: every
@@ -1372,8 +1593,14 @@ static int mesh_fine_from_csr(const float* face_verts, const int64_t* neighbor, 
 static int cuda_order_replay(const float* face_verts, const int64_t* mesh_first, const int64_t* mesh_count,
                              const int64_t* neighbor, const BinCSR* csr, const BinGeom* g, int N, int H, int W, float blur_radius,
                              int K, int persp, int clip, int cull, int64_t* p2f, float* zbuf, float* bary, float* dists,
-                             const int* overflow, hipStream_t s) {
+                             const int* overflow, hipStream_t s, TieMarks marks) {
+  // diagnostic (profiles/tie_order_timing.py --count-marks): leave the marks in the output instead of replaying them
+  static const bool skip = getenv("P3D_TIE_SKIP_REPLAY") != nullptr;
+  if (skip) return P3D_OK;
   MeshArgs a{};
+  a.tie_words = marks.words;
+  a.SY = marks.SY;
+  a.SX = marks.SX;
   a.face_verts = face_verts;
   a.neighbor = neighbor;
   a.mesh_first = mesh_first;
@@ -1393,13 +1620,24 @@ static int cuda_order_replay(const float* face_verts, const int64_t* mesh_first,
   a.dists = dists;
   a.overflow = overflow;
   LaunchScope ls("mesh_cuda_order", s);
+  const uint64_t nwords = (uint64_t)N * (uint64_t)marks.SY * (uint64_t)marks.SX;
+  const bool words = marks.words != nullptr && nwords > 0 && nwords < 0xffffffffull;
+  const unsigned wgrid = (unsigned)ceil_div((int64_t)nwords, kTieWordsPerWave);
+  const unsigned mult = words ? scatter_multiplier(nwords) : 1u;
+  if (!words) a.tie_words = nullptr;
   if (csr != nullptr) {
     a.csr = *csr;
     set_tiles(&a, g->bin_size, g->BH, g->BW);
-    mesh_cuda_order_kernel<true><<<tile_grid(a.tm), kStage, 0, s>>>(a);
+    if (words)
+      mesh_cuda_order_words_kernel<true><<<wgrid, kTieWaves * kWave, 0, s>>>(a, (unsigned)nwords, mult);
+    else
+      mesh_cuda_order_kernel<true><<<tile_grid(a.tm), kStage, 0, s>>>(a);
   } else {
     set_tiles(&a, H > W ? H : W, 1, 1);
-    mesh_cuda_order_kernel<false><<<tile_grid(a.tm), kStage, 0, s>>>(a);
+    if (words)
+      mesh_cuda_order_words_kernel<false><<<wgrid, kTieWaves * kWave, 0, s>>>(a, (unsigned)nwords, mult);
+    else
+      mesh_cuda_order_kernel<false><<<tile_grid(a.tm), kStage, 0, s>>>(a);
   }
   return launch_status();
 }
@@ -1411,12 +1649,28 @@ static int raster_meshes_impl(const float* face_verts, const int64_t* mesh_first
                               bool cuda_order) {
   hipStream_t s = (hipStream_t)stream;
   const bool any_output = (int64_t)N * H * W * K != 0;
+  // CUDA tie order: the lane masks of the marked pixels live in the LAST bytes of the workspace when it has room for them
+  // (p3d_rasterize_meshes_workspace_bytes counts them in); the binning carves the rest as ever
+  TieMarks marks;
+  if (cuda_order && any_output && workspace != nullptr && N > 0 && H > 0 && W > 0) {
+    const size_t mb = tie_marks_bytes(N, H, W);
+    if (workspace_bytes >= mb + 256) {
+      const size_t at = (workspace_bytes - mb) & ~(size_t)255;
+      if (((uintptr_t)workspace & 7u) == 0) {
+        marks.words = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + at);
+        marks.SY = (H + 7) / 8;
+        marks.SX = (W + 7) / 8;
+        workspace_bytes = at;
+        if (hipMemsetAsync(marks.words, 0, mb, s) != hipSuccess) return P3D_ERR_LAUNCH;
+      }
+    }
+  }
   if (bin_size <= 0 || max_faces_per_bin <= 0) {
     const int st = mesh_naive_impl(face_verts, mesh_first, mesh_count, neighbor, F, N, H, W, blur_radius, K, persp, clip, cull,
-                                   p2f, zbuf, bary, dists, cover, stream);
+                                   p2f, zbuf, bary, dists, cover, stream, nullptr, cuda_order, marks);
     if (st != P3D_OK || !cuda_order || !any_output) return st;
     return cuda_order_replay(face_verts, mesh_first, mesh_count, neighbor, nullptr, nullptr, N, H, W, blur_radius, K, persp, clip,
-                             cull, p2f, zbuf, bary, dists, nullptr, s);
+                             cull, p2f, zbuf, bary, dists, nullptr, s, marks);
   }
   const int rc = check_common(N, H, W, K);
   if (rc != P3D_OK) return rc;
@@ -1444,16 +1698,16 @@ static int raster_meshes_impl(const float* face_verts, const int64_t* mesh_first
   if (st != P3D_OK) return st;
   BinCSR csr{ws.offset, ws.total, ws.list, TilePlan{ws.arank, ws.bg_list, ws.plan_hdr, ws.order}};
   st = mesh_fine_from_csr(face_verts, neighbor, csr, N, H, W, g, blur_radius, K, persp, clip, cull, p2f, zbuf, bary, dists, s,
-                          cover, overflow);
+                          cover, overflow, cuda_order, marks);
   if (st == P3D_OK && is_short)
     st = mesh_naive_impl(face_verts, mesh_first, mesh_count, neighbor, F, N, H, W, blur_radius, K, persp, clip, cull, p2f, zbuf,
-                         bary, dists, cover, stream, overflow);
+                         bary, dists, cover, stream, overflow, cuda_order, marks);
   if (st != P3D_OK || !cuda_order) return st;
   st = cuda_order_replay(face_verts, mesh_first, mesh_count, neighbor, &csr, &g, N, H, W, blur_radius, K, persp, clip, cull, p2f,
-                         zbuf, bary, dists, overflow, s);
+                         zbuf, bary, dists, overflow, s, marks);
   if (st != P3D_OK || !is_short) return st;
   return cuda_order_replay(face_verts, mesh_first, mesh_count, neighbor, nullptr, nullptr, N, H, W, blur_radius, K, persp, clip,
-                           cull, p2f, zbuf, bary, dists, overflow, s);
+                           cull, p2f, zbuf, bary, dists, overflow, s, marks);
 }
 
 P3D_API int p3d_rasterize_meshes_with_cover(const float* face_verts, const int64_t* mesh_first, const int64_t* mesh_count,

@@ -108,6 +108,7 @@ struct TopKReg {
 
   // Depth a candidate must not exceed to enter the queue: the K-th entry's z, +inf while the queue has room.
   P3D_HDM float kth_z(int /*K*/) const { return kz; }
+  P3D_HDM int kth_i(int /*K*/) const { return ki; }  // index of the K-th entry (kEmptyIdx while the queue has room)
 
   // Position of primitive `want` in the queue, or -1.
   P3D_HDM int find(int want) const {
@@ -186,6 +187,7 @@ struct TopKMem {
   }
 
   P3D_HDM float kth_z(int K) const { return n < K ? INFINITY : z[K - 1]; }
+  P3D_HDM int kth_i(int K) const { return n < K ? kEmptyIdx : idx[K - 1]; }
 
   P3D_HDM int find(int want) const {
     for (int k = 0; k < n; ++k)
@@ -309,6 +311,7 @@ struct TopKPairs {
     return (cz < kz) | ((cz == kz) & (cidx < ki));
   }
   P3D_HDM float kth_z(int /*K*/) const { return kz; }
+  P3D_HDM int kth_i(int /*K*/) const { return ki; }  // index of the K-th entry (kEmptyIdx while the queue has room)
 
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef unsigned long long LaneMask;
