@@ -1652,6 +1652,7 @@ static int raster_meshes_impl(const float* face_verts, const int64_t* mesh_first
   // CUDA tie order: the lane masks of the marked pixels live in the LAST bytes of the workspace when it has room for them
   // (p3d_rasterize_meshes_workspace_bytes counts them in); the binning carves the rest as ever
   TieMarks marks;
+  const size_t full_workspace_bytes = workspace_bytes;
   if (cuda_order && any_output && workspace != nullptr && N > 0 && H > 0 && W > 0) {
     const size_t mb = tie_marks_bytes(N, H, W);
     if (workspace_bytes >= mb + 256) {
@@ -1690,7 +1691,15 @@ static int raster_meshes_impl(const float* face_verts, const int64_t* mesh_first
   Arena arena(workspace, workspace_bytes);
   BinWorkspace ws;
   // a short workspace is welcome here (binning.h): the list takes what the caller gave, and the naive kernel stands by
-  if (!workspace || !bin_carve(arena, F, N, g, max_faces_per_bin, &ws, /*list_entries=*/1)) return P3D_ERR_WORKSPACE;
+  if (!workspace) return P3D_ERR_WORKSPACE;
+  if (!bin_carve(arena, F, N, g, max_faces_per_bin, &ws, /*list_entries=*/1)) {
+    // the marks of the CUDA tie order took the room the fixed arrays need: give it back (the replay reads the marks in place)
+    if (marks.words == nullptr) return P3D_ERR_WORKSPACE;
+    marks = TieMarks();
+    workspace_bytes = full_workspace_bytes;
+    arena = Arena(workspace, workspace_bytes);
+    if (!bin_carve(arena, F, N, g, max_faces_per_bin, &ws, /*list_entries=*/1)) return P3D_ERR_WORKSPACE;
+  }
   const bool is_short = ws.capacity < ws.worst;
   const int* overflow = is_short ? ws.plan_hdr + 2 : nullptr;
   int st = bin_build(kTriangles, face_verts, nullptr, mesh_first, mesh_count, F, N, g, max_faces_per_bin,

@@ -145,6 +145,61 @@ def test_cuda_tie_order_is_the_references_device_result_where_depths_tie_exactly
         assert differed > 0, "the soup was meant to hold boundary ties"
 
 
+@pytest.mark.parametrize("K", [2, 5, 8, 20])
+def test_cuda_tie_order_with_and_without_room_for_the_marks(K):
+    """The replay finds its pixels through the lane masks the fine kernel leaves in the LAST bytes of the workspace, or -- when the
+    caller's workspace has no room for them (include/p3d_amd.h: p3d_rasterize_meshes_cuda_order) -- through the marks in the
+    output itself (the naive launch without a workspace): same bits either way, and the same as the binned launch on a worst-case,
+    a short and an overflowing workspace, on the soup of the test above (every face three times: exact depth ties everywhere, every eighth face with a clipped neighbour)."""
+    import ctypes
+
+    from pytorch3d_amd import _C, _lib
+
+    lib = _lib.load()
+    d = _d()
+    gen = torch.Generator().manual_seed(300 + K)
+    base = U.triangle_soup(90, gen, behind_every=13)
+    order = torch.randperm(270, generator=gen)
+    fv = base.repeat(3, 1, 1)[order].contiguous().to(d)
+    F = fv.shape[0]
+    nbr = torch.full((F,), -1, dtype=torch.int64)
+    for a in range(0, F - 1, 8):
+        nbr[a], nbr[a + 1] = a + 1, a
+    nbr = nbr.to(d)
+    first, count = [t.to(d) for t in U.split_counts(F, 2)]
+    N, H, W = 2, 72, 56
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(bin_size, M, nbytes):
+        out = _C._mesh_outputs(N, H, W, K, d)
+        ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=d) if nbytes is not None else None
+        rc = lib.p3d_rasterize_meshes_cuda_order(_C._ptr(fv), _C._ptr(first), _C._ptr(count), _C._ptr(nbr), F, N, H, W, 0.004, K, bin_size,
+                                                 M, 1, 1, 0, _C._ptr(out[0]), _C._ptr(out[1]), _C._ptr(out[2]), _C._ptr(out[3]), None,
+                                                 _C._ptr(ws) if ws is not None else None, nbytes or 0, stream)
+        _lib.check(rc, "rasterize_meshes_cuda_order")
+        torch.cuda.synchronize()
+        assert int((out[0] == -2).sum()) == 0, "a mark survived the replay"
+        return out
+
+    marks = N * ((H + 7) // 8) * ((W + 7) // 8) * 8 + 1024
+    naive_without = run(0, 0, None)
+    naive_with = run(0, 0, marks)
+    worst = lib.p3d_rasterize_meshes_workspace_bytes(F, N, H, W, 16, 400)
+    short = lib.p3d_rasterize_meshes_short_workspace_bytes(F, N, H, W, 16, 400, 20 * F)
+    binned_with = run(16, 400, worst)
+    binned_short = run(16, 400, short)  # the marks come off the end of whatever the caller gave: the lists get what is left
+    binned_tiny = run(16, 400, lib.p3d_rasterize_meshes_short_workspace_bytes(F, N, H, W, 16, 400, 0))  # lists overflow: naive fallback
+    for name, got in (("naive, marks in the workspace", naive_with), ("binned, worst-case workspace", binned_with),
+                      ("binned, short workspace", binned_short), ("binned, lists overflow", binned_tiny)):
+        assert torch.equal(got[0], naive_without[0]), f"K={K} {name}: {int((got[0] != naive_without[0]).sum())} indices differ"
+        for x, y in zip(got[1:], naive_without[1:]):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32)), f"K={K} {name}"
+    mod = orc.ref_hip_module(nofma=True) if hasattr(orc, "ref_hip_module") else None
+    if mod is not None:
+        theirs = mod.rasterize_meshes(fv, first, count, nbr, (H, W), 0.004, K, 0, 0, True, True, False)
+        assert torch.equal(naive_without[0], theirs[0])
+
+
 def test_cuda_tie_order_on_bench_meshes_equals_the_references_naive_device_kernel(cuda_tie_order):
     """Two meshes of the bench batch (config 3 as written) at 512^2, K = 8: our binned launch with the CUDA tie order against the
     reference's NAIVE device kernel (every pixel walks its mesh's faces in ascending index, rasterize_meshes.cu:300-320) -- all
