@@ -158,6 +158,26 @@ P3D_HD float seg_dist2(f2 p, f2 a, f2 b) {
   return ((double)l2 <= P3D_KEPS) ? d_point : d_seg;
 }
 
+// The same distance for the backward, where it only RANKS the three edges (tri_dist2_bwd): reciprocal estimate, float
+// predicate, and mul + add fused (the forward's dists never pass through here).
+P3D_HD float seg_dist2_rank(f2 p, f2 a, f2 b) {
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
+  const float bax = b.x - a.x;
+  const float bay = b.y - a.y;
+  const float l2 = bax * bax + bay * bay;
+  float t = qdiv<true>(bax * (p.x - a.x) + bay * (p.y - a.y), l2);
+  const float ex = p.x - b.x;
+  const float ey = p.y - b.y;
+  const float d_point = ex * ex + ey * ey;
+  t = sat01(t);
+  const float dx = (a.x + t * bax) - p.x;
+  const float dy = (a.y + t * bay) - p.y;
+  const float d_seg = dx * dx + dy * dy;
+  return (l2 <= 1e-8f) ? d_point : d_seg;
+}
+
 // Squared distance to the triangle boundary (geometry_utils.cuh:397-408).
 P3D_HD float tri_dist2(f2 p, f2 v0, f2 v1, f2 v2) {
   const float e01 = seg_dist2(p, v0, v1);
@@ -577,9 +597,9 @@ P3D_HD TriGrad tri_dist2_bwd(f2 p, f2 v0, f2 v1, f2 v2, float g) {
   // The distances only choose the edge.  With the reciprocal instead of the IEEE division (10 instructions each) two
   // edges that tie to within an ulp may swap: they tie where the nearest point is their common vertex, and there both
   // give that vertex the same gradient and the other end point none (t saturates at 0 or 1).
-  const float e01 = seg_dist2<true>(p, v0, v1);
-  const float e02 = seg_dist2<true>(p, v0, v2);
-  const float e12 = seg_dist2<true>(p, v1, v2);
+  const float e01 = seg_dist2_rank(p, v0, v1);
+  const float e02 = seg_dist2_rank(p, v0, v2);
+  const float e12 = seg_dist2_rank(p, v1, v2);
   // Which edge is closest (ties: e01, then e02, then e12); 3 = none (NaN distances).  The three candidate
   // branches of the reference are folded into ONE evaluation on selected endpoints: lanes of a wave pick
   // different edges, and divergent branches would run the edge gradient three times.
