@@ -155,7 +155,8 @@ int p3d_rasterize_meshes_with_cover(const float* face_verts, const int64_t* mesh
  * (round 4: ~10 x).  The marks take the LAST N * ceil(H/8) * ceil(W/8) * 8 bytes (rounded up to 256) of the workspace when it
  * is at least that much larger than the binning needs (p3d_rasterize_meshes_workspace_bytes counts them in; a caller of the
  * short-workspace size adds them); without that room the replay finds the marks in the output itself (one pix_to_face entry of
- * every pixel is read). */
+ * every pixel is read).  Diagnostic: with P3D_TIE_SKIP_REPLAY set in the environment the replay is skipped and the marks (-2)
+ * stay in pix_to_face (profiles/tie_order_timing.py --count-marks). */
 int p3d_rasterize_meshes_cuda_order(const float* face_verts, const int64_t* mesh_to_face_first_idx,
                                     const int64_t* num_faces_per_mesh, const int64_t* clipped_faces_neighbor_idx, int64_t F,
                                     int N, int H, int W, float blur_radius, int faces_per_pixel, int bin_size,
