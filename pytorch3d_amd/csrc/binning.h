@@ -80,6 +80,9 @@ struct BinCSR {
   const int* total;       // (N*nbins) entries in each bin's list
   const int* list;        // primitive ids (packed, global), ascending per bin
   TilePlan plan;          // null pointers when the lists did not come from bin_build (user-supplied bins)
+  int stride = 1;         // ints per list entry.  2 (points, round 5): entry i = (id, depth bits) at list[2 i], list[2 i + 1] --
+                          // bin_fill writes both with one 8-byte store, and the fine kernel's depth sort reads the depths with
+                          // the ids (one coalesced round trip) instead of gathering them from the points afterwards
 };
 
 struct BinWorkspace {
@@ -93,6 +96,7 @@ struct BinWorkspace {
   int* plan_hdr;     // (4 + 2 * kPlanClasses)
   int* order;        // (N*nbins)
   int* list;         // (capacity) -- last, so that a short workspace shortens only this
+  int stride;        // ints per list entry: 1, or 2 = (id, depth bits) (bin_carve with_z: points)
   int64_t max_chunks;
   int64_t capacity;  // ids `list` holds
   int64_t worst;     // bin_capacity(): the most the lists can ever need
@@ -108,9 +112,10 @@ struct BinWorkspace {
 // flag is up, and the naive kernel, which returns at once when it is not) -- no host sync, exact either way.  offset[rows]
 // holds the total the call needed; a caller reads it back later to size its next workspace.
 int64_t bin_capacity(int64_t E, int N, const BinGeom& g, int M);
-size_t bin_workspace_bytes(int64_t E, int N, const BinGeom& g, int M, int64_t list_entries = -1);
+size_t bin_workspace_bytes(int64_t E, int N, const BinGeom& g, int M, int64_t list_entries = -1, bool with_z = false);
 // Carve `arena`; returns false when it is too small.  list_entries < 0: the worst case or nothing.
-bool bin_carve(Arena& arena, int64_t E, int N, const BinGeom& g, int M, BinWorkspace* ws, int64_t list_entries = -1);
+// with_z: list entries of two ints, (id, depth bits) (BinWorkspace::stride).
+bool bin_carve(Arena& arena, int64_t E, int N, const BinGeom& g, int M, BinWorkspace* ws, int64_t list_entries = -1, bool with_z = false);
 
 // Build the CSR lists.  elems: face_verts (E,3,3) or points (E,3); aux: radius (E) for points.
 // ordered = false (points only): ids inside a 1024-primitive chunk land in arrival order (integer LDS

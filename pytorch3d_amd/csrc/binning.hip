@@ -62,6 +62,7 @@ struct ChunkCtx {
   int64_t e;    // this thread's primitive (global packed id), -1 if none
   BinRect r;    // its rectangle
   BinRect u;    // union over the wave
+  float z;      // points: the primitive's depth (bin_fill writes it beside the id when BinWorkspace::stride == 2)
 };
 
 // Small launches (N <= kSelfPlanMax, see bin_build) skip the plan kernel: every workgroup derives the chunk table
@@ -148,6 +149,7 @@ __device__ __forceinline__ bool chunk_prologue(const float* __restrict__ elems, 
   r.x0 = r.y0 = 1 << 20;
   r.x1 = r.y1 = -1;
   c->e = -1;
+  c->z = 0.0f;
   if (local < cnt) {
     const int64_t e = first[lo] + local;
     c->e = e;
@@ -173,6 +175,7 @@ __device__ __forceinline__ bool chunk_prologue(const float* __restrict__ elems, 
       ymin = q[1] - rad;
       ymax = q[1] + rad;
       skip = q[2] < 0.0f;
+      c->z = q[2];
     }
     if (!skip) {
       // overlap(b) = (min <= hi_t[b]) && (lo_t[b] < max); both predicates are monotone in b (the tables ascend),
@@ -545,7 +548,8 @@ __global__ __launch_bounds__(kBinChunk) void bin_fill_kernel(const float* __rest
                                                              int bin_size, int BH, int BW, float sqrt_blur, int M,
                                                              const int* __restrict__ counts,
                                                              const int64_t* __restrict__ offset,
-                                                             int* __restrict__ list, const int* __restrict__ plan_hdr) {
+                                                             int* __restrict__ list, const int* __restrict__ plan_hdr,
+                                                             int stride) {
   if (plan_hdr[2] != 0) return;  // uniform: the lists do not fit `list` (a short workspace); the caller's fallback runs instead
   __shared__ float xlo_t[32], xhi_t[32], ylo_t[32], yhi_t[32];
   __shared__ int cs_l[kSelfPlanMax + 1];
@@ -580,7 +584,12 @@ __global__ __launch_bounds__(kBinChunk) void bin_fill_kernel(const float* __rest
       for (int bx = c.r.x0; bx <= c.r.x1; ++bx) {
         const int b = by * BW + bx;
         const int pos = atomicAdd(&pos_t[b], 1);
-        if (pos < M) list[dst_t[b] + pos] = (int)c.e;
+        if (pos < M) {
+          if (KIND == kPoints && stride == 2)
+            reinterpret_cast<int2*>(list)[dst_t[b] + pos] = make_int2((int)c.e, __float_as_int(c.z));  // one request, as the id alone
+          else
+            list[dst_t[b] + pos] = (int)c.e;
+        }
       }
     }
     return;
@@ -611,7 +620,12 @@ __global__ __launch_bounds__(kBinChunk) void bin_fill_kernel(const float* __rest
     for (int bx = c.r.x0; bx <= c.r.x1; ++bx) {
       const int b = by * BW + bx;
       const int pos = base_t[b] + wpre[ORDERED ? w : 0][b] + __popcll(mr & cm[bx]);
-      if (pos < M) list[dst_t[b] + pos] = (int)c.e;
+      if (pos < M) {
+        if (KIND == kPoints && stride == 2)
+          reinterpret_cast<int2*>(list)[dst_t[b] + pos] = make_int2((int)c.e, __float_as_int(c.z));
+        else
+          list[dst_t[b] + pos] = (int)c.e;
+      }
     }
   }
 }
@@ -660,7 +674,7 @@ int64_t bin_capacity(int64_t E, int N, const BinGeom& g, int M) {
   return c;
 }
 
-bool bin_carve(Arena& arena, int64_t E, int N, const BinGeom& g, int M, BinWorkspace* ws, int64_t list_entries) {
+bool bin_carve(Arena& arena, int64_t E, int N, const BinGeom& g, int M, BinWorkspace* ws, int64_t list_entries, bool with_z) {
   ws->max_chunks = ceil_div(E, kBinChunk) + N;
   ws->worst = bin_capacity(E, N, g, M);
   ws->chunk_start = arena.take<int>((size_t)N + 1);
@@ -679,19 +693,20 @@ bool bin_carve(Arena& arena, int64_t E, int N, const BinGeom& g, int M, BinWorks
   if (list_entries >= 0) {
     want = list_entries < 1 ? 1 : (list_entries < ws->worst ? list_entries : ws->worst);
     if (arena.base != nullptr && arena.cap > arena.off) {
-      const int64_t room = (int64_t)((arena.cap - arena.off) / sizeof(int));
+      const int64_t room = (int64_t)((arena.cap - arena.off) / sizeof(int)) / (with_z ? 2 : 1);
       if (room > want) want = room < ws->worst ? room : ws->worst;
     }
   }
   ws->capacity = want;
-  ws->list = arena.take<int>((size_t)want);
+  ws->stride = with_z ? 2 : 1;
+  ws->list = arena.take<int>((size_t)want * (size_t)ws->stride);
   return arena.ok();
 }
 
-size_t bin_workspace_bytes(int64_t E, int N, const BinGeom& g, int M, int64_t list_entries) {
+size_t bin_workspace_bytes(int64_t E, int N, const BinGeom& g, int M, int64_t list_entries, bool with_z) {
   Arena probe(nullptr, 0);
   BinWorkspace ws;
-  bin_carve(probe, E, N, g, M, &ws, list_entries);
+  bin_carve(probe, E, N, g, M, &ws, list_entries, with_z);
   return probe.off;
 }
 
@@ -750,15 +765,15 @@ int bin_build(BinKind kind, const float* elems, const float* aux, const int64_t*
     if (kind == kTriangles)
       bin_fill_kernel<kTriangles, true><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, cs, N, g.H, g.W,
                                                                          g.bin_size, g.BH, g.BW, sqrt_blur, M, ws.counts,
-                                                                         ws.offset, ws.list, ws.plan_hdr);
+                                                                         ws.offset, ws.list, ws.plan_hdr, ws.stride);
     else if (ordered)
       bin_fill_kernel<kPoints, true><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, cs, N, g.H, g.W,
                                                                       g.bin_size, g.BH, g.BW, sqrt_blur, M, ws.counts,
-                                                                      ws.offset, ws.list, ws.plan_hdr);
+                                                                      ws.offset, ws.list, ws.plan_hdr, ws.stride);
     else
       bin_fill_kernel<kPoints, false><<<chunks, kBinChunk, 0, stream>>>(elems, aux, first, count, cs, N, g.H, g.W,
                                                                        g.bin_size, g.BH, g.BW, sqrt_blur, M, ws.counts,
-                                                                       ws.offset, ws.list, ws.plan_hdr);
+                                                                       ws.offset, ws.list, ws.plan_hdr, ws.stride);
   }
   return launch_status();
 }

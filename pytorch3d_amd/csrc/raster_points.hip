@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kStage, WAVES) void point_raster_kernel(PointArgs a
     float px = 0.f, py = 0.f, pz = 0.f, r = 0.f;
     int pid = -1;
     if (i < count) {
-      pid = BINNED ? a.csr.list[src_base + i] : (int)(src_base + i);
+      pid = BINNED ? a.csr.list[(src_base + i) * a.csr.stride] : (int)(src_base + i);
       const float* g = a.points + (int64_t)pid * 3;
       px = g[0];
       py = g[1];
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(kWave, 2) void point_sorted_kernel(PointArgs a) {
       for (int u = 0; u < kBatch; ++u) {
         const int i = pos + u * kWave + lane;
         pid[u] = -1;
-        if (i < count) pid[u] = BINNED ? a.csr.list[src_base + i] : (int)(src_base + i);
+        if (i < count) pid[u] = BINNED ? a.csr.list[(src_base + i) * a.csr.stride] : (int)(src_base + i);
       }
 #pragma unroll
       for (int u = 0; u < kBatch; ++u) {
@@ -565,24 +565,43 @@ struct TileSortLds {
 // The bucket pass: every thread requests its <= 8 list entries and their depths at once (two memory round trips for the list), one
 // integer LDS atomic per point, a workgroup scan, a scatter: sorted[] = the list's point ids in bucket order; hist / start / range
 // stay valid for the caller.  All 256 threads; count <= kTileCap.  Ends with a barrier.
-__device__ __forceinline__ void bucket_sort_tile(const float* __restrict__ points, const int* __restrict__ list, int count,
+__device__ __forceinline__ void bucket_sort_tile(const float* __restrict__ points, const int* __restrict__ list, int stride, int count,
                                                  TileSortLds& L, int tid) {
   constexpr int kSlots = kTileCap / kStage;
   const int lane = tid & 63, w = tid >> 6;
   const unsigned kBehind = 0x7f800000u;
   int pid[kSlots];
   unsigned zb[kSlots];
+  // the depths: beside the ids when the binning left them there (BinCSR::stride == 2: ONE coalesced round trip for ids and
+  // depths), else gathered from the points once the ids are here
+  float zs[kSlots];
+  if (stride == 2) {  // uniform
 #pragma unroll
-  for (int s = 0; s < kSlots; ++s) {
-    const int i = s * kStage + tid;
-    pid[s] = i < count ? list[i] : -1;
+    for (int s = 0; s < kSlots; ++s) {
+      const int i = s * kStage + tid;
+      pid[s] = -1;
+      zs[s] = 0.0f;
+      if (i < count) {
+        const int2 e = reinterpret_cast<const int2*>(list)[i];
+        pid[s] = e.x;
+        zs[s] = __int_as_float(e.y);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+      const int i = s * kStage + tid;
+      pid[s] = i < count ? list[i] : -1;
+    }
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) zs[s] = pid[s] >= 0 ? points[(int64_t)pid[s] * 3 + 2] : 0.0f;
   }
   unsigned lo = 0xffffffffu, hi = 0u;
 #pragma unroll
   for (int s = 0; s < kSlots; ++s) {
     zb[s] = kBehind;
     if (pid[s] >= 0) {
-      const float z = points[(int64_t)pid[s] * 3 + 2];
+      const float z = zs[s];
       if (z >= 0.0f && z < INFINITY) {
         zb[s] = __float_as_uint(z + 0.0f);
         lo = zb[s] < lo ? zb[s] : lo;
@@ -704,7 +723,7 @@ __global__ __launch_bounds__(kStage, 2) void point_tile_sorted_kernel(PointArgs 
   bool monotone = sorted_list;
   float zlo = 0.0f, scale = 0.0f;
   if (sorted_list && count > 0) {
-    bucket_sort_tile(a.points, a.csr.list + src_base, count, s_ts, tid);
+    bucket_sort_tile(a.points, a.csr.list + src_base * a.csr.stride, a.csr.stride, count, s_ts, tid);
     zlo = __uint_as_float(s_ts.range[0]);
     const float span = __uint_as_float(s_ts.range[1]) - zlo;
     scale = span > 0.0f && span < INFINITY ? 255.0f / span : 0.0f;
@@ -741,7 +760,7 @@ __global__ __launch_bounds__(kStage, 2) void point_tile_sorted_kernel(PointArgs 
     float px = 0.f, py = 0.f, pz = 0.f, r = 0.f;
     int pid = -1;
     if (i < hi_pos) {
-      pid = !BINNED ? (int)(src_base + i) : (sorted_list ? s_ts.sorted[i] : a.csr.list[src_base + i]);
+      pid = !BINNED ? (int)(src_base + i) : (sorted_list ? s_ts.sorted[i] : a.csr.list[(src_base + i) * a.csr.stride]);
       const float* g = a.points + (int64_t)pid * 3;
       px = g[0];
       py = g[1];
@@ -1005,7 +1024,7 @@ __global__ __launch_bounds__(kStage) void point_cuda_order_kernel(PointArgs a) {
   int qn = 0, qmax_i = -1;
   float qmax_z = -1000.0f;
   for (int i = 0; i < count; ++i) {
-    const int pid = BINNED ? a.csr.list[src + i] : (int)(src + i);  // uniform
+    const int pid = BINNED ? a.csr.list[(src + i) * a.csr.stride] : (int)(src + i);  // uniform
     const float* g = a.points + (int64_t)pid * 3;
     const float pz = g[2];
     if (pz < 0.0f) continue;  // uniform
@@ -1177,14 +1196,14 @@ P3D_API size_t p3d_rasterize_points_workspace_bytes(int64_t P, int N, int H, int
                                                     int max_points_per_bin) {
   if (bin_size <= 0 || max_points_per_bin <= 0 || N <= 0 || H <= 0 || W <= 0) return 0;
   const size_t user = bin_workspace_bytes(P, N, make_geom(H, W, bin_size), max_points_per_bin);
-  const size_t internal = bin_workspace_bytes(P, N, make_internal_geom(H, W, bin_size), max_points_per_bin);
+  const size_t internal = bin_workspace_bytes(P, N, make_internal_geom(H, W, bin_size), max_points_per_bin, -1, /*with_z=*/true);
   return (user > internal ? user : internal) + 256;
 }
 
 P3D_API size_t p3d_rasterize_points_short_workspace_bytes(int64_t P, int N, int H, int W, int bin_size, int max_points_per_bin,
                                                           int64_t list_entries) {
   if (bin_size <= 0 || max_points_per_bin <= 0 || N <= 0 || H <= 0 || W <= 0 || list_entries < 0) return 0;
-  return bin_workspace_bytes(P, N, make_internal_geom(H, W, bin_size), max_points_per_bin, list_entries) + 256;
+  return bin_workspace_bytes(P, N, make_internal_geom(H, W, bin_size), max_points_per_bin, list_entries, /*with_z=*/true) + 256;
 }
 
 P3D_API size_t p3d_rasterize_points_workspace_need_offset(int64_t P, int N, int H, int W, int bin_size, int max_points_per_bin) {
@@ -1192,7 +1211,7 @@ P3D_API size_t p3d_rasterize_points_workspace_need_offset(int64_t P, int N, int 
   const BinGeom g = make_internal_geom(H, W, bin_size);
   Arena probe(nullptr, 0);
   BinWorkspace ws;
-  bin_carve(probe, P, N, g, max_points_per_bin, &ws, 1);
+  bin_carve(probe, P, N, g, max_points_per_bin, &ws, 1, /*with_z=*/true);
   return ws.need_at;
 }
 
@@ -1248,7 +1267,8 @@ static int raster_points_impl(const float* points, const int64_t* first, const i
   Arena arena(workspace, workspace_bytes);
   BinWorkspace ws;
   // a short workspace is welcome here (binning.h): the list takes what the caller gave, and the naive kernel stands by
-  if (!workspace || !bin_carve(arena, P, N, g, max_points_per_bin, &ws, /*list_entries=*/1)) return P3D_ERR_WORKSPACE;
+  // (with_z: bin_fill leaves every entry's depth beside its id -- the tile-sorted kernel's depth sort reads them with the list)
+  if (!workspace || !bin_carve(arena, P, N, g, max_points_per_bin, &ws, /*list_entries=*/1, /*with_z=*/true)) return P3D_ERR_WORKSPACE;
   const bool is_short = ws.capacity < ws.worst;
   const int* overflow = is_short ? ws.plan_hdr + 2 : nullptr;
   // the K nearest under (z, point index) do not depend on the order inside a bin: unordered fast binning (the replay of the
@@ -1257,7 +1277,7 @@ static int raster_points_impl(const float* points, const int64_t* first, const i
   if (st != P3D_OK) return st;
   PointArgs a{};
   fill_args(&a, points, radius, N, H, W, K, idxs, zbuf, dists);
-  a.csr = BinCSR{ws.offset, ws.total, ws.list, TilePlan{ws.arank, ws.bg_list, ws.plan_hdr, ws.order}};
+  a.csr = BinCSR{ws.offset, ws.total, ws.list, TilePlan{ws.arank, ws.bg_list, ws.plan_hdr, ws.order}, ws.stride};
   a.overflow = overflow;
   set_tiles(&a, g.bin_size, g.BH, g.BW);
   st = launch_point_raster<true>(a, s);
