@@ -84,7 +84,16 @@ def test_library_loads_and_answers_without_a_device():
     at = lib.p3d_rasterize_meshes_workspace_need_offset(*bench)
     assert 0 < at < s0 and at % 8 == 0
     assert lib.p3d_rasterize_meshes_short_workspace_bytes(10000, 4, 128, 128, 0, 0, 100) == 0
+    # round 5: the worst-case size counts the marks of the CUDA tie order in (one 64-bit lane mask per 8 x 8 sub-tile, taken off
+    # the END of the workspace); the short size does not -- a caller of it adds them (_C._mesh_workspace(extra=...))
+    marks = 64 * (512 // 8) * (512 // 8) * 8
+    assert lib.p3d_rasterize_meshes_short_workspace_bytes(*bench, 1 << 40) + marks <= worst
     assert lib.p3d_rasterize_points_workspace_bytes(10000, 2, 64, 64, 8, 100) > 0
+    # ... and a point list entry is (id, depth bits): 8 bytes
+    pts = (1_000_000, 1, 512, 512, 32, 20_000)
+    p0 = lib.p3d_rasterize_points_short_workspace_bytes(*pts, 0)
+    p1 = lib.p3d_rasterize_points_short_workspace_bytes(*pts, 2_000_000)
+    assert p1 - p0 == pytest.approx(8 * 2_000_000, abs=512) and p1 <= lib.p3d_rasterize_points_workspace_bytes(*pts)
     assert lib.p3d_rasterize_fine_workspace_bytes(2, 4, 4, 10) >= 2 * 16 * 10 * 4
     # validation that precedes any launch: K > 150, too many bins, null outputs
     null = ctypes.c_void_p(None)
