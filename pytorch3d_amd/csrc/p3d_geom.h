@@ -306,7 +306,15 @@ struct FaceRec {
   double rd_area;                // 1 / bary_area(v0, v1, v2)
   double rd_l01, rd_l02, rd_l12;  // 1 / |v1 - v0|^2 etc., < 0 when the edge is degenerate
   bool wide;                      // magnitudes beyond the ordinary: per-pixel reciprocals need the f64 seed
+  // The edge vectors the three edge functions and the three segment distances subtract out of the vertices for every pixel
+  // (round 6: six v_sub per evaluation, now once per face).  d01 = v1 - v0, d12 = v2 - v1, d20 = v0 - v2: the very differences
+  // of edge_fn(p, a, b) / edge_fn(p, b, c) / edge_fn(p, c, a); seg_dist2(p, v0, v2) wants v2 - v0 = -d20, and a negation is
+  // exact and commutes with every rounding after it: the same bits.
+  f2 d01, d12, d20;
 };
+
+// edge_fn(p, a, b) with d = b - a formed beforehand
+P3D_HD float edge_fn_d(f2 p, f2 a, f2 d) { return (p.x - a.x) * d.y - (p.y - a.y) * d.x; }
 
 P3D_HD double edge_recip(f2 a, f2 b) {
   const float bax = b.x - a.x;
@@ -325,6 +333,9 @@ P3D_HD void face_rec_make(f3 v0, f3 v1, f3 v2, FaceRec* r) {
   r->rd_l01 = edge_recip(a, b);
   r->rd_l02 = edge_recip(a, c);
   r->rd_l12 = edge_recip(b, c);
+  r->d01 = mk2(b.x - a.x, b.y - a.y);
+  r->d12 = mk2(c.x - b.x, c.y - b.y);
+  r->d20 = mk2(a.x - c.x, a.y - c.y);
   const float big = fmaxf(fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v1.x), fabsf(v1.y))),
                           fmaxf(fmaxf(fabsf(v2.x), fabsf(v2.y)), max3(fabsf(v0.z), fabsf(v1.z), fabsf(v2.z))));
   // Ordinary: |x|, |y|, z <= 1024 and |area| >= 1e-9 bound the perspective denominator by 1e22 and the clip sum by
@@ -332,10 +343,10 @@ P3D_HD void face_rec_make(f3 v0, f3 v1, f3 v2, FaceRec* r) {
   r->wide = !((big <= 1024.0f) & (fabsf(area) >= 1e-9f));
 }
 
-// seg_dist2 with the edge's reciprocal: same value as seg_dist2(p, a, b)
-P3D_HD float seg_dist2_rec(f2 p, f2 a, f2 b, double rd_l2) {
-  const float bax = b.x - a.x;
-  const float bay = b.y - a.y;
+// seg_dist2 with the edge's reciprocal and its vector ba = b - a: same value as seg_dist2(p, a, b)
+P3D_HD float seg_dist2_rec(f2 p, f2 a, f2 b, f2 ba, double rd_l2) {
+  const float bax = ba.x;
+  const float bay = ba.y;
   float t = exact_div(bax * (p.x - a.x) + bay * (p.y - a.y), rd_l2);
   const float ex = p.x - b.x;
   const float ey = p.y - b.y;
@@ -356,8 +367,8 @@ P3D_HD f3 face_depth_rec(const FaceRec& r, f2 p, bool perspective_correct, bool 
   const f2 a = mk2(r.v0.x, r.v0.y);
   const f2 b = mk2(r.v1.x, r.v1.y);
   const f2 c = mk2(r.v2.x, r.v2.y);
-  const f3 bw = mk3(exact_div(edge_fn(p, b, c), r.rd_area), exact_div(edge_fn(p, c, a), r.rd_area),
-                    exact_div(edge_fn(p, a, b), r.rd_area));
+  const f3 bw = mk3(exact_div(edge_fn_d(p, b, r.d12), r.rd_area), exact_div(edge_fn_d(p, c, r.d20), r.rd_area),
+                    exact_div(edge_fn_d(p, a, r.d01), r.rd_area));
   f3 bp = bw;
   if (perspective_correct) {
     const float t0 = bw.x * r.v1.z * r.v2.z;
@@ -387,9 +398,9 @@ P3D_HD bool face_dist_rec(const FaceRec& r, f2 p, float blur_radius, f3 bp, Face
   const f2 a = mk2(r.v0.x, r.v0.y);
   const f2 b = mk2(r.v1.x, r.v1.y);
   const f2 c = mk2(r.v2.x, r.v2.y);
-  const float e01 = seg_dist2_rec(p, a, b, r.rd_l01);
-  const float e02 = seg_dist2_rec(p, a, c, r.rd_l02);
-  const float e12 = seg_dist2_rec(p, b, c, r.rd_l12);
+  const float e01 = seg_dist2_rec(p, a, b, r.d01, r.rd_l01);
+  const float e02 = seg_dist2_rec(p, a, c, mk2(-r.d20.x, -r.d20.y), r.rd_l02);
+  const float e12 = seg_dist2_rec(p, b, c, r.d12, r.rd_l12);
   const float dist = fminf(fminf(e01, e02), e12);
   const bool inside = (bp.x > 0.0f) & (bp.y > 0.0f) & (bp.z > 0.0f);
   out->dist = inside ? -dist : dist;

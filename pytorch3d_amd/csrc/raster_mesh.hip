@@ -431,7 +431,8 @@ __device__ __forceinline__ void write_pixel_long(const MeshArgs& a, const Queue&
 
 // Staged face in LDS: five 16-byte words, each read by a wave as one broadcast (all lanes, same address).
 //   [0] v0x v0y v1x v1y   [1] v2x v2y z0 z1   [2] z2 fid nb wide   [3] rd_area, rd_l01 (doubles)   [4] rd_l02, rd_l12
-constexpr int kRecWords = 5;
+//   [5] d01x d01y d12x d12y   [6] d20x d20y - -      (the edge vectors, FaceRec::d01 ...)
+constexpr int kRecWords = 7;
 
 // One 64-face group of a staged chunk against one wave's 8x8 sub-tile: every candidate is evaluated on its FaceRec
 // (shared-reciprocal arithmetic, p3d_geom.h: same bits as the reference's expression tree).  GENERAL adds the
@@ -514,6 +515,11 @@ __device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue&
         fr.rd_l01 = d0.y;
         fr.rd_l02 = d1.x;
         fr.rd_l12 = d1.y;
+        const float4 r5 = rec[5];
+        const float2 r6 = *reinterpret_cast<const float2*>(&rec[6]);
+        fr.d01 = mk2(r5.x, r5.y);
+        fr.d12 = mk2(r5.z, r5.w);
+        fr.d20 = mk2(r6.x, r6.y);
         const bool pcs = PC && !GENERAL;  // wide faces make their chunk general (stage_chunk)
         fr.wide = pcs ? false : __float_as_int(r2.w) != 0;
         const f3 bp = face_depth_rec(fr, p, pcs || persp, pcs || clip, &h);
@@ -679,6 +685,8 @@ __device__ __forceinline__ int stage_chunk(const MeshArgs& a, const StageLds& l,
     d1.y = fr.rd_l12;
     *reinterpret_cast<double2*>(&l.rec[pos][3]) = d0;
     *reinterpret_cast<double2*>(&l.rec[pos][4]) = d1;
+    l.rec[pos][5] = make_float4(fr.d01.x, fr.d01.y, fr.d12.x, fr.d12.y);
+    l.rec[pos][6] = make_float4(fr.d20.x, fr.d20.y, 0.0f, 0.0f);
     // Depth cull (exact): with clipped barycentrics a sample's depth is a convex combination of
     // the vertex depths, so pz >= zmin * (1 - 4e-7) in float arithmetic (three roundings each in
     // the normalisation and the dot product); a lane whose queue is full with K-th depth below

@@ -356,7 +356,9 @@ __device__ __forceinline__ void run_reduce(int& f, float (&g)[9], int lane) {
   if (continues) f = -1;
 }
 
-template <int KT, bool TO_VERTS>
+// PC: perspective_correct && clip_barycentric_coords are known to be set (what the renderer uses for perspective cameras with blur,
+// as in the forward's PC kernels): the step's arithmetic is one basic block instead of five behind uniform flag branches.
+template <int KT, bool TO_VERTS, bool PC = false>
 __global__ __launch_bounds__(256, RowsCfg<KT>::kWaves) void mesh_backward_rows_kernel(BwdArgs a) {
   constexpr int SPR = KT / 4;  // steps per 16-pixel row segment
   constexpr int PIX = RowsCfg<KT>::kPix;
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(256, RowsCfg<KT>::kWaves) void mesh_backward_rows_k
   tab.init(s_table[w], lane);
   tab.index = a.faces;
   tab.index_limit = a.V;
-  const bool persp = a.persp != 0, clip = a.clip != 0;
+  const bool persp = PC || a.persp != 0, clip = PC || a.clip != 0;
 
   const int seg = min(16, W - ax) * KT;               // samples of a row segment inside the image
   const int e = (lane & (PIX - 1)) * KT + lane / PIX;  // this lane's sample within a step's 64
@@ -523,12 +525,19 @@ int launch_mesh_backward(const float* face_verts, const int64_t* faces, int64_t 
   }
   LaunchScope ls("mesh_backward", s);
   const unsigned grid = rows_kernel ? (unsigned)ceil_div(items, 4) : (unsigned)items;
+  const bool pc = persp && clip;
 #define P3D_LAUNCH_MESH_BWD(TV)                                                  \
   switch (K) {                                                                   \
     case 1: mesh_backward_kernel<1, TV><<<grid, 256, 0, s>>>(a); break;          \
     case 2: mesh_backward_kernel<2, TV><<<grid, 256, 0, s>>>(a); break;          \
-    case 4: mesh_backward_rows_kernel<4, TV><<<grid, 256, 0, s>>>(a); break;     \
-    case 8: mesh_backward_rows_kernel<8, TV><<<grid, 256, 0, s>>>(a); break;     \
+    case 4:                                                                      \
+      if (pc) mesh_backward_rows_kernel<4, TV, true><<<grid, 256, 0, s>>>(a);    \
+      else mesh_backward_rows_kernel<4, TV><<<grid, 256, 0, s>>>(a);             \
+      break;                                                                     \
+    case 8:                                                                      \
+      if (pc) mesh_backward_rows_kernel<8, TV, true><<<grid, 256, 0, s>>>(a);    \
+      else mesh_backward_rows_kernel<8, TV><<<grid, 256, 0, s>>>(a);             \
+      break;                                                                     \
     case 16: mesh_backward_rows_kernel<16, TV><<<grid, 256, 0, s>>>(a); break;   \
     case 32: mesh_backward_rows_kernel<32, TV><<<grid, 256, 0, s>>>(a); break;   \
     default: mesh_backward_kernel<0, TV><<<grid, 256, 0, s>>>(a); break;         \

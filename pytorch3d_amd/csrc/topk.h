@@ -19,6 +19,11 @@
 
 #include "p3d_geom.h"  // P3D_HDM
 
+// steps per segment of the exact-K insertion network (TopKPairs::insert_segments)
+#ifndef P3D_SEG_LEN
+#define P3D_SEG_LEN 2
+#endif
+
 namespace p3d {
 
 constexpr int kEmptyIdx = 0x7fffffff;
@@ -326,6 +331,8 @@ struct TopKPairs {
     const LaneMask il = __builtin_amdgcn_ballot_w64(cidx < ix(k));
     return lt | (eq & il);
   }
+  // does any lane of this insertion hold entry k?  (wave-uniform)
+  __device__ __forceinline__ bool any_holds(int k) const { return __builtin_amdgcn_ballot_w64(ix(k) != kEmptyIdx) != 0; }
   // entry k <- candidate where m, then entry k <- entry k-1 where m1
   __device__ __forceinline__ void place_and_shift(int k, LaneMask m, LaneMask m1, u32x2 czi, u32x2 cpa, u32x2 cpb) {
     LaneMask saved;
@@ -384,6 +391,7 @@ struct TopKPairs {
     if (KEY64) return key_of(mk_entry(cz, cidx)) < key_of(zi[k]);
     return (cz < zf(k)) | ((cz == zf(k)) & (cidx < ix(k)));
   }
+  bool any_holds(int k) const { return ix(k) != kEmptyIdx; }
   void place_and_shift(int k, LaneMask m, LaneMask m1, u32x2 czi, u32x2 cpa, u32x2 cpb) {
     if (m) {
       zi[k] = czi;
@@ -419,6 +427,14 @@ struct TopKPairs {
     const u32x2 czi = mk_entry(cz, cidx);
     const u32x2 cpa = NP == 4 ? mk_pair(f32_bits(cpl[0]), f32_bits(cpl[1 % NPS])) : czi;
     const u32x2 cpb = NP == 4 ? mk_pair(f32_bits(cpl[2 % NPS]), f32_bits(cpl[3 % NPS])) : czi;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (KT % 2 == 0 && KT >= 4 && KT <= 8 && KT % P3D_SEG_LEN == 0) {
+      if (__builtin_constant_p(K) && K == KT) {
+        insert_segments(czi, cpa, cpb, cz, cidx);
+        return;
+      }
+    }
+#endif
     LaneMask mk = 0;
 #pragma unroll
     for (int k = KT - 1; k >= 1; --k) {
@@ -443,6 +459,55 @@ struct TopKPairs {
       ki = ix(0);
     }
   }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+  // The exact-K network (K == KT) in SEGMENTS of two steps, entered and left where it can change something (round 6).
+  // A step costs its nine instructions whether or not a lane's mask is set, the network is a quarter of the fine kernel's
+  // candidate pass, and at the bench workload 57 % of its steps change nothing in any lane (profiles/r06/probe_insert.txt):
+  //   * top: entries fill from the front, so while NO inserting lane holds entry k - 1, entry k stays empty in all of them
+  //     (the candidate lands at k - 1 or before): the segment {k + 1, k} is skipped when nobody holds entry k - 1;
+  //   * bottom: lt[k] is monotone in k, so once no lane's candidate sorts before entry k - 1 nothing below k changes.
+  // The kernel's time follows its instruction COUNT, scalar ones included (a version with both tests at every step ran 57 %
+  // fewer steps and 3 % slower, profiles/r06/): one test per segment and side, nothing per step.
+  // The K-th entry (kz, ki) changes only if the top step ran.
+  static constexpr int SL = P3D_SEG_LEN;  // steps per segment
+  // segment S holds steps S * SL + SL - 1 ... S * SL (step 0 = the placement into entry 0)
+  template <int S>
+  __device__ __forceinline__ LaneMask enter_segments(float cz, int cidx, int* seg) {
+    if constexpr (S > 0) {
+      if (!any_holds(S * SL - 1)) return enter_segments<S - 1>(cz, cidx, seg);  // uniform: nobody reaches entry S * SL -- this segment's steps change nothing
+    }
+    *seg = S;
+    return sorts_before(cz, cidx, S * SL + SL - 1);
+  }
+  __device__ __forceinline__ void insert_segments(u32x2 czi, u32x2 cpa, u32x2 cpb, float cz, int cidx) {
+    static_assert(KT % SL == 0, "whole segments");
+    constexpr int NS = KT / SL;
+    int seg = 0;
+    LaneMask mk = enter_segments<NS - 1>(cz, cidx, &seg);
+    // one chain of segments, entered at `seg` (no copies of the chain: with one copy per entry point the register allocator shuffles the queue)
+#pragma unroll
+    for (int S = NS - 1; S >= 0; --S) {
+      if (S <= seg) {  // uniform
+#pragma unroll
+        for (int k = S * SL + SL - 1; k >= S * SL; --k) {
+          if (k > 0) {
+            const LaneMask m1 = sorts_before(cz, cidx, k - 1);
+            place_and_shift(k, mk, m1, czi, cpa, cpb);
+            if (k == KT - 1) {
+              kz = zf(k);
+              ki = ix(k);
+            }
+            mk = m1;
+          } else {
+            place(0, mk, czi, cpa, cpb);
+          }
+        }
+        if (S > 0 && mk == 0) break;  // uniform
+      }
+    }
+  }
+#endif
 
   P3D_HDM int find(int want) const {
     int at = -1;
