@@ -103,7 +103,12 @@ def main():
         return
     here = os.path.dirname(os.path.abspath(__file__))
     with open(os.path.join(here, "traffic.json"), "w") as fh:
-        json.dump({k: v["hbm_bytes"] for k, v in traffic.items()} | {"_detail": traffic, "_source": os.path.basename(dst),
+        # the issue-side counters bench.py quotes beside the HBM roofline ("fp32 VALU issue rate and LDS bandwidth
+        # for the fine stage, reported alongside"): wave-instructions per launch, LDS-active and bank-conflict cycles
+        issue = {k: {c: pmc[k][c] for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES",
+                                            "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE",
+                                            "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY") if c in pmc[k]} for k in pmc if "SQ_INSTS_VALU" in pmc[k]}
+        json.dump({k: v["hbm_bytes"] for k, v in traffic.items()} | {"_detail": traffic, "_issue": issue, "_source": os.path.basename(dst),
                                                                     "_torus_div": float(sys.argv[3]) if len(sys.argv) > 3 else 1.0},
                   fh, indent=1)
     print("\n".join(lines))

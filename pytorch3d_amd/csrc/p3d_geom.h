@@ -344,19 +344,26 @@ P3D_HD void face_rec_make(f3 v0, f3 v1, f3 v2, FaceRec* r) {
 }
 
 // seg_dist2 with the edge's reciprocal and its vector ba = b - a: same value as seg_dist2(p, a, b)
+// PROPER: the caller knows the edge is not degenerate (rd_l2 > 0): the end-point distance and the select are not formed
+// (five instructions per edge in the fine kernel's hottest block; round 6).
+template <bool PROPER = false>
 P3D_HD float seg_dist2_rec(f2 p, f2 a, f2 b, f2 ba, double rd_l2) {
   const float bax = ba.x;
   const float bay = ba.y;
   float t = exact_div(bax * (p.x - a.x) + bay * (p.y - a.y), rd_l2);
-  const float ex = p.x - b.x;
-  const float ey = p.y - b.y;
-  const float d_point = ex * ex + ey * ey;
   t = sat01(t);
   const float dx = (a.x + t * bax) - p.x;
   const float dy = (a.y + t * bay) - p.y;
   const float d_seg = dx * dx + dy * dy;
+  if (PROPER) return d_seg;
+  const float ex = p.x - b.x;
+  const float ey = p.y - b.y;
+  const float d_point = ex * ex + ey * ey;
   return (rd_l2 < 0.0) ? d_point : d_seg;
 }
+
+// a face with a degenerate edge (FaceRec::rd_l.. < 0): the fine kernel's fast nest hands such faces to its general nest
+P3D_HD bool face_rec_degenerate(const FaceRec& r) { return (r.rd_l01 < 0.0) | (r.rd_l02 < 0.0) | (r.rd_l12 < 0.0); }
 
 // face_hit on a FaceRec: identical outputs, 12 divisions -> 12 (cvt, mul_f64, cvt) + 2 reciprocals.  In two halves so that
 // the fine kernel can stop after the depth: a sample whose depth cannot enter a full queue needs no distance
@@ -393,14 +400,16 @@ P3D_HD f3 face_depth_rec(const FaceRec& r, f2 p, bool perspective_correct, bool 
   return bp;
 }
 
-// Second half: the signed squared distance and the hit test (bp, out->z from face_depth_rec).
+// Second half: the signed squared distance and the hit test (bp, out->z from face_depth_rec).  PROPER: no edge of the face is
+// degenerate (face_rec_degenerate is false).
+template <bool PROPER = false>
 P3D_HD bool face_dist_rec(const FaceRec& r, f2 p, float blur_radius, f3 bp, FaceHit* out) {
   const f2 a = mk2(r.v0.x, r.v0.y);
   const f2 b = mk2(r.v1.x, r.v1.y);
   const f2 c = mk2(r.v2.x, r.v2.y);
-  const float e01 = seg_dist2_rec(p, a, b, r.d01, r.rd_l01);
-  const float e02 = seg_dist2_rec(p, a, c, mk2(-r.d20.x, -r.d20.y), r.rd_l02);
-  const float e12 = seg_dist2_rec(p, b, c, r.d12, r.rd_l12);
+  const float e01 = seg_dist2_rec<PROPER>(p, a, b, r.d01, r.rd_l01);
+  const float e02 = seg_dist2_rec<PROPER>(p, a, c, mk2(-r.d20.x, -r.d20.y), r.rd_l02);
+  const float e12 = seg_dist2_rec<PROPER>(p, b, c, r.d12, r.rd_l12);
   const float dist = fminf(fminf(e01, e02), e12);
   const bool inside = (bp.x > 0.0f) & (bp.y > 0.0f) & (bp.z > 0.0f);
   out->dist = inside ? -dist : dist;

@@ -526,7 +526,7 @@ __device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue&
         // Depth first: a sample behind the camera or one that sorts after the K-th entry of a full queue is never
         // stored, whatever its distance -- half of the evaluations at the bench workload end here for every lane
         // (profiles/r03/probe_counts.txt).  Not under the neighbour rule: a face may replace its queued other half.
-        const bool adm = !(h.z < 0.0f) && q.admits(K, h.z, f);
+        const bool adm = !(h.z < 0.0f) & q.admits(K, h.z, f);  // (one exec region, not two: `&&` put a branch between the tests)
         if constexpr (TIES && !GENERAL) {
           // turned away at the depth of the K-th entry (whether it lies within the blur radius is not looked at); selects, not
           // branches: control flow between the stages of the evaluation costs the kernel 60 registers
@@ -535,7 +535,7 @@ __device__ __forceinline__ void eval_candidates(const MeshArgs& a, int K, Queue&
           tie_drop = ev ? d : tie_drop;
           tie_z = ev ? kz0 : tie_z;
         }
-        if (GENERAL || adm) hit = face_dist_rec(fr, p, a.blur, bp, &h);
+        if (GENERAL || adm) hit = face_dist_rec<PC && !GENERAL>(fr, p, a.blur, bp, &h);  // (faces with a degenerate edge make their chunk general)
       }
       if (hit) {
         bool ins = true;
@@ -673,7 +673,9 @@ __device__ __forceinline__ int stage_chunk(const MeshArgs& a, const StageLds& l,
   if (keep) {
     FaceRec fr;
     face_rec_make(v0, v1, v2, &fr);
-    gen = nb != -1 || (PC && fr.wide);
+    // PC: the fast nest evaluates ordinary faces only -- per-pixel reciprocals from the f32 seed (`wide` false) and segment
+    // distances without the degenerate-edge alternative (an edge shorter than 1e-4 NDC on a face that is not of zero area)
+    gen = nb != -1 || (PC && (fr.wide || face_rec_degenerate(fr)));
     l.pm[pos] = cm | (rm << 16);
     l.rec[pos][0] = make_float4(v0.x, v0.y, v1.x, v1.y);
     l.rec[pos][1] = make_float4(v2.x, v2.y, v0.z, v1.z);

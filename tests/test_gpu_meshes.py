@@ -121,6 +121,31 @@ def test_k_above_the_register_queues_on_a_scene_with_sparse_and_dense_tiles(K, p
         _assert_fwd_equal(ours, ref, tag=f"K={K} bin={bin_size}")
 
 
+@pytest.mark.parametrize("K", [1, 4, 8, 12, 50])
+def test_needle_faces_with_a_degenerate_edge(K):
+    """Faces with ONE edge shorter than 1e-4 (squared length <= 1e-8: the reference takes the distance to that edge as the distance
+    to its end point, geometry_utils.cuh:345) but an area well above 1e-8 -- needles.  The perspective + clip kernels evaluate
+    ordinary faces without that alternative and hand chunks that hold such a face to their general nest (raster_mesh.hip:
+    stage_chunk, p3d_geom.h: face_rec_degenerate): needles among ordinary faces, in every position of a chunk, several chunks per
+    tile, all flag combinations, against the oracle."""
+    gen = torch.Generator().manual_seed(700 + K)
+    F = 620
+    fv = U.triangle_soup(F, gen, size=0.6)
+    needles = torch.randperm(F, generator=gen)[:90]
+    for j, i in enumerate(needles.tolist()):
+        a, b = (0, 1) if j % 3 == 0 else ((1, 2) if j % 3 == 1 else (2, 0))
+        step = (torch.rand(2, generator=gen) - 0.5) * (3e-4 if j % 2 else 2e-5)  # both sides of the 1e-4 threshold
+        fv[i, b, :2] = fv[i, a, :2] + step
+    first, count = U.split_counts(F, 2)
+    nbr = torch.full((F,), -1, dtype=torch.int64)
+    for persp, clip in ((True, True), (False, False), (True, False)):
+        ref = orc.rasterize_meshes_naive(fv, first, count, nbr, (40, 56), 0.004, K, persp, clip, False)
+        assert int(torch.isin(ref[0], needles).sum()) > 0, "no needle is visible"
+        for bin_size in (0, 16, 32):
+            ours = _run_ours(fv, first, count, nbr, (40, 56), 0.004, K, bin_size, 700, persp, clip, False)
+            _assert_fwd_equal(ours, ref, tag=f"K={K} persp={persp} clip={clip} bin={bin_size}")
+
+
 def test_k_too_large_raises():
     from pytorch3d_amd import _C
 
