@@ -78,8 +78,15 @@ def parse():
                     help="seconds of the same step, untimed, BEFORE the --warmup steps: a fresh box reaches its steady clocks and a warm "
                          "allocator only after some tenths of a second of work, and the driver's `--steps 20 --warmup 5` is 65 ms in all "
                          "(round 4: 6456 Mpix/s in that form against 6648 over 200 steps).  Reported in the line as `prewarm_s`; 0 turns it off")
+    ap.add_argument("--gather-checksum", action="store_true",
+                    help="after the timed region: sha256 of the gathered depth images on rank 0, in job order (tests compare an N-rank run "
+                         "with the one-rank run of the same jobs bit for bit)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="multi-rank plumbing only: every rank reports (RANK, LOCAL_RANK, device) over gloo, rank 0 prints the mapping and what "
+                         "is wrong with it; no RCCL, no kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-reference-device", action="store_true", help="skip the same-GPU leg on the reference's own device kernels (vs_reference_device)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the timing of the unmodified reference MeshRasterizer through the shim")
     ap.add_argument("--cpu-budget-s", type=float, default=110.0,
                     help="wall-clock bound for the CPU baseline legs (the Python reference takes ~31 s of it; the C++ kernels then "
@@ -90,13 +97,13 @@ def parse():
 
 def sub_batches_of_rank(jobs, batch, rank, world):
     """BASELINE configs[4] (SURVEY.md 8d config 5): `jobs` render jobs = jobs / batch sub-batches (generator seeds 0, 1, ...);
-    rank r owns sub-batches r, r + world, ...  Raises when the sub-batches do not divide over the ranks."""
+    rank r owns sub-batches r, r + world, ...  (8 sub-batches over 3 ranks: 3 + 3 + 2).  Raises when a rank would get none."""
     if jobs % batch:
         raise SystemExit("--jobs must be a multiple of --batch")
     n_sub = jobs // batch
-    if n_sub % world:
-        raise SystemExit(f"--jobs {jobs}: {n_sub} sub-batches do not divide over {world} ranks")
-    return list(range(rank, n_sub, world))
+    if n_sub < world:
+        raise SystemExit(f"--jobs {jobs}: {n_sub} sub-batches for {world} ranks -- a rank would have nothing to run")
+    return list(range(rank, n_sub, world))  # an uneven deal is fine: the ranks with one sub-batch more set the time
 
 
 def build_batch(n_meshes, seed, device, torus_div=TORUS_DIV):
@@ -358,6 +365,206 @@ def other_configs(lib, _lib, device):
     return out
 
 
+def config5_one_gpu(args, device, H, W, K, blur, headline_mpix):
+    """BASELINE configs[4] on ONE GPU, the N = 1 anchor of the scaling curve: 512 jobs = 8 sub-batches of
+    64 (configs[2] generator, seeds 0..7) back to back through the headline's own step, then the job's one collective -- the gather
+    of the depth images to rank 0 (`sharding.gather_batch`: with one rank the batch itself)."""
+    import pytorch3d_amd as p3d
+    from pytorch3d_amd import sharding
+
+    B, n_sub = args.batch, 8
+    gen = torch.Generator().manual_seed(231)
+    g = [torch.randn(sh, generator=gen).to(device) for sh in ((B, H, W, K), (B, H, W, K, 3), (B, H, W, K))]
+    subs = []
+    for seed in range(n_sub):
+        meshes, _, _, nfaces = build_batch(B, seed=seed, device=device)
+        subs.append((meshes, meshes.verts_packed().clone().requires_grad_(True), sum(nfaces)))
+
+    def one_pass():
+        kept = []
+        for meshes, vp, _ in subs:
+            vp.grad = None
+            p2f, zbuf, bary, dists = p3d.rasterize_meshes(meshes.update_verts_packed(vp), image_size=(H, W), blur_radius=blur,
+                                                          faces_per_pixel=K, perspective_correct=True, clip_barycentric_coords=True)
+            torch.autograd.backward([zbuf, bary, dists], g)
+            kept.append(zbuf)
+        shard = torch.cat([z[..., 0].detach() for z in kept], 0).contiguous()
+        return sharding.gather_batch(shard, [B * n_sub], dst=0)
+
+    one_pass()
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        final = one_pass()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[1]
+    mpix = n_sub * B * H * W / dt / 1e6
+    return {"jobs": n_sub * B, "sub_batches": n_sub, "seconds_per_pass": dt, "ms_per_sub_batch": dt / n_sub * 1e3, "Mpix_s": mpix,
+            "vs_headline": mpix / headline_mpix, "gathered_shape": list(final.shape), "total_faces": sum(s[2] for s in subs),
+            "passes_timed": 3, "how": "median of 3 passes; the same as `python bench.py --jobs 512 --gpus 1`, inside the default line"}
+
+
+def reference_device_leg(device, verts_cpu, faces_cpu, H, W, K, blur, our_ms_per_step):
+    """The reference's OWN device kernels (pytorch3d/csrc/rasterize_meshes/*.cu as a ROCm build of pytorch3d compiles them:
+    torch hipify + hipcc, default flags; oracle/build_ref_hip.py -> oracle/_ref/p3d_ref_hip.so) on the bench batch on this GPU:
+    `_C.rasterize_meshes` (coarse + fine, bin_size / max_faces_per_bin as the reference's Python wrapper picks them,
+    renderer/mesh/rasterize_meshes.py:201-222) + `_C.rasterize_meshes_backward`.  A checker leg, after the timed region."""
+    from oracle import oracle as orc
+
+    ref = orc.ref_hip_module(nofma=False)
+    if ref is None:
+        return {"value": None, "reason": "oracle/_ref/p3d_ref_hip.so is not built on this machine"}
+    B = len(faces_cpu)
+    fv = torch.cat([v[f] for v, f in zip(verts_cpu, faces_cpu)], 0).contiguous().to(device)
+    counts = torch.tensor([int(f.shape[0]) for f in faces_cpu], dtype=torch.int64)
+    first = (torch.cumsum(counts, 0) - counts).to(device)
+    counts = counts.to(device)
+    F = int(fv.shape[0])
+    nbr = torch.full((F,), -1, dtype=torch.int64, device=device)
+    M = int(max(10000, F / 5))
+    fargs = (fv, first, counts, nbr, (H, W), blur, K, 32, M, True, True, False)
+    gen = torch.Generator().manual_seed(231)
+    g = [torch.randn(sh, generator=gen).to(device) for sh in ((B, H, W, K), (B, H, W, K, 3), (B, H, W, K))]
+
+    def ms(fn, iters):
+        ts = []
+        for _ in range(iters):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            r = fn()
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        return sorted(ts)[len(ts) // 2], r
+
+    out = ref.rasterize_meshes(*fargs)  # warm-up
+    torch.cuda.synchronize()
+    t_f, out = ms(lambda: ref.rasterize_meshes(*fargs), 2)
+    ref.rasterize_meshes_backward(fv, out[0], g[0], g[1], g[2], True, True)
+    t_b, _ = ms(lambda: ref.rasterize_meshes_backward(fv, out[0], g[0], g[1], g[2], True, True), 5)
+    mpix = B * H * W / ((t_f + t_b) * 1e-3) / 1e6
+    return {"value": mpix, "unit": "Mpix/s", "forward_ms": t_f, "backward_ms": t_b, "ours_ms_per_step": our_ms_per_step,
+            "speedup": (t_f + t_b) / our_ms_per_step, "faces": F, "max_faces_per_bin": M,
+            "kind": "the reference's rasterize_meshes.cu / rasterize_coarse.cu kernels, hipified and compiled for gfx950 as a checker "
+                    "(oracle/build_ref_hip.py); same operator boundary, same inputs, torch events on the current stream"}
+
+
+def config4_cpu_baseline(budget_s=40.0):
+    """BASELINE.md B3 / B4 on this box's host cores (the reference's C++ CPU kernels, oracle/_ref/p3d_ref_cpu.so, and its Python
+    interpolate_face_attributes_python): config 4 at the reduced size BASELINE.md measured (P = 100k, 128^2, K = 10, r = 0.01) with
+    the factor to the full size stated; the compositor at its full size (it is cheap); a 64 x 64 x 8 fragment for the interpolation."""
+    from oracle import oracle as orc
+
+    ref = orc.ref_module()
+    if ref is None:
+        return {"value": None, "reason": "oracle/_ref/p3d_ref_cpu.so is not built on this machine"}
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    gen = torch.Generator().manual_seed(0)
+    P, H, K, r, C = 100_000, 128, 10, 0.01, 3
+    pts = torch.cat([torch.rand(P, 2, generator=gen) * 2 - 1, torch.rand(P, 1, generator=gen) * 2 + 0.5], 1)
+    first, count = torch.zeros(1, dtype=torch.int64), torch.full((1,), P, dtype=torch.int64)
+    radius = torch.full((P,), r)
+    t0 = time.perf_counter()
+    idx, zbuf, dists = ref._rasterize_points_naive(pts, first, count, (H, H), radius, K)
+    t_rf = time.perf_counter() - t0
+    gz, gd = torch.randn(zbuf.shape, generator=gen), torch.randn(dists.shape, generator=gen)
+    t0 = time.perf_counter()
+    ref.rasterize_points_backward(pts, idx, gz, gd)
+    t_rb = time.perf_counter() - t0
+    feats = torch.rand(C, P, generator=gen)
+    alphas = (1 - dists / (r * r)).clamp(0, 1).permute(0, 3, 1, 2).contiguous()
+    pidx = idx.long().permute(0, 3, 1, 2).contiguous()
+    t0 = time.perf_counter()
+    img = ref.accum_alphacomposite(feats, alphas, pidx)
+    t_cf = time.perf_counter() - t0
+    gi = torch.randn(img.shape, generator=gen)
+    t0 = time.perf_counter()
+    ref.accum_alphacomposite_backward(gi, feats, alphas, pidx)
+    t_cb = time.perf_counter() - t0
+    total = t_rf + t_rb + t_cf + t_cb
+    pairs_factor = (1_000_000 * 512 * 512) / (P * H * H)  # the naive rasterizer tests every (pixel, point) pair
+    pixel_factor = (512 * 512) / (H * H)                  # backward and compositor work per pixel slot
+    full_s = t_rf * pairs_factor + (t_rb + t_cf + t_cb) * pixel_factor
+    out = {"kind": "reference", "cores": cores, "unit": "Mpix/s",
+           "value": H * H / total / 1e6,
+           "sample": f"P={P}, {H}x{H}, K={K}, r={r}: RasterizePointsNaiveCpu fwd {t_rf:.2f} s + RasterizePointsBackwardCpu {t_rb * 1e3:.1f} ms + "
+                     f"alphaCompositeCpuForward {t_cf * 1e3:.1f} ms + Backward {t_cb * 1e3:.1f} ms (rasterize_points_cpu.cpp:14-96, "
+                     "alpha_composite_cpu.cpp:17-124; single-threaded as the reference writes them)",
+           "hits_per_pixel": float((idx >= 0).float().sum() / (H * H)),
+           "scale_to_full_config4": {"pixel_point_pairs": pairs_factor, "pixel_slots": pixel_factor, "extrapolated_seconds": full_s,
+                                     "extrapolated_Mpix_s": 512 * 512 / full_s / 1e6}}
+    # B4: the reference has no C++ CPU interpolation (interp_face_attrs.h:29-35); its Python formulation on a 64 x 64 x 8 fragment
+    try:
+        N, Hf, Kf, F, D = 1, 64, 8, 5000, 3
+        p2f = torch.randint(-1, F, (N, Hf, Hf, Kf), generator=gen)
+        bary = torch.rand(N, Hf, Hf, Kf, 3, generator=gen)
+        attrs = torch.rand(F, 3, D, generator=gen)
+        fn, what = None, None
+        try:  # the reference's own function, when its Python package is on this machine (python_reference_baseline staged the import)
+            from pytorch3d.ops.interp_face_attrs import interpolate_face_attributes_python as fn
+
+            what = "the reference's interpolate_face_attributes_python (ops/interp_face_attrs.py:86-102) on CPU tensors"
+        except Exception:
+            def fn(p2f, bary, attrs):  # the same formulation restated: gather + weighted sum + mask
+                mask = p2f < 0
+                idxe = p2f.clone().view(-1, 1, 1).expand(-1, 3, attrs.shape[-1])
+                idxe = torch.where(idxe < 0, torch.zeros_like(idxe), idxe)
+                pix = attrs.gather(0, idxe).view(tuple(p2f.shape) + (3, attrs.shape[-1]))
+                vals = (bary[..., None] * pix).sum(dim=-2)
+                vals[mask] = 0
+                return vals
+
+            what = "the torch formulation of ops/interp_face_attrs.py:86-102 restated (the reference's package is not importable here)"
+        fn(p2f, bary, attrs)
+        t0 = time.perf_counter()
+        fn(p2f, bary, attrs)
+        t_i = time.perf_counter() - t0
+        out["interp_face_attrs_python"] = {"seconds": t_i, "fragment": [N, Hf, Hf, Kf], "D": D, "Mpix_s": Hf * Hf / t_i / 1e6, "cores": cores,
+                                           "what": what}
+    except Exception as e:
+        out["interp_face_attrs_python"] = {"value": None, "reason": repr(e)}
+    return out
+
+
+def dry_run(world, rank, local_rank):
+    """`--dry-run`: the launch plumbing of an N-GPU run without RCCL and without a kernel -- what a first contact with an 8-GPU node
+    should not have to debug.  Every rank reports (RANK, LOCAL_RANK, the device it would bind, visible devices, pid) over gloo;
+    rank 0 checks that the ranks are 0..N-1, that LOCAL_RANK -> device is one-to-one and inside the visible devices, and prints
+    ONE JSON line.  Exit code 0 also when the mapping has problems on this box (they are in the line: a one-GPU box running
+    `--gpus 8 --dry-run` lists seven devices that do not exist)."""
+    import torch.distributed as dist
+
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    mine = {"rank": rank, "local_rank": local_rank, "device": f"cuda:{local_rank}", "devices_visible": visible, "pid": os.getpid(),
+            "master": f"{os.environ.get('MASTER_ADDR', '?')}:{os.environ.get('MASTER_PORT', '?')}",
+            "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+    rows = [mine]
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        rows = [None] * world
+        dist.all_gather_object(rows, mine)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        problems = []
+        if sorted(r["rank"] for r in rows) != list(range(world)):
+            problems.append("ranks are not 0..N-1: %r" % [r["rank"] for r in rows])
+        if len({r["local_rank"] for r in rows}) != world:
+            problems.append("LOCAL_RANK is not one-to-one: %r" % [r["local_rank"] for r in rows])
+        for r in rows:
+            if r["local_rank"] >= r["devices_visible"]:
+                problems.append(f"rank {r['rank']}: LOCAL_RANK {r['local_rank']} has no device (visible: {r['devices_visible']})")
+        if world > 1 and any(r["ipc_mode_legacy"] != "0" for r in rows):
+            problems.append("HSA_ENABLE_IPC_MODE_LEGACY is not 0 on every rank: RCCL across processes needs dmabuf IPC on this driver")
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ok": not problems, "problems": problems, "mapping": rows,
+                          "backend_planned": "nccl (RCCL over xGMI), gloo if it cannot be brought up"}), flush=True)
+    return 0
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: re-execute this script under torch.distributed.run with one rank per
     GPU (what the driver does itself for N > 1, and what the reference's only multi-device test does with
@@ -367,7 +574,7 @@ def spawn_ranks(args):
 
     n = args.gpus
     have = torch.cuda.device_count()
-    if have < n and not (os.environ.get("P3D_BENCH_TEST_BACKEND") or os.environ.get("P3D_BENCH_SHARED_GPU")):
+    if have < n and not (args.dry_run or os.environ.get("P3D_BENCH_TEST_BACKEND") or os.environ.get("P3D_BENCH_SHARED_GPU")):
         raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -474,6 +681,8 @@ def main():
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size is used", file=sys.stderr)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        raise SystemExit(dry_run(world, rank, local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); no CPU fallback exists for the product path")
     # P3D_BENCH_TEST_BACKEND=gloo maps every rank to cuda:0 and uses gloo: lets the multi-rank code path (barriers,
@@ -561,7 +770,7 @@ def main():
         torch.autograd.backward([zbuf, bary, dists], [g_z, g_b, g_d])
         return p2f, zbuf
 
-    own = [B] * world if not jobs_mode else [B * steps] * world
+    own = [B] * world if not jobs_mode else [B * len(sub_batches_of_rank(args.jobs, B, r, world)) for r in range(world)]
 
     gather_state = {"ok": True, "how": "gather to rank 0", "error": None}
 
@@ -578,6 +787,20 @@ def main():
                 gather_state.update(ok=False, how="none", error=f"{type(e2).__name__}: {str(e2)[:300]}")
                 return None
 
+    # The driver's protocol to the letter first (W warm-up steps, K timed, nothing ahead of them): reported beside the headline as
+    # `without_prewarm`, so that the two protocols never have to be compared across runs.
+    cold = None
+    if args.prewarm_s > 0 and not jobs_mode:
+        for i in range(args.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        tc0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize()
+        cold_s = time.perf_counter() - tc0
+        cold = {"ms_per_step": cold_s / steps * 1e3, "value": world * B * H * W * steps / cold_s / 1e6, "steps": steps, "warmup": args.warmup,
+                "what": "this rank's own clock over the same K steps after W warm-up steps on a process that had run nothing before"}
     prewarm_steps = 0
     if args.prewarm_s > 0:
         # untimed, ahead of the W warm-up steps (see --prewarm-s): never inside the timed region, never counted as steps
@@ -610,11 +833,13 @@ def main():
             kept.append(zbuf)
     tg0 = time.perf_counter()
     gather_ms = 0.0
-    if dist_on:
+    final = None
+    if dist_on or args.gather_checksum:
         torch.cuda.synchronize()
         tg0 = time.perf_counter()
         final = final_gather(kept if jobs_mode else [zbuf])
-        del final
+        if not args.gather_checksum:
+            final = None
     torch.cuda.synchronize()
     if dist_on:
         gather_ms = (time.perf_counter() - tg0) * 1e3
@@ -650,8 +875,19 @@ def main():
     del pad
     total_faces = batches[(steps - 1) % len(batches)][2]
 
+    gathered = None
+    if rank == 0 and final is not None:
+        import hashlib
+
+        if jobs_mode:  # rank-major (rank r holds sub-batches r, r + world, ...) -> job order
+            deal = [sb for r in range(world) for sb in sub_batches_of_rank(args.jobs, B, r, world)]
+            pos = torch.tensor([deal.index(sb) for sb in range(len(deal))], device=final.device)
+            final = final.view(len(deal), B, H, W)[pos].reshape(-1, H, W)
+        gathered = {"shape": list(final.shape), "sha256": hashlib.sha256(final.detach().cpu().contiguous().numpy().tobytes()).hexdigest(),
+                    "order": "job order (sub-batch = generator seed, ascending)" if jobs_mode else "rank order (rank r ran generator seed r)"}
+    del final
     if rank == 0:
-        pixels = world * B * H * W * steps
+        pixels = args.jobs * H * W if jobs_mode else world * B * H * W * steps
         value = pixels / elapsed / 1e6
         # ---- roofline of the dominant kernel (algorithmic bytes) -----------------------------------
         px = B * H * W
@@ -671,22 +907,48 @@ def main():
         kernels = {k: {"launches": n, "avg_ms": ms / n} for k, (n, ms) in prof.items()}
         dom = max((k for k in kernels if k in alg), key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
         achieved = alg[dom] / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
-        traffic, traffic_source = None, None
+        traffic, traffic_source, tj = None, None, {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 # counters of another workload say nothing about this one: the file names the generator scale it was collected on
-                if float(tj.get("_torus_div", 1.5)) == float(TORUS_DIV) and not jobs_mode:
+                if float(tj.get("_torus_div", 1.5)) == float(TORUS_DIV) and not jobs_mode and (B, H, W, K) == (64, 512, 512, 8):
                     traffic = tj.get(dom)
                     traffic_source = tj.get("_source", "profiles/traffic.json") + " (rocprofv3 PMC passes of an earlier run of this command; not measured in this run)"
                 else:
                     traffic_source = "profiles/traffic.json was collected on another workload (torus_div %s): not used" % tj.get("_torus_div", 1.5)
             except Exception:
                 traffic = None
+        # "secondary, reported alongside: fp32 VALU issue rate and LDS bandwidth for the fine stage".  The counters
+        # (SQ_INSTS_VALU per launch, from the same committed rocprofv3 PMC passes as `traffic`) priced at one wave64 instruction
+        # per 4 cycles and SIMD: the time the launch cannot go under while it issues that many vector instructions.
+        valu, lds_note = None, None
+        try:
+            props = torch.cuda.get_device_properties(device)
+            simds = props.multi_processor_count * 4
+            clock_ghz = 2.4  # MI355X peak engine clock, /opt/skills/guides/MI355X_MICROARCH.md (the sustained clock is lower: the bound is a floor)
+            iss = (tj.get("_issue") or {}).get(dom) if traffic is not None else None
+            if iss and iss.get("SQ_INSTS_VALU"):
+                insts = float(iss["SQ_INSTS_VALU"])
+                bound_ms = insts * 4.0 / simds / (clock_ghz * 1e9) * 1e3
+                valu = {"insts_per_launch": insts, "cycles_per_inst": 4, "simds": simds, "clock_ghz": clock_ghz, "issue_bound_ms": bound_ms,
+                        "frac": bound_ms / kernels[dom]["avg_ms"], "salu_insts_per_launch": iss.get("SQ_INSTS_SALU"),
+                        "per_wave": insts / iss["SQ_WAVES"] if iss.get("SQ_WAVES") else None,
+                        "source": traffic_source}
+                if iss.get("SQ_LDS_IDX_ACTIVE"):
+                    lds_note = {"lds_insts_per_launch": iss.get("SQ_INSTS_LDS"), "lds_active_cycles": iss.get("SQ_LDS_IDX_ACTIVE"),
+                                "bank_conflict_cycles": iss.get("SQ_LDS_BANK_CONFLICT"),
+                                "bank_conflict_frac": iss.get("SQ_LDS_BANK_CONFLICT", 0.0) / iss["SQ_LDS_IDX_ACTIVE"]}
+        except Exception:
+            valu = None
+        hbm_frac = achieved / HBM_PEAK_GBPS
         roofline = {
-            "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+            # the binding resource: whichever fraction is higher (both headline kernels sit on the vector issue
+            # ceiling with HBM two thirds idle).  achieved / peak / frac stay the HBM figures the metric asks for.
+            "bound": "valu" if (valu is not None and valu["frac"] > hbm_frac) else "hbm",
+            "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": hbm_frac, "valu": valu, "lds": lds_note, "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kernels[dom]["avg_ms"],
             "per_kernel": {k: {"avg_ms": round(kernels[k]["avg_ms"], 4), "algorithmic_gbps": alg[k] / (kernels[k]["avg_ms"] * 1e-3) / 1e9,
                                "compulsory_bytes": compulsory[k],
@@ -710,11 +972,11 @@ def main():
             "n_gpus": world,
             "steps": steps,
             "warmup": args.warmup,
-            "prewarm_s": args.prewarm_s, "prewarm_steps": prewarm_steps,
+            "prewarm_s": args.prewarm_s, "prewarm_steps": prewarm_steps, "without_prewarm": cold,
             "ms_per_step": elapsed / steps * 1e3,
             "ms_per_step_median": median_ms,
             "gather_ms": gather_ms,
-            "gather": dict(gather_state, backend=backend, backend_note=backend_note) if dist_on else None,
+            "gather": dict(gather_state, backend=backend, backend_note=backend_note, gathered=gathered) if (dist_on or gathered) else None,
             "per_rank": per_rank,
             "higher_is_better": True,
             "scaling": "strong" if jobs_mode else "weak",
@@ -723,7 +985,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": workload,
-                "global_batch": world * B * (steps if jobs_mode else 1), "image_size": [H, W], "faces_per_pixel": K, "blur_radius": blur,
+                "global_batch": args.jobs if jobs_mode else world * B, "image_size": [H, W], "faces_per_pixel": K, "blur_radius": blur,
                 "total_faces_per_rank": total_faces, "pixel_slot_fill": hit_frac, "covered_pixel_fraction": covered / px,
                 "parallelism": f"batch-sharded x{world}, final gather to rank 0 only",
                 "path": "pytorch3d_amd.rasterize_meshes -- this package's L2 mirror of renderer/mesh/rasterize_meshes.py (autograd Function over "
@@ -750,12 +1012,33 @@ def main():
                                                    if isinstance(v, dict) and v.get("ms_per_step")}
             if B == 64 and H == 512 and isinstance(out.get("other_configs"), dict):
                 out["other_configs"]["config4_points_renderer_dropin"] = dropin_points_timing()
+        if world == 1 and not jobs_mode and not args.no_other_configs and B == 64 and H == 512 and isinstance(out.get("other_configs"), dict):
+            try:  # the N = 1 anchor of BASELINE configs[4]'s scaling curve, timed on this build in this run
+                out["other_configs"]["config5_jobs512_1gpu"] = config5_one_gpu(args, device, H, W, K, blur, value)
+            except Exception as e:
+                out["other_configs"]["config5_jobs512_1gpu"] = {"error": repr(e)}
+        if world == 1 and not jobs_mode and not args.no_reference_device:
+            try:  # the same-GPU baseline: the reference's own device kernels on the bench batch
+                _, _, _, verts_cpu, faces_cpu = batches[0]
+                rd = reference_device_leg(device, verts_cpu, faces_cpu, H, W, K, blur, elapsed / steps * 1e3)
+                out["vs_reference_device"] = rd
+                if rd.get("value"):
+                    out["vs_baseline"] = value / rd["value"]
+                    out["vs_baseline_note"] = ("BASELINE.md publishes no number for this metric; the ratio is against the reference's own device kernels "
+                                               "compiled for this GPU and timed in this run (vs_reference_device)")
+            except Exception as e:
+                out["vs_reference_device"] = {"value": None, "error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 _, _, _, verts_cpu, faces_cpu = batches[0]
                 out["cpu_baseline"] = cpu_baseline(verts_cpu, faces_cpu, H, W, K, blur, args.cpu_budget_s)
             except Exception as e:  # the baseline must never sink the GPU measurement
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
+            if isinstance(out.get("other_configs"), dict) and isinstance(out["other_configs"].get("config4_points_1m_512_k10_fwd_bwd"), dict):
+                try:
+                    out["other_configs"]["config4_points_1m_512_k10_fwd_bwd"]["cpu_baseline"] = config4_cpu_baseline()
+                except Exception as e:
+                    out["other_configs"]["config4_points_1m_512_k10_fwd_bwd"]["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.destroy_process_group()

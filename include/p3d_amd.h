@@ -134,6 +134,14 @@ int p3d_rasterize_meshes_backward_verts(const float* face_verts, const int64_t* 
  * The backward TRUSTS the cover: a clear bit skips the row without looking. */
 size_t p3d_rasterize_meshes_cover_bytes(int N, int H, int W);
 
+/* Is `cover` still the cover of `pix_to_face`?  *stale (one int32 on the device, written here) becomes non-zero iff some 16-pixel
+ * row segment holds a face the cover does not know of -- the one way a cover can make the backward wrong (a set bit over an
+ * empty segment only costs time).  For callers that cannot rule out writes into pix_to_face between the forward and the
+ * backward (pytorch3d_amd._C with P3D_CHECK=1: tensors edited through `.data`); reads slot 0 of every pixel, ~0.2 ms at the
+ * bench size -- about half of what the cover saves.  The reference has no counterpart (its backward reads every entry). */
+int p3d_rasterize_meshes_cover_check(const int64_t* pix_to_face, const int32_t* cover, int N, int H, int W, int K, int32_t* stale,
+                                     p3d_stream_t stream);
+
 /* p3d_rasterize_meshes + the row cover of its output (cover may be null: then identical to p3d_rasterize_meshes). */
 int p3d_rasterize_meshes_with_cover(const float* face_verts, const int64_t* mesh_to_face_first_idx,
                                     const int64_t* num_faces_per_mesh, const int64_t* clipped_faces_neighbor_idx, int64_t F,

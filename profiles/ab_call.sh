@@ -16,7 +16,7 @@ for v in "$@"; do
   P3D_LIB_PATH=$L/libp3d_$v.so timeout 240 python -m pytest tests/test_gpu_bench_launch_parity.py tests/test_gpu_cover.py tests/test_gpu_meshes.py \
     tests/test_gpu_points_composite_interp.py tests/test_gpu_reference_suite_replay.py tests/test_gpu_vs_reference_device_kernels.py -x -q > $O/tests_$v.txt 2>&1
   echo "[$v] $(tail -n 1 $O/tests_$v.txt)"
-  P3D_LIB_PATH=$L/libp3d_$v.so timeout 100 python bench.py --steps 100 --no-cpu-baseline --no-dropin > $O/bench_$v.json 2>/dev/null
+  P3D_LIB_PATH=$L/libp3d_$v.so timeout 100 python bench.py --steps 100 --no-cpu-baseline --no-dropin --no-reference-device > $O/bench_$v.json 2>/dev/null
   python -c "
 import json;b=json.load(open('$O/bench_$v.json'));print('[$v]', round(b['value'],1), 'Mpix/s', round(b['ms_per_step'],4), 'ms', b['kernels_ms']); print('[$v]', {k:(x['wall_ms'],x['kernels_ms']) for k,x in b['other_configs'].items()})"
 done

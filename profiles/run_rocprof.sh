@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 OUT=${1:-gpurun_out/prof}
 mkdir -p "$OUT"
 # $2 (optional): another command to profile instead of the bench step, e.g. "python profiles/dropin_points_timing.py --mode patched"
-BENCH=${2:-"python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs --no-dropin"}
+BENCH=${2:-"python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs --no-dropin --no-reference-device"}
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $BENCH > "$OUT/stats.log" 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS \
   --kernel-trace --output-format csv -d "$OUT/pmc_sq" -- $BENCH > "$OUT/pmc_sq.log" 2>&1

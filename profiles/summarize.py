@@ -36,7 +36,7 @@ def main():
     src, dst = sys.argv[1], sys.argv[2]
     # argv[4] (optional): the profiled command, when it is not bench.py's (then profiles/traffic.json is left alone: bench.py reads
     # it as the counters of ITS dominant kernel)
-    cmd_text = sys.argv[4] if len(sys.argv) > 4 else "python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs --no-dropin"
+    cmd_text = sys.argv[4] if len(sys.argv) > 4 else "python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs --no-dropin --no-reference-device"
     lines = ["# rocprofv3 summary (" + os.path.basename(dst) + ")", "",
              "Command: `" + cmd_text + "` under `rocprofv3` (profiles/run_rocprof.sh: `--kernel-trace --stats`, then one run per `--pmc` set), "
              "MI355X / gfx950.", ""]

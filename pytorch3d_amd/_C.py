@@ -166,15 +166,16 @@ class _Need:
 
 
 def _mesh_workspace(lib, F, N, H, W, bin_size, M, dev, what="meshes", extra=0):
-    """(workspace, _Need or None, byte offset of the call's needed-entries word); what: "meshes" (F faces) or "points";
-    extra: bytes the entry point takes off the END of the workspace (the marks of the CUDA tie order)."""
+    """(workspace, _Need or None, byte offset of the call's needed-entries word, list entries the workspace was sized for or None);
+    what: "meshes" (F faces) or "points"; extra: bytes the entry point takes off the END of the workspace (the marks of the CUDA
+    tie order) -- p3d_rasterize_meshes_workspace_bytes counts them in already (include/p3d_amd.h), the short size does not."""
     worst_fn = getattr(lib, f"p3d_rasterize_{what}_workspace_bytes")
     short_fn = getattr(lib, f"p3d_rasterize_{what}_short_workspace_bytes")
     at_fn = getattr(lib, f"p3d_rasterize_{what}_workspace_need_offset")
-    worst = worst_fn(F, N, H, W, bin_size, M) + extra
+    worst = worst_fn(F, N, H, W, bin_size, M)
     if SHORT_WORKSPACE == "never" or (SHORT_WORKSPACE != "always" and worst <= SHORT_WORKSPACE_ABOVE):
         WORKSPACE_STATS["last_bytes"], WORKSPACE_STATS["last_entries"] = worst, None
-        return _workspace(worst, dev), None, 0
+        return _workspace(worst, dev), None, 0, None
     key = (what, dev.index, F, N, H, W, bin_size, M)
     need = _NEEDS.get(key)
     if need is None:
@@ -190,7 +191,8 @@ def _mesh_workspace(lib, F, N, H, W, bin_size, M, dev, what="meshes", extra=0):
     nbytes = min(short_fn(F, N, H, W, bin_size, M, int(entries)) + extra, worst)
     WORKSPACE_STATS["short_calls"] += 1
     WORKSPACE_STATS["last_bytes"], WORKSPACE_STATS["last_entries"] = nbytes, int(entries)
-    return _workspace(nbytes, dev), need, at_fn(F, N, H, W, bin_size, M)
+    # (the entries go back to the caller, who hands them to report_later: the module-wide stats are another thread's too)
+    return _workspace(nbytes, dev), need, at_fn(F, N, H, W, bin_size, M), int(entries)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -234,56 +236,79 @@ def rasterize_meshes(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, cli
     return out
 
 
-# pix_to_face tensors returned by rasterize_meshes -> their row covers, for as long as the tensor OBJECT lives.  Keyed by the
-# memory the tensor occupies; an entry is used only if the tensor that was returned is still alive (so the memory cannot have
-# been handed to anybody else), has not been written in place since (version counter), and the argument of the backward is a
-# contiguous tensor of the same shape at the same address.  Anything else: no cover, the backward reads every row.
+# The row cover of a pix_to_face tensor returned by rasterize_meshes rides ON that tensor object (a Python attribute: it lives
+# exactly as long as the object does, and nothing else can ever be mistaken for it -- until round 5 a module-wide map keyed by
+# the tensor's address played this part).  The reference's autograd node saves the very object and hands it back to
+# `rasterize_meshes_backward` (renderer/mesh/rasterize_meshes.py:291-357: pix_to_face is a non-differentiable output, autograd
+# keeps the original).  The cover is used only if the tensor has not been written in place since (version counter) and still has
+# the shape the cover was made for; a copy, a view, another tensor: no cover, the backward reads every row.
 #
-# NOT SEEN: writes that bypass the version counter -- `pix_to_face.data[...] = x`, an external kernel writing
-# through data_ptr() -- between the forward and the backward.  A row the stale cover calls empty is then skipped and the faces
-# written into it get no gradient.  Verifying the cover on the device would cost what it saves (reading every pix_to_face row),
-# so such writes are unsupported with the recall: call `forget_cover(pix_to_face)` after one, or switch the recall off
-# (`RECALL_COVERS = False` / P3D_RECALL_COVERS=0: the backward then reads every row, +0.5 ms on the bench batch).  Pinned by
-# tests/test_gpu_cover.py::test_writes_the_version_counter_cannot_see.
+# Writes that bypass the version counter (`pix_to_face.data[...] = x`, an external kernel writing through data_ptr()) are not seen
+# by that test: a row the stale cover calls empty would be skipped and the faces written into it would get no gradient.  Three
+# ways to be safe: CHECK_COVERS (P3D_CHECK=1) verifies every recalled cover on the device before it is trusted
+# (p3d_rasterize_meshes_cover_check: one read of slot 0 of every pixel and a host sync -- about half of what the cover saves) and
+# falls back to reading every row, with a warning, when the tensor holds a face the cover does not know of;
+# `forget_cover(pix_to_face)` after such a write; RECALL_COVERS = False (P3D_RECALL_COVERS=0) switches the recall off (+0.5 ms on
+# the bench batch).  Pinned by tests/test_gpu_cover.py.
 RECALL_COVERS = os.environ.get("P3D_RECALL_COVERS", "1") not in ("", "0")
-_COVERS = {}
-_COVERS_MAX = 64
+CHECK_COVERS = os.environ.get("P3D_CHECK", "0") not in ("", "0")
 COVER_RECALLS = [0, 0]  # backward calls without an explicit cover: [found the forward's, found none] (read by tests / profiles)
-
-
-def _cover_key(t):
-    return (t.device.index, t.data_ptr(), tuple(t.shape))
+COVER_CHECKS = [0, 0]   # CHECK_COVERS: [covers verified, of which stale]
+_COVER_ATTR = "_p3d_row_cover"
 
 
 def _remember_cover(p2f, cover):
-    import weakref
-
-    key = _cover_key(p2f)
-
-    def drop(_ref, key=key):
-        e = _COVERS.get(key)
-        if e is not None and e[0] is _ref:
-            del _COVERS[key]
-
-    if len(_COVERS) >= _COVERS_MAX:
-        for k in list(_COVERS)[: _COVERS_MAX // 2]:
-            _COVERS.pop(k, None)
-    _COVERS[key] = (weakref.ref(p2f, drop), p2f._version, cover)
+    setattr(p2f, _COVER_ATTR, (cover, p2f._version))
 
 
 def forget_cover(pix_to_face):
-    """Drop the remembered row cover of a pix_to_face tensor (after writing into it behind autograd's back: see above)."""
-    _COVERS.pop(_cover_key(pix_to_face), None)
+    """Drop the row cover that rides on a pix_to_face tensor (after writing into it behind autograd's back: see above)."""
+    if hasattr(pix_to_face, _COVER_ATTR):
+        delattr(pix_to_face, _COVER_ATTR)
+
+
+def cover_is_current(p2f, cover):
+    """CHECK_COVERS: True unless `p2f` holds a face in a 16-pixel row segment that `cover` calls empty (device check + host sync)."""
+    N, H, W, K = p2f.shape
+    lib = _lib.load()
+    with torch.cuda.device(p2f.device):
+        stale = torch.empty((1,), dtype=torch.int32, device=p2f.device)
+        rc = lib.p3d_rasterize_meshes_cover_check(_ptr(p2f), _ptr(cover), N, H, W, K, _ptr(stale), _stream(p2f.device))
+        _lib.check(rc, "rasterize_meshes_cover_check")
+        bad = bool(int(stale.item()))
+    COVER_CHECKS[0] += 1
+    COVER_CHECKS[1] += int(bad)
+    return not bad
+
+
+def checked_cover(p2f, cover):
+    """For the autograd nodes that carry their cover themselves (pytorch3d_amd/rasterize_meshes.py): `cover`, or None when CHECK_COVERS
+    finds it stale."""
+    if cover is None or not CHECK_COVERS or torch.cuda.is_current_stream_capturing() or cover_is_current(p2f, cover):
+        return cover
+    import warnings
+
+    warnings.warn("pytorch3d_amd: pix_to_face holds faces its forward's row cover does not know of (written through .data or by "
+                  "another kernel since the forward?); the backward reads every row instead", RuntimeWarning)
+    return None
 
 
 def _recall_cover(p2f):
-    e = _COVERS.get(_cover_key(p2f)) if RECALL_COVERS and p2f.dtype == torch.int64 and p2f.is_contiguous() else None
-    alive = e[0]() if e is not None else None
-    if alive is None or p2f._version != e[1] or alive._version != e[1]:
+    e = getattr(p2f, _COVER_ATTR, None) if RECALL_COVERS and p2f.dtype == torch.int64 and p2f.is_contiguous() and p2f.dim() == 4 else None
+    ok = e is not None and p2f._version == e[1] and e[0].device == p2f.device and \
+        tuple(e[0].shape) == (p2f.shape[0], (p2f.shape[1] + 15) // 16, (p2f.shape[2] + 15) // 16)
+    if ok and CHECK_COVERS and not torch.cuda.is_current_stream_capturing() and not cover_is_current(p2f, e[0]):
+        import warnings
+
+        warnings.warn("pytorch3d_amd: pix_to_face holds faces its forward's row cover does not know of (written through .data or by "
+                      "another kernel since the forward?); the backward reads every row instead", RuntimeWarning)
+        forget_cover(p2f)
+        ok = False
+    if not ok:
         COVER_RECALLS[1] += 1
         return None
     COVER_RECALLS[0] += 1
-    return e[2]
+    return e[0]
 
 
 def _rasterize_meshes_covered(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, image_size,
@@ -318,7 +343,7 @@ def _rasterize_meshes_covered(face_verts, mesh_to_face_first_idx, num_faces_per_
         # (the naive launch needs no workspace; with the CUDA tie order it takes one for the lane masks of the marked pixels --
         # without it the replay finds its pixels by reading a pix_to_face entry of every pixel)
         marks = N * ((H + 7) // 8) * ((W + 7) // 8) * 8 + 1024 if CUDA_TIE_ORDER else 0
-        ws, need, need_at = _mesh_workspace(lib, F, N, H, W, bin_size, M, dev, extra=marks) if binned else (_workspace(marks, dev), None, 0)
+        ws, need, need_at, entries = _mesh_workspace(lib, F, N, H, W, bin_size, M, dev, extra=marks) if binned else (_workspace(marks, dev), None, 0, None)
         cover = torch.empty((N, (H + 15) // 16, (W + 15) // 16), dtype=torch.int32, device=dev) if want_cover else None
         entry = lib.p3d_rasterize_meshes_cuda_order if CUDA_TIE_ORDER else lib.p3d_rasterize_meshes_with_cover
         rc = entry(
@@ -328,7 +353,7 @@ def _rasterize_meshes_covered(face_verts, mesh_to_face_first_idx, num_faces_per_
             _stream(dev))
         _lib.check(rc, "rasterize_meshes")
         if need is not None:
-            need.report_later(ws, need_at, WORKSPACE_STATS["last_entries"])
+            need.report_later(ws, need_at, entries)
     return out, cover
 
 
@@ -479,13 +504,13 @@ def rasterize_points(points, cloud_to_packed_first_idx, num_points_per_cloud, im
         out = _point_outputs(N, H, W, K, dev)
         if out[0].numel() == 0:
             return out
-        ws, need, need_at = _mesh_workspace(lib, P, N, H, W, bin_size, M, dev, "points") if binned else (_workspace(0, dev), None, 0)
+        ws, need, need_at, entries = _mesh_workspace(lib, P, N, H, W, bin_size, M, dev, "points") if binned else (_workspace(0, dev), None, 0, None)
         entry = lib.p3d_rasterize_points_cuda_order if CUDA_TIE_ORDER else lib.p3d_rasterize_points
         rc = entry(_ptr(pts), _ptr(first), _ptr(count), _ptr(rad), P, N, H, W, K, bin_size if binned else 0, M if binned else 0,
                    _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(ws), ws.numel(), _stream(dev))
         _lib.check(rc, "rasterize_points")
         if need is not None:
-            need.report_later(ws, need_at, WORKSPACE_STATS["last_entries"])
+            need.report_later(ws, need_at, entries)
     return out
 
 

@@ -39,6 +39,7 @@ _SIGNATURES = {
     "p3d_rasterize_meshes_backward_verts": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int,
                                                     c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
     "p3d_rasterize_meshes_cover_bytes": (c_size, [c_int, c_int, c_int]),
+    "p3d_rasterize_meshes_cover_check": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
     "p3d_rasterize_meshes_with_cover": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_f32, c_int, c_int,
                                                 c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size,
                                                 c_ptr]),

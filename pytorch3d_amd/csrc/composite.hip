@@ -481,9 +481,17 @@ int launch_fwd(const CompArgs& a, unsigned grid, hipStream_t s) {
   return launch_status();
 }
 
-// The two feature layouts the kernels address (include/p3d_amd.h): (P, 1) planes or (1, C) rows.
-bool feature_strides_ok(const int64_t st[2], int C, int64_t P) {
-  return (st[0] == P && st[1] == 1) || (st[0] == 1 && st[1] == C) || C <= 1 || P <= 1;
+// The two feature layouts the kernels address (include/p3d_amd.h): (P, 1) planes or (1, C) rows.  A dimension of size 1 may
+// carry any stride -- but the kernels of K <= 16 read the layout off (fs0, fs1) themselves, so what is accepted is NORMALISED
+// to one of the two before the launch: a single channel (its P values contiguous) is one plane, a single point (its C values
+// contiguous) one row.  Anything else is refused, whatever K.
+bool feature_strides_ok(const int64_t st[2], int C, int64_t P, int64_t out[2]) {
+  const bool planar = (st[0] == P || C <= 1) && (st[1] == 1 || P <= 1);
+  const bool rows = (st[0] == 1 || C <= 1) && (st[1] == C || P <= 1);
+  if (!planar && !rows) return false;
+  out[0] = planar ? P : 1;
+  out[1] = planar ? 1 : C;
+  return true;
 }
 
 template <int MODE>
@@ -531,12 +539,16 @@ P3D_API int p3d_composite_forward_strided(int mode, const float* features, const
   const int64_t nout = (int64_t)N * C * H * W;
   if (nout == 0) return P3D_OK;
   if (!result || !alphas_strides || !idx_strides || !feature_strides) return P3D_ERR_INVALID_ARG;
-  if (!feature_strides_ok(feature_strides, C, P)) return P3D_ERR_INVALID_ARG;
+  int64_t fst[2];
+  if (!feature_strides_ok(feature_strides, C, P, fst)) return P3D_ERR_INVALID_ARG;
   if (K > 0 && (!alphas || !points_idx || !features)) return P3D_ERR_INVALID_ARG;
+  if (P == 0) {  // no point: every slot is empty and every compositor returns zeros (the kernels' empty slots gather point 0)
+    return hipMemsetAsync(result, 0, (size_t)nout * sizeof(float), (hipStream_t)stream) == hipSuccess ? P3D_OK : P3D_ERR_LAUNCH;
+  }
   CompArgs a{};
   a.features = features;
-  a.fs0 = feature_strides[0];
-  a.fs1 = feature_strides[1];
+  a.fs0 = fst[0];
+  a.fs1 = fst[1];
   a.alphas = alphas;
   a.idx = points_idx;
   a.N = N;
@@ -573,7 +585,8 @@ P3D_API int p3d_composite_backward_strided(int mode, const float* grad_outputs, 
                                            const int64_t grad_feature_strides[2], float* grad_alphas, p3d_stream_t stream) {
   if (mode < 0 || mode > 2 || N < 0 || C < 0 || K < 0 || H < 0 || W < 0 || P < 0) return P3D_ERR_INVALID_ARG;
   if (!feature_strides || !grad_feature_strides) return P3D_ERR_INVALID_ARG;
-  if (!feature_strides_ok(feature_strides, C, P) || !feature_strides_ok(grad_feature_strides, C, P)) return P3D_ERR_INVALID_ARG;
+  int64_t fst[2], gst[2];
+  if (!feature_strides_ok(feature_strides, C, P, fst) || !feature_strides_ok(grad_feature_strides, C, P, gst)) return P3D_ERR_INVALID_ARG;
   // grad_features: C * P floats of ONE allocation in either layout ((P, 1) planes or (1, C) rows): zeroed as a block
   hipStream_t s = (hipStream_t)stream;
   if ((int64_t)C * P > 0) {
@@ -588,12 +601,16 @@ P3D_API int p3d_composite_backward_strided(int mode, const float* grad_outputs, 
     return P3D_OK;
   }
   if (!grad_outputs || !features) return P3D_ERR_INVALID_ARG;
+  if (P == 0) {  // no point: every slot is empty, nothing flows to the alphas
+    if (hipMemsetAsync(grad_alphas, 0, (size_t)nga * sizeof(float), s) != hipSuccess) return P3D_ERR_LAUNCH;
+    return P3D_OK;
+  }
   CompArgs a{};
   a.features = features;
-  a.fs0 = feature_strides[0];
-  a.fs1 = feature_strides[1];
-  a.gs0 = grad_feature_strides[0];
-  a.gs1 = grad_feature_strides[1];
+  a.fs0 = fst[0];
+  a.fs1 = fst[1];
+  a.gs0 = gst[0];
+  a.gs1 = gst[1];
   a.alphas = alphas;
   a.idx = points_idx;
   a.grad_out = grad_outputs;

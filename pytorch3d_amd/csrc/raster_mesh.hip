@@ -1663,7 +1663,12 @@ static int raster_meshes_impl(const float* face_verts, const int64_t* mesh_first
   // (p3d_rasterize_meshes_workspace_bytes counts them in); the binning carves the rest as ever
   TieMarks marks;
   const size_t full_workspace_bytes = workspace_bytes;
-  if (cuda_order && any_output && workspace != nullptr && N > 0 && H > 0 && W > 0) {
+  // The words are indexed by (sy0 >> 3, sx0 >> 3) and decoded as pixels (8 sy + L / 8, 8 sx + L % 8): sub-tile origins must be
+  // multiples of 8.  They are whenever a bin is a whole number of 8 x 8 sub-tiles -- not with a caller's bin_size of 9..15
+  // (or any other non-multiple below a tile), which make_internal_geom honours: sub-tiles of neighbouring bins then share a
+  // word and the last store wins.  Those launches mark in place only.
+  const bool words_ok = bin_size <= 0 || max_faces_per_bin <= 0 || make_internal_geom(H > 0 ? H : 1, W > 0 ? W : 1, bin_size).bin_size % 8 == 0;
+  if (cuda_order && words_ok && any_output && workspace != nullptr && N > 0 && H > 0 && W > 0) {
     const size_t mb = tie_marks_bytes(N, H, W);
     if (workspace_bytes >= mb + 256) {
       const size_t at = (workspace_bytes - mb) & ~(size_t)255;

@@ -294,6 +294,21 @@ __global__ __launch_bounds__(256) void area_list_kernel(const int* __restrict__ 
   if (on) list[base + mask_rank(m)] = i;
 }
 
+// p3d_rasterize_meshes_cover_check: one thread per 16-pixel row segment; raises the flag when the segment holds a face
+// (pix_to_face[n, y, x, 0] >= 0: entries are sorted, slot 0 is the first to fill) that the cover does not know of.
+__global__ __launch_bounds__(256) void cover_check_kernel(const int64_t* __restrict__ p2f, const int* __restrict__ cover, int N, int H, int W,
+                                                          int K, int CY, int CX, int* __restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)N * H * CX) return;
+  const int cx = (int)(i % CX);
+  const int64_t t = i / CX;
+  const int y = (int)(t % H), n = (int)(t / H);
+  bool any = false;
+  for (int x = cx * 16; x < min(W, cx * 16 + 16); ++x) any |= p2f[(((int64_t)n * H + y) * W + x) * K] >= 0;
+  const int word = cover[((int64_t)n * CY + (y >> 4)) * CX + cx];
+  if (any && !((word >> (y & 15)) & 1)) atomicOr(flag, 1);
+}
+
 template <int KT>
 struct RowsCfg {
   static constexpr int kWaves = KT >= 16 ? 5 : 6;     // waves per SIMD the kernel is built for (512 / kWaves registers)
@@ -604,4 +619,20 @@ P3D_API int p3d_rasterize_meshes_backward_verts(const float* face_verts, const i
                                                 float* grad_verts, p3d_stream_t stream) {
   return p3d_rasterize_meshes_backward_verts_with_cover(face_verts, faces, p2f, grad_zbuf, grad_bary, grad_dists, nullptr, F, V,
                                                         N, H, W, K, persp, clip, grad_verts, nullptr, 0, stream);
+}
+
+P3D_API int p3d_rasterize_meshes_cover_check(const int64_t* p2f, const int32_t* cover, int N, int H, int W, int K, int32_t* stale,
+                                             p3d_stream_t stream) {
+  if (N < 0 || H < 0 || W < 0 || K < 0 || !stale) return P3D_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(stale, 0, sizeof(int32_t), s) != hipSuccess) return P3D_ERR_LAUNCH;
+  const int CY = (H + 15) / 16, CX = (W + 15) / 16;
+  const int64_t items = (int64_t)N * H * CX;
+  if (items == 0 || K == 0) return P3D_OK;
+  if (!p2f || !cover) return P3D_ERR_INVALID_ARG;
+  const int64_t blocks = ceil_div(items, 256);
+  if (blocks > 0x7fffffffll) return P3D_ERR_INVALID_ARG;
+  LaunchScope ls("mesh_cover_check", s);
+  cover_check_kernel<<<(unsigned)blocks, 256, 0, s>>>(p2f, reinterpret_cast<const int*>(cover), N, H, W, K, CY, CX, reinterpret_cast<int*>(stale));
+  return launch_status();
 }

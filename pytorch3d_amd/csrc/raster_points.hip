@@ -785,7 +785,10 @@ __global__ __launch_bounds__(kStage, 2) void point_tile_sorted_kernel(PointArgs 
     if (keep) {
       const unsigned zb = __float_as_uint(pz + 0.0f);  // +0.0: a zero depth's key orders by its bits
       key = ((unsigned long long)zb << 32) | (unsigned)pid;
-      bk = sorted_list ? tile_bucket_of(zb, zlo, scale) : 0;
+      // the bucket the pre-sort (bucket_sort_tile) gave this point: depths that are not finite non-negative numbers -- a NaN passes
+      // `!(pz < 0)` above, as in the reference -- sit in its last bucket, and the exact order below counts inversions inside a bucket:
+      // with another bucket number here two entries could take one position
+      bk = sorted_list ? ((pz >= 0.0f && pz < INFINITY) ? tile_bucket_of(zb, zlo, scale) : kStage - 1) : 0;
       s_pt[pos] = make_float4(px, py, pz + 0.0f, r);
       s_key[pos] = key;
       s_bk[pos] = bk;

@@ -102,19 +102,6 @@ struct WaveTable {
 
   // out[f * NV + j] += vals[slot][j] for every occupied slot; empties the table.
   __device__ __forceinline__ void flush(float* __restrict__ out, int lane) {
-#ifdef P3D_FLUSH_LANE_PER_ROW  // the flush of rounds 2-4, kept as the A/B switch of profiles/r05/call22.sh
-    for (int s = lane; s < SLOTS; s += 64) {
-      const int f = keys[s];
-      if (f != kEmptyKey) {
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-          float* o = dest(out, f, j);
-          if (o) unsafeAtomicAdd(o, vals[s * kStride + j]);
-        }
-        keys[s] = kEmptyKey;
-      }
-    }
-#else
     // The NV values of an entry leave from ADJACENT lanes (lane = entry * NV + value).  Global float atomics are served per
     // REQUEST, not per lane (profiles/microbench/global_atomic_mi355x.txt: a lane per row 20 G lane-atomics/s whatever NV; the
     // values of a row in adjacent lanes 56 / 84 / 126 G for NV = 3 / 4 / 9), and until round 5 instruction j carried value j of
@@ -165,7 +152,6 @@ struct WaveTable {
       }
       if (occ) keys[s] = kEmptyKey;
     }
-#endif
     used = 0;
   }
 

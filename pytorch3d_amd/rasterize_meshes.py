@@ -180,6 +180,7 @@ class _RasterizeFaceVerts(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_pix_to_face, grad_zbuf, grad_barycentric_coords, grad_dists):
         face_verts, pix_to_face, cover = ctx.saved_tensors
+        cover = _C.checked_cover(pix_to_face, cover)  # (P3D_CHECK=1: verified on the device before it is trusted)
         if grad_zbuf is None and grad_barycentric_coords is None and grad_dists is None:
             return (None,) * 12
         if grad_zbuf is None:
@@ -229,6 +230,8 @@ class _RasterizeMeshVerts(torch.autograd.Function):
         from . import _lib
 
         face_verts, faces, pix_to_face, cover = ctx.saved_tensors
+
+        cover = _C.checked_cover(pix_to_face, cover)  # (P3D_CHECK=1: verified on the device before it is trusted)
         if grad_zbuf is None and grad_barycentric_coords is None and grad_dists is None:
             return (None,) * 13
         _refuse_when_deterministic()
@@ -438,6 +441,7 @@ class _RasterizeMeshWorld(torch.autograd.Function):
         from . import _lib
 
         verts, faces, vert_first, mats, face_verts, pix_to_face, cover = ctx.saved_tensors
+        cover = _C.checked_cover(pix_to_face, cover)  # (P3D_CHECK=1: verified on the device before it is trusted)
         if grad_zbuf is None and grad_bary is None and grad_dists is None:
             return (None,) * 8
         _refuse_when_deterministic()

@@ -66,6 +66,11 @@ def gather_batch(local: torch.Tensor, sizes: Sequence[int], group=None, dst=None
     per link, instead of circulating all shards around a ring.  Ranks may own different numbers of jobs: shards are
     padded to max(sizes) for the collective (RCCL needs equal shapes) and trimmed after.  Not differentiable (final
     gather)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        # one process, no process group (BASELINE configs[4] on one GPU): the batch is the shard
+        if len(sizes) != 1:
+            raise RuntimeError("gather_batch without a process group takes exactly one shard; got sizes=%r" % (list(sizes),))
+        return local[: int(sizes[0])]
     world = dist.get_world_size(group)
     m = max(int(s) for s in sizes) if len(sizes) else 0
     tail = tuple(local.shape[1:])

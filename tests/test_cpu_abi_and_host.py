@@ -357,8 +357,11 @@ def test_bench_jobs_partition_and_fast_path_on_the_cow():
         got = sorted(s for r in range(world) for s in bench.sub_batches_of_rank(512, 64, r, world))
         assert got == list(range(8))
         assert all(len(bench.sub_batches_of_rank(512, 64, r, world)) == 8 // world for r in range(world))
+    # an uneven deal (round 6): 8 sub-batches over 3 ranks = 3 + 3 + 2, every sub-batch exactly once; rank 0 never has fewer than another
+    deal = [bench.sub_batches_of_rank(512, 64, r, 3) for r in range(3)]
+    assert [len(d) for d in deal] == [3, 3, 2] and sorted(s for d in deal for s in d) == list(range(8))
     with pytest.raises(SystemExit):
-        bench.sub_batches_of_rank(512, 64, 0, 3)
+        bench.sub_batches_of_rank(512, 64, 0, 9)  # a rank would have nothing to run
     with pytest.raises(SystemExit):
         bench.sub_batches_of_rank(500, 64, 0, 1)
 
@@ -467,8 +470,8 @@ def test_short_workspace_sizing_follows_a_running_maximum_and_reports_while_tigh
 
 def test_bench_jobs_mode_deals_every_sub_batch_to_exactly_one_rank():
     """BASELINE configs[4]: 512 jobs = 8 sub-batches of 64 (generator seeds 0..7); on G in
-    {1, 2, 4, 8} GPUs rank r runs sub-batches r, r + G, ...: every seed exactly once, the same number per rank (what the
-    padded gather of `own` sizes relies on), and a G that does not divide is refused rather than silently unbalanced."""
+    {1, 2, 4, 8} GPUs rank r runs sub-batches r, r + G, ...: every seed exactly once, the same number per rank.  A G that does
+    not divide deals unevenly (round 6: the gather pads the shards to the largest, bench.py: `own`); a G with an idle rank is refused."""
     import importlib.util
 
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(U.ROOT, "bench.py"))
@@ -479,8 +482,10 @@ def test_bench_jobs_mode_deals_every_sub_batch_to_exactly_one_rank():
         assert sorted(s for d in dealt for s in d) == list(range(8))
         assert len({len(d) for d in dealt}) == 1 and len(dealt[0]) == 8 // world
         assert all(d == sorted(d) and d[0] == r for r, d in enumerate(dealt))
-    for world in (3, 5, 16):
-        with pytest.raises(SystemExit):
-            bench.sub_batches_of_rank(512, 64, 0, world)
+    for world in (3, 5):
+        dealt = [bench.sub_batches_of_rank(512, 64, r, world) for r in range(world)]
+        assert sorted(s for d in dealt for s in d) == list(range(8)) and max(len(d) for d in dealt) == len(dealt[0]) == -(-8 // world)
+    with pytest.raises(SystemExit):
+        bench.sub_batches_of_rank(512, 64, 0, 16)
     with pytest.raises(SystemExit):
         bench.sub_batches_of_rank(500, 64, 0, 2)

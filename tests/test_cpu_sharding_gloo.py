@@ -106,3 +106,25 @@ def test_shard_and_rebase():
     assert sharding.rebase_indices(idx, lo).tolist() == [-1, 4, 10]
     lo, hi, f, c = sharding.shard_packed(first, cnt, 2, 2)
     assert (lo, hi) == (0, 0) and f.numel() == 0
+
+
+def test_bench_dry_run_maps_ranks_to_devices_without_a_gpu():
+    """`python bench.py --gpus 4 --dry-run` (bench.py: dry_run): the launcher, the RANK / LOCAL_RANK -> device mapping and the gloo
+    rendezvous of an N-GPU run, with no RCCL and no kernel -- runs in this container, where no device is visible: the line must
+    list every rank and say that its device does not exist."""
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--dry-run"], capture_output=True, text=True, timeout=240, cwd=root, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-1000:]
+    j = json.loads(lines[0])
+    assert j["dry_run"] is True and j["n_gpus"] == 4
+    assert [m["rank"] for m in j["mapping"]] == [0, 1, 2, 3] and [m["device"] for m in j["mapping"]] == [f"cuda:{i}" for i in range(4)]
+    visible = j["mapping"][0]["devices_visible"]
+    assert len([p for p in j["problems"] if "has no device" in p]) == max(0, 4 - visible) and j["ok"] == (not j["problems"])
