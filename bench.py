@@ -310,6 +310,18 @@ def other_configs(lib, _lib, device):
             replay_ms = wall_of(graph.replay)
             graph.replay()
             torch.cuda.synchronize()
+            # the same operator through the two flavours of the boundary: the ctypes module (default) and the compiled pybind module
+            # (pytorch3d_amd/csrc/bind.cpp) -- same five launches, different host side
+            flav = {"ctypes_call_ms": round(eager_ms, 4)}
+            try:
+                from pytorch3d_amd import build_bind
+
+                pyb = build_bind.load()
+                same = all(torch.equal(a, b) for a, b in zip(pyb.rasterize_meshes(*cargs), ref))
+                flav.update(pybind_call_ms=round(wall_of(lambda: pyb.rasterize_meshes(*cargs)), 4), identical_outputs=bool(same))
+            except Exception as e:
+                flav["pybind"] = "not available: %r" % (e,)
+            out["config2_cow_256_k8_fwd"]["boundary_flavours"] = flav
             out["config2_cow_256_k8_fwd"]["hip_graph"] = {
                 "eager_C_call_ms": round(eager_ms, 4), "graph_replay_ms": round(replay_ms, 4),
                 "identical_outputs": bool(all(torch.equal(a, b) for a, b in zip(gout, ref))),

@@ -43,11 +43,23 @@ import types
 from . import _C as _ours
 
 
-def make_module():
+def make_module(flavour="ctypes"):
+    """flavour: "ctypes" -- the operators of pytorch3d_amd/_C.py (ctypes over libp3d_amd.so; row-cover recall, short workspaces,
+    CUDA tie order; no compiler needed) -- or "pybind": the same operator set compiled as a torch extension over the same C ABI
+    (pytorch3d_amd/csrc/bind.cpp, built by pytorch3d_amd/build_bind.py: INTEGRATION.md section B, the reference's allocation
+    pattern and nothing besides)."""
+    if flavour not in ("ctypes", "pybind"):
+        raise ValueError("flavour must be 'ctypes' or 'pybind'")
     mod = types.ModuleType("pytorch3d._C")
-    mod.__doc__ = "pytorch3d._C provided by pytorch3d_amd (MI355X rasterization hot path)"
+    mod.__doc__ = "pytorch3d._C provided by pytorch3d_amd (MI355X rasterization hot path), %s flavour" % flavour
+    mod.__p3d_amd_flavour__ = flavour
+    src = _ours
+    if flavour == "pybind":
+        from . import build_bind
+
+        src = build_bind.load()
     for name in _ours.HOT_PATH_EXPORTS:
-        setattr(mod, name, getattr(_ours, name))
+        setattr(mod, name, getattr(src, name))
     for name in ("EPS", "MAX_FLOAT", "MAX_INT", "MAX_UINT", "MAX_USHORT", "PULSAR_MAX_GRAD_SPHERES"):
         setattr(mod, name, getattr(_ours, name))
     # four small operators the reference's mesh classes call on the way to the renderer (face normals / areas, packed <->
@@ -71,15 +83,15 @@ def make_module():
     return mod
 
 
-def install(reference_root=None, patch_python=False):
-    """Register the shim (idempotent).  Returns the module object.  patch_python: see the module docstring."""
+def install(reference_root=None, patch_python=False, flavour="ctypes"):
+    """Register the shim (idempotent).  Returns the module object.  patch_python: see the module docstring; flavour: make_module."""
     if reference_root is not None and reference_root not in sys.path:
         sys.path.insert(0, reference_root)
     existing = sys.modules.get("pytorch3d._C")
-    if existing is not None and getattr(existing, "__p3d_amd__", False):
+    if existing is not None and getattr(existing, "__p3d_amd__", False) and getattr(existing, "__p3d_amd_flavour__", "ctypes") == flavour:
         mod = existing
     else:
-        mod = make_module()
+        mod = make_module(flavour)
         mod.__p3d_amd__ = True
         sys.modules["pytorch3d._C"] = mod
         pkg = sys.modules.get("pytorch3d")

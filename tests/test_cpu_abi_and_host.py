@@ -489,3 +489,20 @@ def test_bench_jobs_mode_deals_every_sub_batch_to_exactly_one_rank():
         bench.sub_batches_of_rank(512, 64, 0, 16)
     with pytest.raises(SystemExit):
         bench.sub_batches_of_rank(500, 64, 0, 2)
+
+
+def test_pybind_flavour_builds_and_exports_the_operator_set():
+    """pytorch3d_amd/csrc/bind.cpp (INTEGRATION.md section B compiled): the torch extension builds against include/p3d_amd.h, links
+    libp3d_amd.so and exports every hot-path operator of `pytorch3d._C` under the reference's names (no compute call without a GPU)."""
+    from pytorch3d_amd import _C, build_bind
+
+    try:
+        mod = build_bind.load()
+    except Exception as e:  # noqa: BLE001
+        pytest.skip("no host toolchain for the pybind flavour here: %r" % (e,))
+    missing = [n for n in _C.HOT_PATH_EXPORTS if not callable(getattr(mod, n, None))]
+    assert not missing, missing
+    assert mod.MAX_INT == 2147483647 and mod.__p3d_amd_flavour__ == "pybind"
+    with pytest.raises(RuntimeError, match="GPU tensor"):  # CPU tensors are refused, as in the ctypes flavour
+        z = torch.zeros(1, dtype=torch.int64)
+        mod.rasterize_meshes(torch.rand(4, 3, 3), z, z + 4, torch.full((4,), -1, dtype=torch.int64), (8, 8), 0.0, 2, 0, 0, False, False, False)

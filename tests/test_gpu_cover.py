@@ -260,17 +260,16 @@ def test_writes_the_version_counter_cannot_see():
     import importlib
 
     node = importlib.import_module("pytorch3d_amd.rasterize_meshes")._RasterizeFaceVerts
-    x_px = x
-    x = fv.clone().requires_grad_(True)
-    o = node.apply(x, first, cnt, nbr, size, 1e-3, K, 32, 5000, True, True, False)
-    o[0].data[n, y, x_px, 0] = 0
+    xv = fv.clone().requires_grad_(True)
+    o = node.apply(xv, first, cnt, nbr, size, 1e-3, K, 32, 5000, True, True, False)
+    o[0].data[n, y, x, 0] = 0
     _C.CHECK_COVERS = True
     try:
         with pytest.warns(RuntimeWarning, match="row cover does not know of"):
             torch.autograd.backward([o[1], o[2], o[3]], [gz, gb, gd])
     finally:
         _C.CHECK_COVERS = saved
-    assert float(((x.grad - truth).abs() / scale).max()) < 5e-3
+    assert float(((xv.grad - truth).abs() / scale).max()) < 5e-3
     # (3) the same write through the ordinary API bumps the version counter: the cover is dropped by itself
     out3 = _C.rasterize_meshes(fv, first, cnt, nbr, size, 1e-3, K, 32, 5000, True, True, False)
     out3[0][n, y, x, 0] = 0
