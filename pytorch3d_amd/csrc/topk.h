@@ -18,6 +18,9 @@
 #include <stdint.h>
 
 #include "p3d_geom.h"  // P3D_HDM
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "topk_insert_asm.h"
+#endif
 
 // steps per segment of the exact-K insertion network (TopKPairs::insert_segments)
 #ifndef P3D_SEG_LEN
@@ -428,6 +431,20 @@ struct TopKPairs {
     const u32x2 cpa = NP == 4 ? mk_pair(f32_bits(cpl[0]), f32_bits(cpl[1 % NPS])) : czi;
     const u32x2 cpb = NP == 4 ? mk_pair(f32_bits(cpl[2 % NPS]), f32_bits(cpl[3 % NPS])) : czi;
 #if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (KEY64 && NP == 4 && (KT == 8 || KT == 4 || KT == 2)) {
+      // the exact-K queues of the perspective + clip kernels: the whole network as one asm statement, its lane masks in the exec
+      // register (topk_insert_asm.h)
+      if (__builtin_constant_p(K) && K == KT) {
+        const unsigned long long ek = ((unsigned long long)f32_bits(INFINITY) << 32) | (unsigned)kEmptyIdx;  // the key of an empty entry
+        unsigned long long sv;
+        if constexpr (KT == 8) P3D_TOPK_INSERT_ASM_8(zi, pa, pb, czi, cpa, cpb, ek, sv);
+        if constexpr (KT == 4) P3D_TOPK_INSERT_ASM_4(zi, pa, pb, czi, cpa, cpb, ek, sv);
+        if constexpr (KT == 2) P3D_TOPK_INSERT_ASM_2(zi, pa, pb, czi, cpa, cpb, ek, sv);
+        kz = zf(KT - 1);
+        ki = ix(KT - 1);
+        return;
+      }
+    }
     if constexpr (KT % 2 == 0 && KT >= 4 && KT <= 8 && KT % P3D_SEG_LEN == 0) {
       if (__builtin_constant_p(K) && K == KT) {
         insert_segments(czi, cpa, cpb, cz, cidx);
