@@ -134,8 +134,8 @@ P3D_HD f3 bary_clip(f3 b) {
   return mk3(qdiv<FAST>(w0, s), qdiv<FAST>(w1, s), qdiv<FAST>(w2, s));
 }
 
-// Squared distance from p to segment (a, b) (geometry_utils.cuh:340-352).  FAST (backward only): the distances only
-// RANK the three edges there, see tri_dist2_bwd.
+// Squared distance from p to segment (a, b) (geometry_utils.cuh:340-352).  (FAST: reciprocal estimate and float predicate; the
+// backward forms its ranking distances inline, see face_sample_bwd.)
 template <bool FAST = false>
 P3D_HD float seg_dist2(f2 p, f2 a, f2 b) {
   const float bax = b.x - a.x;
@@ -156,26 +156,6 @@ P3D_HD float seg_dist2(f2 p, f2 a, f2 b) {
   // v_cmp_f64 per edge and sample
   if (FAST) return (l2 <= 1e-8f) ? d_point : d_seg;
   return ((double)l2 <= P3D_KEPS) ? d_point : d_seg;
-}
-
-// The same distance for the backward, where it only RANKS the three edges (tri_dist2_bwd): reciprocal estimate, float
-// predicate, and mul + add fused (the forward's dists never pass through here).
-P3D_HD float seg_dist2_rank(f2 p, f2 a, f2 b) {
-#if defined(__clang__)
-#pragma clang fp contract(fast)
-#endif
-  const float bax = b.x - a.x;
-  const float bay = b.y - a.y;
-  const float l2 = bax * bax + bay * bay;
-  float t = qdiv<true>(bax * (p.x - a.x) + bay * (p.y - a.y), l2);
-  const float ex = p.x - b.x;
-  const float ey = p.y - b.y;
-  const float d_point = ex * ex + ey * ey;
-  t = sat01(t);
-  const float dx = (a.x + t * bax) - p.x;
-  const float dy = (a.y + t * bay) - p.y;
-  const float d_seg = dx * dx + dy * dy;
-  return (l2 <= 1e-8f) ? d_point : d_seg;
 }
 
 // Squared distance to the triangle boundary (geometry_utils.cuh:397-408).
@@ -527,33 +507,6 @@ P3D_HD TriGrad bary_coords_bwd(f2 p, f2 v0, f2 v1, f2 v2, f3 g) {
   return r;
 }
 
-struct PerspGrad {
-  f3 dbary;
-  float dz0, dz1, dz2;
-};
-
-P3D_HD PerspGrad bary_perspective_bwd(f3 b, float z0, float z1, float z2, f3 g) {
-#if defined(__clang__)
-#pragma clang fp contract(fast)  // gradient-only arithmetic (tolerance-gated): let mul+add fuse into FMA
-#endif
-  const float t0 = b.x * z1 * z2;
-  const float t1 = z0 * b.y * z2;
-  const float t2 = z0 * z1 * b.z;
-  const float denom = fmaxf(t0 + t1 + t2, (float)P3D_KEPS);
-  const float gd_top = -t0 * g.x - t1 * g.y - t2 * g.z;
-  const float inv_denom = qdiv<true>(1.0f, denom);
-  const float gd = gd_top * (inv_denom * inv_denom);
-  const float g0 = gd + g.x * inv_denom;
-  const float g1 = gd + g.y * inv_denom;
-  const float g2 = gd + g.z * inv_denom;
-  PerspGrad r;
-  r.dbary = mk3(g0 * z1 * z2, g1 * z0 * z2, g2 * z0 * z1);
-  r.dz0 = g1 * b.y * z2 + g2 * b.z * z1;
-  r.dz1 = g0 * b.x * z2 + g2 * b.z * z0;
-  r.dz2 = g0 * b.x * z1 + g1 * b.y * z0;
-  return r;
-}
-
 P3D_HD f3 bary_clip_bwd(f3 b, f3 g) {
 #if defined(__clang__)
 #pragma clang fp contract(fast)  // gradient-only arithmetic (tolerance-gated): let mul+add fuse into FMA
@@ -588,53 +541,6 @@ P3D_HD f3 bary_clip_bwd(f3 b, f3 g) {
   return mk3(m0 * (g.x * c0 + g.y * q1 + g.z * q2), m1 * (g.y * c1 + g.x * q0 + g.z * q2), m2 * (g.z * c2 + g.x * q0 + g.y * q1));
 }
 
-struct SegGrad {
-  f2 da, db;
-};
-
-P3D_HD SegGrad seg_dist2_bwd(f2 p, f2 a, f2 b, float g) {
-#if defined(__clang__)
-#pragma clang fp contract(fast)  // gradient-only arithmetic (tolerance-gated): let mul+add fuse into FMA
-#endif
-  const float bax = b.x - a.x;
-  const float bay = b.y - a.y;
-  const float bot = bax * bax + bay * bay;
-  const float top = bax * (p.x - a.x) + bay * (p.y - a.y);
-  const float tt = sat01(qdiv<true>(top, bot));
-  const float dx = ((1.0f - tt) * a.x + tt * b.x) - p.x;
-  const float dy = ((1.0f - tt) * a.y + tt * b.y) - p.y;
-  const float sa = g * (1.0f - tt) * 2.0f;
-  const float sb = g * tt * 2.0f;
-  SegGrad r;
-  r.da = mk2(sa * dx, sa * dy);
-  r.db = mk2(sb * dx, sb * dy);
-  return r;
-}
-
-// Gradient of tri_dist2 wrt the three vertices: only the closest edge gets one,
-// ties resolved e01, e02, e12 (geometry_utils.cuh:441-459).
-P3D_HD TriGrad tri_dist2_bwd(f2 p, f2 v0, f2 v1, f2 v2, float g) {
-  // The distances only choose the edge.  With the reciprocal instead of the IEEE division (10 instructions each) two
-  // edges that tie to within an ulp may swap: they tie where the nearest point is their common vertex, and there both
-  // give that vertex the same gradient and the other end point none (t saturates at 0 or 1).
-  const float e01 = seg_dist2_rank(p, v0, v1);
-  const float e02 = seg_dist2_rank(p, v0, v2);
-  const float e12 = seg_dist2_rank(p, v1, v2);
-  // Which edge is closest (ties: e01, then e02, then e12); 3 = none (NaN distances).  The three candidate
-  // branches of the reference are folded into ONE evaluation on selected endpoints: lanes of a wave pick
-  // different edges, and divergent branches would run the edge gradient three times.
-  const int sel = ((e01 <= e02) & (e01 <= e12)) ? 0 : (((e02 <= e01) & (e02 <= e12)) ? 1 : (((e12 <= e01) & (e12 <= e02)) ? 2 : 3));
-  const f2 ea = sel == 2 ? v1 : v0;
-  const f2 eb = sel == 0 ? v1 : v2;
-  const SegGrad s = seg_dist2_bwd(p, ea, eb, sel == 3 ? 0.0f : g);
-  const f2 zero = mk2(0.0f, 0.0f);
-  TriGrad r;
-  r.d0 = sel <= 1 ? s.da : zero;
-  r.d1 = sel == 0 ? s.db : (sel == 2 ? s.da : zero);
-  r.d2 = (sel == 1 || sel == 2) ? s.db : zero;
-  return r;
-}
-
 // Nine partials of one (pixel, k) sample wrt its face's vertices
 // (rasterize_meshes.cu:486-561).  The CUDA variant feeds the *pre-perspective*
 // barycentrics to the clip backward (rasterize_meshes.cu:528); the CPU variant
@@ -650,42 +556,92 @@ P3D_HD FaceGrad face_sample_bwd(f3 v0, f3 v1, f3 v2, f2 p, float g_zbuf, f3 g_ba
 #if defined(__clang__)
 #pragma clang fp contract(fast)  // gradient-only arithmetic (tolerance-gated): let mul+add fuse into FMA
 #endif
+  // One fused function (round 6) instead of a forward recompute followed by the reference's five backward routines called one
+  // after the other: each shared quantity -- the perspective numerators and their denominator, a segment's parameter and
+  // closest point -- is formed ONCE.  The backward kernel follows its instruction count, and the separate routines rebuilt these
+  // with other roundings (fused or not), which the compiler cannot merge.  Formulas: geometry_utils.cuh:54-64 (edge function),
+  // 101-161 (barycentrics), 200-228 (perspective), 273-329 (clip), 365-385 / 421-462 (point-segment / point-triangle distance).
   const f2 a = mk2(v0.x, v0.y);
   const f2 b = mk2(v1.x, v1.y);
   const f2 c = mk2(v2.x, v2.y);
-  // forward recompute: only signs of bw / bp decide anything here (inside test, clip masks), and the
-  // sign of a quotient does not depend on how the division rounds
+  const float z0 = v0.z, z1 = v1.z, z2 = v2.z;
+  // ---- forward recompute: only signs of bw / bp decide anything here (inside test, clip masks), and the sign of a quotient does
+  // not depend on how the division rounds
   const f3 bw = bary_coords<true>(p, a, b, c);
-  const f3 bp = perspective_correct ? bary_perspective<true>(bw, v0.z, v1.z, v2.z) : bw;
+  f3 bp = bw;
+  float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, inv_denom = 0.0f;
+  if (perspective_correct) {
+    t0 = bw.x * z1 * z2;
+    t1 = z0 * bw.y * z2;
+    t2 = z0 * z1 * bw.z;
+    const float denom = fmaxf(t0 + t1 + t2, (float)P3D_KEPS);
+    inv_denom = qdiv<true>(1.0f, denom);
+    bp = mk3(t0 * inv_denom, t1 * inv_denom, t2 * inv_denom);
+  }
   const f3 bc = clip_bary ? bary_clip<true>(bp) : bp;
   const bool inside = (bp.x > 0.0f) & (bp.y > 0.0f) & (bp.z > 0.0f);
-  const float sign = inside ? -1.0f : 1.0f;
+  const float gd = inside ? -g_dist : g_dist;
 
-  const TriGrad dd = tri_dist2_bwd(p, a, b, c, sign * g_dist);
-
-  f3 gb = mk3(g_bary.x + g_zbuf * v0.z, g_bary.y + g_zbuf * v1.z, g_bary.z + g_zbuf * v2.z);
-  if (clip_bary) {
-    gb = bary_clip_bwd(clip_bwd_on_corrected ? bp : bw, gb);
+  // ---- squared distance to the boundary: only the closest edge gets a gradient, ties resolved e01, e02, e12
+  // (geometry_utils.cuh:441-459).  Per edge (s, e): t = clamp(<e - s, p - s> / |e - s|^2), q = s + t (e - s) - p; the distances only
+  // RANK the edges (reciprocal estimate, float predicate for the degenerate edge: 1e-8 lies between the floats 9.99999994e-9 and
+  // 1.00000008e-8); two edges that tie to within an ulp may swap: they tie where the nearest point is their common vertex, and
+  // there both give that vertex the same gradient and the other end point none (t saturates at 0 or 1).
+  float et[3], ex[3], ey[3], ed[3];
+  const f2 es[3] = {a, a, b}, ee[3] = {b, c, c};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float bax = ee[i].x - es[i].x, bay = ee[i].y - es[i].y;
+    const float l2 = bax * bax + bay * bay;
+    const float t = sat01(qdiv<true>(bax * (p.x - es[i].x) + bay * (p.y - es[i].y), l2));
+    const float qx = (es[i].x + t * bax) - p.x, qy = (es[i].y + t * bay) - p.y;
+    const float px = p.x - ee[i].x, py = p.y - ee[i].y;
+    et[i] = t;
+    ex[i] = qx;
+    ey[i] = qy;
+    ed[i] = (l2 <= 1e-8f) ? px * px + py * py : qx * qx + qy * qy;
   }
+  // which edge is closest; 3 = none (NaN distances).  The three candidate branches of the reference are folded into ONE
+  // evaluation on selected values: lanes of a wave pick different edges, and divergent branches would run it three times.
+  const int sel = ((ed[0] <= ed[1]) & (ed[0] <= ed[2])) ? 0 : (((ed[1] <= ed[0]) & (ed[1] <= ed[2])) ? 1 : (((ed[2] <= ed[0]) & (ed[2] <= ed[1])) ? 2 : 3));
+  const float st = sel == 0 ? et[0] : (sel == 1 ? et[1] : et[2]);
+  const float sx = sel == 0 ? ex[0] : (sel == 1 ? ex[1] : ex[2]);
+  const float sy = sel == 0 ? ey[0] : (sel == 1 ? ey[1] : ey[2]);
+  const float g2 = sel == 3 ? 0.0f : gd + gd;  // d |q|^2 / d q = 2 q
+  const float ga = g2 * (1.0f - st), gb_ = g2 * st;  // q = (1 - t) s + t e - p: weights of the segment's start and end point
+  const f2 da = mk2(ga * sx, ga * sy), db = mk2(gb_ * sx, gb_ * sy);
+  const f2 zero = mk2(0.0f, 0.0f);
+  const f2 dd0 = sel <= 1 ? da : zero;                        // v0 starts e01 and e02
+  const f2 dd1 = sel == 0 ? db : (sel == 2 ? da : zero);      // v1 ends e01, starts e12
+  const f2 dd2 = (sel == 1 || sel == 2) ? db : zero;          // v2 ends e02 and e12
+
+  // ---- barycentrics: zbuf = sum bc_i z_i, so its upstream joins the barycentrics' (rasterize_meshes.cu:486-561)
+  f3 gb = mk3(g_bary.x + g_zbuf * z0, g_bary.y + g_zbuf * z1, g_bary.z + g_zbuf * z2);
+  if (clip_bary) gb = bary_clip_bwd(clip_bwd_on_corrected ? bp : bw, gb);
   float dz0 = 0.0f, dz1 = 0.0f, dz2 = 0.0f;
   if (perspective_correct) {
-    const PerspGrad pg = bary_perspective_bwd(bw, v0.z, v1.z, v2.z, gb);
-    gb = pg.dbary;
-    dz0 = pg.dz0;
-    dz1 = pg.dz1;
-    dz2 = pg.dz2;
+    // geometry_utils.cuh:200-228 on the numerators and the reciprocal formed above
+    const float gd_top = -t0 * gb.x - t1 * gb.y - t2 * gb.z;
+    const float gdn = gd_top * (inv_denom * inv_denom);
+    const float g0 = gdn + gb.x * inv_denom;
+    const float g1 = gdn + gb.y * inv_denom;
+    const float g2p = gdn + gb.z * inv_denom;
+    dz0 = g1 * bw.y * z2 + g2p * bw.z * z1;
+    dz1 = g0 * bw.x * z2 + g2p * bw.z * z0;
+    dz2 = g0 * bw.x * z1 + g1 * bw.y * z0;
+    gb = mk3(g0 * z1 * z2, g1 * z0 * z2, g2p * z0 * z1);
   }
-  const TriGrad db = bary_coords_bwd(p, a, b, c, gb);
+  const TriGrad dbw = bary_coords_bwd(p, a, b, c, gb);
 
   FaceGrad r;
-  r.g[0] = db.d0.x + dd.d0.x;
-  r.g[1] = db.d0.y + dd.d0.y;
+  r.g[0] = dbw.d0.x + dd0.x;
+  r.g[1] = dbw.d0.y + dd0.y;
   r.g[2] = g_zbuf * bc.x + dz0;
-  r.g[3] = db.d1.x + dd.d1.x;
-  r.g[4] = db.d1.y + dd.d1.y;
+  r.g[3] = dbw.d1.x + dd1.x;
+  r.g[4] = dbw.d1.y + dd1.y;
   r.g[5] = g_zbuf * bc.y + dz1;
-  r.g[6] = db.d2.x + dd.d2.x;
-  r.g[7] = db.d2.y + dd.d2.y;
+  r.g[6] = dbw.d2.x + dd2.x;
+  r.g[7] = dbw.d2.y + dd2.y;
   r.g[8] = g_zbuf * bc.z + dz2;
   return r;
 }

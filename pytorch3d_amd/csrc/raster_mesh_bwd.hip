@@ -68,6 +68,15 @@ __device__ __forceinline__ unsigned area_rows(const BwdArgs& a, int n, int ay, i
   return (unsigned)a.cover[((int64_t)n * a.CY + (ay >> 4)) * a.CX + (ax >> 4)] & 0xffffu;
 }
 
+// A wave-uniform pointer the optimizer may not take apart: loads through it are [scalar base][32-bit lane offset] (global_load
+// with an SGPR pair), not 64-bit per-lane address arithmetic.
+template <typename T>
+__device__ __forceinline__ const __attribute__((address_space(1))) T* uniform_ptr(const T* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return (const __attribute__((address_space(1))) T*)(((unsigned long long)hi << 32) | (unsigned long long)lo);  // (global memory: not a flat access)
+}
+
 // Row loaders: KT contiguous elements starting at a (KT * elemsize)-aligned address.
 template <int KT>
 __device__ __forceinline__ void load_idx_row(const int64_t* p, int (&out)[KT]) {
@@ -431,10 +440,14 @@ __global__ __launch_bounds__(256, RowsCfg<KT>::kWaves) void mesh_backward_rows_k
   const int64_t area_base = (((int64_t)n * H + ay) * W + ax) * KT;
   const int64_t row_pitch = (int64_t)W * KT;
 
+  // Addresses: a step's operands are [uniform row pointer][this lane's fixed sample offset] -- the row pointer is scalar arithmetic,
+  // the lane offsets (e, 3 e) never change: written with 64-bit per-lane indices each step cost nine vector instructions of
+  // address arithmetic (round 6, seen in the ISA).
+  const unsigned eu = (unsigned)e, eu3 = 3u * (unsigned)e;
   // pix_to_face one step ahead: the only load every step needs (steps without a sample cost nothing else)
   int rn = __builtin_ctz(todo), sn = 0;  // the next step: row, part of the row
   todo &= todo - 1;
-  int f_nxt = e < seg ? (int)a.p2f[area_base + (int64_t)rn * row_pitch + e] : -1;
+  int f_nxt = e < seg ? (int)uniform_ptr(a.p2f + (area_base + (int64_t)rn * row_pitch))[eu] : -1;
 #pragma unroll 1
   while (rn >= 0) {
     const int r = rn, s = sn;
@@ -446,15 +459,18 @@ __global__ __launch_bounds__(256, RowsCfg<KT>::kWaves) void mesh_backward_rows_k
     }
     {
       const int en = 64 * sn + e;
-      f_nxt = (rn >= 0 && en < seg) ? (int)a.p2f[area_base + (int64_t)rn * row_pitch + en] : -1;
+      const auto* prow = uniform_ptr(a.p2f + (area_base + (int64_t)(rn < 0 ? 0 : rn) * row_pitch + 64 * sn));
+      f_nxt = (rn >= 0 && en < seg) ? (int)prow[eu] : -1;
     }
     if (__ballot(f >= 0) == 0) continue;  // wave-uniform: nothing rendered in these 64 samples
     FaceGrad g;
     if (f >= 0) {
       const int64_t rb = area_base + (int64_t)r * row_pitch + 64 * s;  // uniform
-      const float gz = a.grad_zbuf[rb + e], gd = a.grad_dists[rb + e];
-      const float* gbp = a.grad_bary + 3 * rb;
-      const f3 gb = mk3(gbp[3 * e], gbp[3 * e + 1], gbp[3 * e + 2]);
+      const auto* gzp = uniform_ptr(a.grad_zbuf + rb);
+      const auto* gdp = uniform_ptr(a.grad_dists + rb);
+      const auto* gbp = uniform_ptr(a.grad_bary + 3 * rb);
+      const float gz = gzp[eu], gd = gdp[eu];
+      const f3 gb = mk3(gbp[eu3], gbp[eu3 + 1u], gbp[eu3 + 2u]);
       const float* q = a.face_verts + (int64_t)f * 9;
       float pxs = px[0];
 #pragma unroll
