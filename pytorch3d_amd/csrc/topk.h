@@ -22,11 +22,6 @@
 #include "topk_insert_asm.h"
 #endif
 
-// steps per segment of the exact-K insertion network (TopKPairs::insert_segments)
-#ifndef P3D_SEG_LEN
-#define P3D_SEG_LEN 2
-#endif
-
 namespace p3d {
 
 constexpr int kEmptyIdx = 0x7fffffff;
@@ -445,7 +440,7 @@ struct TopKPairs {
         return;
       }
     }
-    if constexpr (KT % 2 == 0 && KT >= 4 && KT <= 8 && KT % P3D_SEG_LEN == 0) {
+    if constexpr (KT % 2 == 0 && KT >= 4 && KT <= 8) {
       if (__builtin_constant_p(K) && K == KT) {
         insert_segments(czi, cpa, cpb, cz, cidx);
         return;
@@ -487,7 +482,7 @@ struct TopKPairs {
   // The kernel's time follows its instruction COUNT, scalar ones included (a version with both tests at every step ran 57 %
   // fewer steps and 3 % slower, profiles/r06/): one test per segment and side, nothing per step.
   // The K-th entry (kz, ki) changes only if the top step ran.
-  static constexpr int SL = P3D_SEG_LEN;  // steps per segment
+  static constexpr int SL = 2;  // steps per segment (1: the tests cost what the steps save; 4: the same time as 2, profiles/r06/README.md)
   // segment S holds steps S * SL + SL - 1 ... S * SL (step 0 = the placement into entry 0)
   template <int S>
   __device__ __forceinline__ LaneMask enter_segments(float cz, int cidx, int* seg) {
