@@ -150,6 +150,30 @@ int p3d_rasterize_meshes_with_cover(const float* face_verts, const int64_t* mesh
                                     int cull_backfaces, int64_t* pix_to_face, float* zbuf, float* bary, float* dists,
                                     int32_t* cover, void* workspace, size_t workspace_bytes, p3d_stream_t stream);
 
+/* The cover AND the list of its non-empty words (round 6): `cover_and_list` is one buffer of p3d_rasterize_meshes_cover_list_bytes --
+ * the (N, ceil(H/16), ceil(W/16)) words of the cover as above, an int32 counter (+ 15 spare), then room for one int32 per word.
+ * The wave that sets the first bit of a word appends the word's index to the list (one atomic per 16 x 16 pixel block that holds a
+ * face), so the backward finds its work without a pass over the cover: p3d_rasterize_meshes_backward[_verts]_with_cover_list take
+ * the same buffer and no workspace, and launch two kernels fewer than the _with_cover forms (the list builder and the memset of
+ * its counter; 0.02 ms of the 2.3 ms bench step).  The words in front are a plain cover: the buffer may be handed to every
+ * function that takes `cover`.  The list's order is the order in which the forward's tiles finished. */
+size_t p3d_rasterize_meshes_cover_list_bytes(int N, int H, int W);
+int p3d_rasterize_meshes_with_cover_list(const float* face_verts, const int64_t* mesh_to_face_first_idx,
+                                         const int64_t* num_faces_per_mesh, const int64_t* clipped_faces_neighbor_idx, int64_t F,
+                                         int N, int H, int W, float blur_radius, int faces_per_pixel, int bin_size,
+                                         int max_faces_per_bin, int perspective_correct, int clip_barycentric_coords,
+                                         int cull_backfaces, int64_t* pix_to_face, float* zbuf, float* bary, float* dists,
+                                         int32_t* cover_and_list, void* workspace, size_t workspace_bytes, p3d_stream_t stream);
+int p3d_rasterize_meshes_backward_with_cover_list(const float* face_verts, const int64_t* pix_to_face, const float* grad_zbuf,
+                                                  const float* grad_bary, const float* grad_dists, const int32_t* cover_and_list,
+                                                  int64_t F, int N, int H, int W, int K, int perspective_correct,
+                                                  int clip_barycentric_coords, float* grad_face_verts, p3d_stream_t stream);
+int p3d_rasterize_meshes_backward_verts_with_cover_list(const float* face_verts, const int64_t* faces, const int64_t* pix_to_face,
+                                                        const float* grad_zbuf, const float* grad_bary, const float* grad_dists,
+                                                        const int32_t* cover_and_list, int64_t F, int64_t V, int N, int H, int W,
+                                                        int K, int perspective_correct, int clip_barycentric_coords,
+                                                        float* grad_verts, p3d_stream_t stream);
+
 /* CUDA tie order -- p3d_rasterize_meshes_with_cover, then a replay that makes pix_to_face (and the rows that go with it) what
  * the reference's CUDA kernels return where faces tie EXACTLY in depth at a pixel's K-th place.  The kernels of this library keep
  * the K nearest under the total order (depth, face index), as the reference's CPU and Python implementations do

@@ -251,6 +251,9 @@ def rasterize_meshes(face_verts, mesh_to_face_first_idx, num_faces_per_mesh, cli
 # `forget_cover(pix_to_face)` after such a write; RECALL_COVERS = False (P3D_RECALL_COVERS=0) switches the recall off (+0.5 ms on
 # the bench batch).  Pinned by tests/test_gpu_cover.py.
 RECALL_COVERS = os.environ.get("P3D_RECALL_COVERS", "1") not in ("", "0")
+# the forward appends the non-empty words of its cover to a list behind it (p3d_rasterize_meshes_with_cover_list); 0: the plain cover,
+# the backward builds the list itself (mesh_backward_areas)
+COVER_LIST = os.environ.get("P3D_COVER_LIST", "1") not in ("", "0")
 CHECK_COVERS = os.environ.get("P3D_CHECK", "0") not in ("", "0")
 COVER_RECALLS = [0, 0]  # backward calls without an explicit cover: [found the forward's, found none] (read by tests / profiles)
 COVER_CHECKS = [0, 0]   # CHECK_COVERS: [covers verified, of which stale]
@@ -344,8 +347,18 @@ def _rasterize_meshes_covered(face_verts, mesh_to_face_first_idx, num_faces_per_
         # without it the replay finds its pixels by reading a pix_to_face entry of every pixel)
         marks = N * ((H + 7) // 8) * ((W + 7) // 8) * 8 + 1024 if CUDA_TIE_ORDER else 0
         ws, need, need_at, entries = _mesh_workspace(lib, F, N, H, W, bin_size, M, dev, extra=marks) if binned else (_workspace(marks, dev), None, 0, None)
-        cover = torch.empty((N, (H + 15) // 16, (W + 15) // 16), dtype=torch.int32, device=dev) if want_cover else None
-        entry = lib.p3d_rasterize_meshes_cuda_order if CUDA_TIE_ORDER else lib.p3d_rasterize_meshes_with_cover
+        cover = None
+        if want_cover and not CUDA_TIE_ORDER and COVER_LIST:
+            # the cover with the list of its non-empty words behind it (include/p3d_amd.h: p3d_rasterize_meshes_with_cover_list): what is
+            # handed on is the (N, CY, CX) view of the buffer's first words -- a plain cover to everybody; the backward wrappers of this
+            # package see the room behind it (cover_has_list) and take the list
+            words = N * ((H + 15) // 16) * ((W + 15) // 16)
+            buf = torch.empty((lib.p3d_rasterize_meshes_cover_list_bytes(N, H, W) // 4,), dtype=torch.int32, device=dev)
+            cover = buf[:words].view(N, (H + 15) // 16, (W + 15) // 16)
+        elif want_cover:
+            cover = torch.empty((N, (H + 15) // 16, (W + 15) // 16), dtype=torch.int32, device=dev)
+        entry = lib.p3d_rasterize_meshes_cuda_order if CUDA_TIE_ORDER else (lib.p3d_rasterize_meshes_with_cover_list if (want_cover and COVER_LIST)
+                                                                            else lib.p3d_rasterize_meshes_with_cover)
         rc = entry(
             _ptr(fv), _ptr(first), _ptr(count), _ptr(nb), F, N, H, W, float(blur_radius), K, bin_size if binned else 0,
             M if binned else 0, int(bool(perspective_correct)), int(bool(clip_barycentric_coords)), int(bool(cull_backfaces)),
@@ -431,9 +444,18 @@ def cover_ptr(cover, N, H, W):
     return _ptr(cover)
 
 
+def cover_has_list(cover, N, H, W):
+    """Is `cover` the front of a buffer of p3d_rasterize_meshes_cover_list_bytes, as _rasterize_meshes_covered makes them (the list of
+    its non-empty words behind it)?  A clone, a cover from elsewhere, a slice: no."""
+    if cover is None or cover.storage_offset() != 0 or not cover.is_contiguous():
+        return False
+    need = _lib.load().p3d_rasterize_meshes_cover_list_bytes(N, H, W)
+    return need > 0 and cover.untyped_storage().nbytes() == need
+
+
 def backward_workspace(cover, N, H, W, dev):
-    """Scratch of the covered backward (the list of areas with work); empty without a cover."""
-    n = _lib.load().p3d_rasterize_meshes_backward_workspace_bytes(N, H, W) if cover is not None else 0
+    """Scratch of the covered backward (the list of areas with work); empty without a cover, or when the cover brings its list."""
+    n = _lib.load().p3d_rasterize_meshes_backward_workspace_bytes(N, H, W) if (cover is not None and not cover_has_list(cover, N, H, W)) else 0
     return _workspace(n, dev)
 
 
@@ -458,10 +480,15 @@ def rasterize_meshes_backward(face_verts, pix_to_face, grad_zbuf, grad_bary, gra
         out = torch.empty((F, 3, 3), dtype=torch.float32, device=dev)
         if F == 0:
             return out
-        ws = backward_workspace(_cover, N, H, W, dev)
-        rc = lib.p3d_rasterize_meshes_backward_with_cover(
-            _ptr(fv), _ptr(p2f), _ptr(gz), _ptr(gb), _ptr(gd), cover_ptr(_cover, N, H, W), F, N, H, W, K,
-            int(bool(perspective_correct)), int(bool(clip_barycentric_coords)), _ptr(out), _ptr(ws), ws.numel(), _stream(dev))
+        if cover_has_list(_cover, N, H, W):
+            rc = lib.p3d_rasterize_meshes_backward_with_cover_list(
+                _ptr(fv), _ptr(p2f), _ptr(gz), _ptr(gb), _ptr(gd), cover_ptr(_cover, N, H, W), F, N, H, W, K,
+                int(bool(perspective_correct)), int(bool(clip_barycentric_coords)), _ptr(out), _stream(dev))
+        else:
+            ws = backward_workspace(_cover, N, H, W, dev)
+            rc = lib.p3d_rasterize_meshes_backward_with_cover(
+                _ptr(fv), _ptr(p2f), _ptr(gz), _ptr(gb), _ptr(gd), cover_ptr(_cover, N, H, W), F, N, H, W, K,
+                int(bool(perspective_correct)), int(bool(clip_barycentric_coords)), _ptr(out), _ptr(ws), ws.numel(), _stream(dev))
         _lib.check(rc, "rasterize_meshes_backward")
     return out
 

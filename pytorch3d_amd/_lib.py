@@ -43,6 +43,14 @@ _SIGNATURES = {
     "p3d_rasterize_meshes_with_cover": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_f32, c_int, c_int,
                                                 c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size,
                                                 c_ptr]),
+    "p3d_rasterize_meshes_cover_list_bytes": (c_size, [c_int, c_int, c_int]),
+    "p3d_rasterize_meshes_with_cover_list": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_f32, c_int, c_int,
+                                                     c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size,
+                                                     c_ptr]),
+    "p3d_rasterize_meshes_backward_with_cover_list": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int,
+                                                              c_int, c_int, c_int, c_ptr, c_ptr]),
+    "p3d_rasterize_meshes_backward_verts_with_cover_list": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64,
+                                                                    c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
     "p3d_rasterize_meshes_cuda_order": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_f32, c_int, c_int,
                                                 c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size,
                                                 c_ptr]),

@@ -66,6 +66,10 @@ struct MeshArgs {
   float* dists;
   int* cover;  // row cover of the output (include/p3d_amd.h: p3d_rasterize_meshes_with_cover), zeroed by the launcher; or null
   int CY, CX;  // its 16 x 16 pixel blocks per image
+  // p3d_rasterize_meshes_with_cover_list: the words of the cover that hold a face, appended by the wave that sets a word's first bit
+  // (its atomicOr returns 0): area_count[0] entries of area_list, zeroed with the cover.  Null without.
+  int* area_count;
+  int* area_list;
   // short workspaces (binning.h): the device flag "the lists did not fit", or null.  A binned launch returns at once when
   // it is up, the naive launch that follows it returns at once when it is not: exactly one of the two writes the output.
   const int* overflow;
@@ -596,7 +600,12 @@ __device__ __forceinline__ void cover_mark(const MeshArgs& a, int n, int sy0, bo
     for (int j = 0; j < 8; ++j)
       if ((same >> (8 * j)) & 0xffull) bits |= 1u << ((a.H - 1 - (sy0 + j)) & 15);
     rem &= ~same;
-    if (lane == 0) atomicOr(a.cover + ((int64_t)n * a.CY) * a.CX + w0, (int)bits);
+    if (lane == 0) {
+      const int word = (n * a.CY) * a.CX + w0;
+      const int before = atomicOr(a.cover + word, (int)bits);
+      // the first to mark this word lists it for the backward (which then needs no pass over the cover to find its work)
+      if (a.area_list != nullptr && before == 0 && bits != 0u) a.area_list[atomicAdd(a.area_count, 1)] = word;
+    }
   }
 }
 
@@ -1477,14 +1486,26 @@ P3D_API size_t p3d_rasterize_meshes_cover_bytes(int N, int H, int W) {
   return (size_t)N * (size_t)((H + 15) / 16) * (size_t)((W + 15) / 16) * sizeof(int32_t);
 }
 
-// the cover starts empty; the waves that write a pixel with a face set its bit
-static int cover_begin(MeshArgs* a, int32_t* cover, hipStream_t s) {
+P3D_API size_t p3d_rasterize_meshes_cover_list_bytes(int N, int H, int W) {
+  const size_t words = p3d_rasterize_meshes_cover_bytes(N, H, W) / sizeof(int32_t);
+  return words == 0 ? 0 : (2 * words + 16) * sizeof(int32_t);  // cover | count + 15 spare | list
+}
+
+// the cover starts empty; the waves that write a pixel with a face set its bit.  with_list: cover is a buffer of
+// p3d_rasterize_meshes_cover_list_bytes -- the counter of the area list behind the words is zeroed in the same memset
+static int cover_begin(MeshArgs* a, int32_t* cover, hipStream_t s, bool with_list = false) {
   a->cover = cover;
   a->CY = (a->H + 15) / 16;
   a->CX = (a->W + 15) / 16;
+  a->area_count = nullptr;
+  a->area_list = nullptr;
   if (cover == nullptr) return P3D_OK;
   const size_t bytes = p3d_rasterize_meshes_cover_bytes(a->N, a->H, a->W);
-  return (bytes == 0 || hipMemsetAsync(cover, 0, bytes, s) == hipSuccess) ? P3D_OK : P3D_ERR_LAUNCH;
+  if (with_list && bytes > 0) {
+    a->area_count = cover + bytes / sizeof(int32_t);
+    a->area_list = a->area_count + 16;
+  }
+  return (bytes == 0 || hipMemsetAsync(cover, 0, bytes + (with_list ? 16 * sizeof(int32_t) : 0), s) == hipSuccess) ? P3D_OK : P3D_ERR_LAUNCH;
 }
 
 // CUDA tie order: where the TIES kernels leave their lane masks (MeshArgs::tie_words), or words == null: marks in place only
@@ -1496,17 +1517,22 @@ struct TieMarks {
 static int mesh_naive_impl(const float* face_verts, const int64_t* mesh_first, const int64_t* mesh_count,
                            const int64_t* neighbor, int64_t F, int N, int H, int W, float blur_radius, int K, int persp,
                            int clip, int cull, int64_t* p2f, float* zbuf, float* bary, float* dists, int32_t* cover,
-                           p3d_stream_t stream, const int* overflow = nullptr, bool ties = false, TieMarks marks = TieMarks()) {
+                           p3d_stream_t stream, const int* overflow = nullptr, bool ties = false, TieMarks marks = TieMarks(),
+                           bool with_list = false) {
   (void)F;
   const int rc = check_common(N, H, W, K);
   if (rc != P3D_OK) return rc;
+  MeshArgs z{};
+  z.N = N;
+  z.H = H;
+  z.W = W;
   if (cover != nullptr && overflow == nullptr) {  // (as the fallback of a binned launch: that one zeroed the cover)
-    MeshArgs z{};
-    z.N = N;
-    z.H = H;
-    z.W = W;
-    const int st = cover_begin(&z, cover, (hipStream_t)stream);  // also for K == 0: nothing is covered
+    const int st = cover_begin(&z, cover, (hipStream_t)stream, with_list);  // also for K == 0: nothing is covered
     if (st != P3D_OK) return st;
+  } else if (cover != nullptr && with_list) {
+    const size_t words = p3d_rasterize_meshes_cover_bytes(N, H, W) / sizeof(int32_t);
+    z.area_count = cover + words;
+    z.area_list = z.area_count + 16;
   }
   if ((int64_t)N * H * W * K == 0) return P3D_OK;
   if ((!face_verts || !neighbor) && F > 0) return P3D_ERR_INVALID_ARG;
@@ -1532,6 +1558,8 @@ static int mesh_naive_impl(const float* face_verts, const int64_t* mesh_first, c
   a.cover = cover;  // zeroed above
   a.CY = (H + 15) / 16;
   a.CX = (W + 15) / 16;
+  a.area_count = cover != nullptr ? z.area_count : nullptr;
+  a.area_list = cover != nullptr ? z.area_list : nullptr;
   a.overflow = overflow;
   a.ties = ties ? 1 : 0;
   a.tie_words = marks.words;
@@ -1552,7 +1580,7 @@ P3D_API int p3d_rasterize_meshes_naive(const float* face_verts, const int64_t* m
 static int mesh_fine_from_csr(const float* face_verts, const int64_t* neighbor, const BinCSR& csr, int N, int H, int W,
                               const BinGeom& g, float blur_radius, int K, int persp, int clip, int cull, int64_t* p2f,
                               float* zbuf, float* bary, float* dists, hipStream_t stream, int32_t* cover = nullptr,
-                              const int* overflow = nullptr, bool ties = false, TieMarks marks = TieMarks()) {
+                              const int* overflow = nullptr, bool ties = false, TieMarks marks = TieMarks(), bool with_list = false) {
   MeshArgs a{};
   a.face_verts = face_verts;
   a.neighbor = neighbor;
@@ -1570,7 +1598,7 @@ static int mesh_fine_from_csr(const float* face_verts, const int64_t* neighbor, 
   a.zbuf = zbuf;
   a.bary = bary;
   a.dists = dists;
-  const int st = cover_begin(&a, cover, stream);
+  const int st = cover_begin(&a, cover, stream, with_list);
   if (st != P3D_OK) return st;
   a.overflow = overflow;
   a.ties = ties ? 1 : 0;
@@ -1656,7 +1684,7 @@ static int raster_meshes_impl(const float* face_verts, const int64_t* mesh_first
                               const int64_t* neighbor, int64_t F, int N, int H, int W, float blur_radius, int K, int bin_size,
                               int max_faces_per_bin, int persp, int clip, int cull, int64_t* p2f, float* zbuf, float* bary,
                               float* dists, int32_t* cover, void* workspace, size_t workspace_bytes, p3d_stream_t stream,
-                              bool cuda_order) {
+                              bool cuda_order, bool with_list = false) {
   hipStream_t s = (hipStream_t)stream;
   const bool any_output = (int64_t)N * H * W * K != 0;
   // CUDA tie order: the lane masks of the marked pixels live in the LAST bytes of the workspace when it has room for them
@@ -1683,7 +1711,7 @@ static int raster_meshes_impl(const float* face_verts, const int64_t* mesh_first
   }
   if (bin_size <= 0 || max_faces_per_bin <= 0) {
     const int st = mesh_naive_impl(face_verts, mesh_first, mesh_count, neighbor, F, N, H, W, blur_radius, K, persp, clip, cull,
-                                   p2f, zbuf, bary, dists, cover, stream, nullptr, cuda_order, marks);
+                                   p2f, zbuf, bary, dists, cover, stream, nullptr, cuda_order, marks, with_list);
     if (st != P3D_OK || !cuda_order || !any_output) return st;
     return cuda_order_replay(face_verts, mesh_first, mesh_count, neighbor, nullptr, nullptr, N, H, W, blur_radius, K, persp, clip,
                              cull, p2f, zbuf, bary, dists, nullptr, s, marks);
@@ -1695,7 +1723,7 @@ static int raster_meshes_impl(const float* face_verts, const int64_t* mesh_first
     z.N = N;
     z.H = H;
     z.W = W;
-    return cover_begin(&z, cover, s);
+    return cover_begin(&z, cover, s, with_list);
   }
   if (!any_output) return P3D_OK;
   if ((!face_verts || !neighbor) && F > 0) return P3D_ERR_INVALID_ARG;
@@ -1722,10 +1750,10 @@ static int raster_meshes_impl(const float* face_verts, const int64_t* mesh_first
   if (st != P3D_OK) return st;
   BinCSR csr{ws.offset, ws.total, ws.list, TilePlan{ws.arank, ws.bg_list, ws.plan_hdr, ws.order}};
   st = mesh_fine_from_csr(face_verts, neighbor, csr, N, H, W, g, blur_radius, K, persp, clip, cull, p2f, zbuf, bary, dists, s,
-                          cover, overflow, cuda_order, marks);
+                          cover, overflow, cuda_order, marks, with_list);
   if (st == P3D_OK && is_short)
     st = mesh_naive_impl(face_verts, mesh_first, mesh_count, neighbor, F, N, H, W, blur_radius, K, persp, clip, cull, p2f, zbuf,
-                         bary, dists, cover, stream, overflow, cuda_order, marks);
+                         bary, dists, cover, stream, overflow, cuda_order, marks, with_list);
   if (st != P3D_OK || !cuda_order) return st;
   st = cuda_order_replay(face_verts, mesh_first, mesh_count, neighbor, &csr, &g, N, H, W, blur_radius, K, persp, clip, cull, p2f,
                          zbuf, bary, dists, overflow, s, marks);
@@ -1741,6 +1769,16 @@ P3D_API int p3d_rasterize_meshes_with_cover(const float* face_verts, const int64
                                             void* workspace, size_t workspace_bytes, p3d_stream_t stream) {
   return raster_meshes_impl(face_verts, mesh_first, mesh_count, neighbor, F, N, H, W, blur_radius, K, bin_size, max_faces_per_bin,
                             persp, clip, cull, p2f, zbuf, bary, dists, cover, workspace, workspace_bytes, stream, false);
+}
+
+P3D_API int p3d_rasterize_meshes_with_cover_list(const float* face_verts, const int64_t* mesh_first, const int64_t* mesh_count,
+                                                 const int64_t* neighbor, int64_t F, int N, int H, int W, float blur_radius,
+                                                 int K, int bin_size, int max_faces_per_bin, int persp, int clip, int cull,
+                                                 int64_t* p2f, float* zbuf, float* bary, float* dists, int32_t* cover_and_list,
+                                                 void* workspace, size_t workspace_bytes, p3d_stream_t stream) {
+  return raster_meshes_impl(face_verts, mesh_first, mesh_count, neighbor, F, N, H, W, blur_radius, K, bin_size, max_faces_per_bin,
+                            persp, clip, cull, p2f, zbuf, bary, dists, cover_and_list, workspace, workspace_bytes, stream, false,
+                            cover_and_list != nullptr);
 }
 
 P3D_API int p3d_rasterize_meshes_cuda_order(const float* face_verts, const int64_t* mesh_first, const int64_t* mesh_count,

@@ -513,7 +513,8 @@ unsigned scatter_multiplier(uint64_t items) {
 
 int launch_mesh_backward(const float* face_verts, const int64_t* faces, int64_t V, const int64_t* p2f, const float* grad_zbuf,
                          const float* grad_bary, const float* grad_dists, int N, int H, int W, int K, int persp, int clip,
-                         float* grad_out, const int32_t* cover, void* workspace, size_t workspace_bytes, hipStream_t s) {
+                         float* grad_out, const int32_t* cover, void* workspace, size_t workspace_bytes, hipStream_t s,
+                         bool cover_has_list = false) {
   BwdArgs a;
   a.V = V;
   a.face_verts = face_verts;
@@ -544,7 +545,12 @@ int launch_mesh_backward(const float* face_verts, const int64_t* faces, int64_t 
   if (items > 0x7fffffffll) return P3D_ERR_INVALID_ARG;
   a.nblocks = (unsigned)items;
   a.scatter = scatter_multiplier((uint64_t)items);
-  if (rows_kernel && cover != nullptr && workspace != nullptr &&
+  if (rows_kernel && cover != nullptr && cover_has_list) {
+    // the forward listed the areas itself (p3d_rasterize_meshes_with_cover_list): no pass over the cover, no counter to clear
+    const int* count = reinterpret_cast<const int*>(cover) + items;
+    a.area_list = count + 16;
+    a.area_count = count;
+  } else if (rows_kernel && cover != nullptr && workspace != nullptr &&
       workspace_bytes >= p3d_rasterize_meshes_backward_workspace_bytes(N, H, W)) {
     int* count = static_cast<int*>(workspace);
     int* list = count + 16;
@@ -651,4 +657,34 @@ P3D_API int p3d_rasterize_meshes_cover_check(const int64_t* p2f, const int32_t* 
   LaunchScope ls("mesh_cover_check", s);
   cover_check_kernel<<<(unsigned)blocks, 256, 0, s>>>(p2f, reinterpret_cast<const int*>(cover), N, H, W, K, CY, CX, reinterpret_cast<int*>(stale));
   return launch_status();
+}
+
+P3D_API int p3d_rasterize_meshes_backward_with_cover_list(const float* face_verts, const int64_t* p2f, const float* grad_zbuf,
+                                                          const float* grad_bary, const float* grad_dists, const int32_t* cover_and_list,
+                                                          int64_t F, int N, int H, int W, int K, int persp, int clip,
+                                                          float* grad_face_verts, p3d_stream_t stream) {
+  if (F < 0 || N < 0 || H < 0 || W < 0 || K < 0) return P3D_ERR_INVALID_ARG;
+  if (F == 0) return P3D_OK;
+  if (!grad_face_verts || !face_verts) return P3D_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(grad_face_verts, 0, (size_t)F * 9 * sizeof(float), s) != hipSuccess) return P3D_ERR_LAUNCH;
+  if ((int64_t)N * H * W * K == 0) return P3D_OK;
+  if (!p2f || !grad_zbuf || !grad_bary || !grad_dists) return P3D_ERR_INVALID_ARG;
+  return launch_mesh_backward(face_verts, nullptr, -1, p2f, grad_zbuf, grad_bary, grad_dists, N, H, W, K, persp, clip, grad_face_verts,
+                              cover_and_list, nullptr, 0, s, cover_and_list != nullptr);
+}
+
+P3D_API int p3d_rasterize_meshes_backward_verts_with_cover_list(const float* face_verts, const int64_t* faces, const int64_t* p2f,
+                                                                const float* grad_zbuf, const float* grad_bary, const float* grad_dists,
+                                                                const int32_t* cover_and_list, int64_t F, int64_t V, int N, int H, int W,
+                                                                int K, int persp, int clip, float* grad_verts, p3d_stream_t stream) {
+  if (F < 0 || V < 0 || N < 0 || H < 0 || W < 0 || K < 0) return P3D_ERR_INVALID_ARG;
+  if (V == 0) return P3D_OK;
+  if (!grad_verts) return P3D_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(grad_verts, 0, (size_t)V * 3 * sizeof(float), s) != hipSuccess) return P3D_ERR_LAUNCH;
+  if (F == 0 || (int64_t)N * H * W * K == 0) return P3D_OK;
+  if (!face_verts || !faces || !p2f || !grad_zbuf || !grad_bary || !grad_dists) return P3D_ERR_INVALID_ARG;
+  return launch_mesh_backward(face_verts, faces, V, p2f, grad_zbuf, grad_bary, grad_dists, N, H, W, K, persp, clip, grad_verts,
+                              cover_and_list, nullptr, 0, s, cover_and_list != nullptr);
 }

@@ -244,11 +244,17 @@ class _RasterizeMeshVerts(torch.autograd.Function):
         lib = _lib.load()
         with torch.cuda.device(dev):
             grad_verts = torch.empty((ctx.V, 3), dtype=torch.float32, device=dev)
-            ws = _C.backward_workspace(cover, N, H, W, dev)
-            rc = lib.p3d_rasterize_meshes_backward_verts_with_cover(
-                _C._ptr(face_verts), _C._ptr(faces), _C._ptr(pix_to_face), _C._ptr(gz), _C._ptr(gb), _C._ptr(gd),
-                _C.cover_ptr(cover, N, H, W), faces.shape[0], ctx.V, N, H, W, K, ctx.flags[0], ctx.flags[1], _C._ptr(grad_verts),
-                _C._ptr(ws), ws.numel(), _C._stream(dev))
+            if _C.cover_has_list(cover, N, H, W):  # the forward listed the areas that hold a face: no list builder, no workspace
+                rc = lib.p3d_rasterize_meshes_backward_verts_with_cover_list(
+                    _C._ptr(face_verts), _C._ptr(faces), _C._ptr(pix_to_face), _C._ptr(gz), _C._ptr(gb), _C._ptr(gd),
+                    _C.cover_ptr(cover, N, H, W), faces.shape[0], ctx.V, N, H, W, K, ctx.flags[0], ctx.flags[1], _C._ptr(grad_verts),
+                    _C._stream(dev))
+            else:
+                ws = _C.backward_workspace(cover, N, H, W, dev)
+                rc = lib.p3d_rasterize_meshes_backward_verts_with_cover(
+                    _C._ptr(face_verts), _C._ptr(faces), _C._ptr(pix_to_face), _C._ptr(gz), _C._ptr(gb), _C._ptr(gd),
+                    _C.cover_ptr(cover, N, H, W), faces.shape[0], ctx.V, N, H, W, K, ctx.flags[0], ctx.flags[1], _C._ptr(grad_verts),
+                    _C._ptr(ws), ws.numel(), _C._stream(dev))
             _lib.check(rc, "rasterize_meshes_backward")
         return (grad_verts,) + (None,) * 12
 
@@ -455,11 +461,16 @@ class _RasterizeMeshWorld(torch.autograd.Function):
         V = verts.shape[0]
         with torch.cuda.device(dev):
             g_ndc = torch.empty((V, 3), dtype=torch.float32, device=dev)
-            ws = _C.backward_workspace(cover, N, H, W, dev)
-            rc = lib.p3d_rasterize_meshes_backward_verts_with_cover(
-                _C._ptr(face_verts), _C._ptr(faces), _C._ptr(pix_to_face), _C._ptr(gz), _C._ptr(gb), _C._ptr(gd),
-                _C.cover_ptr(cover, N, H, W), faces.shape[0], V, N, H, W, K, ctx.flags[0], ctx.flags[1], _C._ptr(g_ndc), _C._ptr(ws),
-                ws.numel(), _C._stream(dev))
+            if _C.cover_has_list(cover, N, H, W):
+                rc = lib.p3d_rasterize_meshes_backward_verts_with_cover_list(
+                    _C._ptr(face_verts), _C._ptr(faces), _C._ptr(pix_to_face), _C._ptr(gz), _C._ptr(gb), _C._ptr(gd),
+                    _C.cover_ptr(cover, N, H, W), faces.shape[0], V, N, H, W, K, ctx.flags[0], ctx.flags[1], _C._ptr(g_ndc), _C._stream(dev))
+            else:
+                ws = _C.backward_workspace(cover, N, H, W, dev)
+                rc = lib.p3d_rasterize_meshes_backward_verts_with_cover(
+                    _C._ptr(face_verts), _C._ptr(faces), _C._ptr(pix_to_face), _C._ptr(gz), _C._ptr(gb), _C._ptr(gd),
+                    _C.cover_ptr(cover, N, H, W), faces.shape[0], V, N, H, W, K, ctx.flags[0], ctx.flags[1], _C._ptr(g_ndc), _C._ptr(ws),
+                    ws.numel(), _C._stream(dev))
             _lib.check(rc, "rasterize_meshes_backward")
             g_world = torch.empty((V, 3), dtype=torch.float32, device=dev)
             rc = lib.p3d_transform_verts_backward(_C._ptr(verts), _C._ptr(vert_first), _C._ptr(mats), _C._ptr(g_ndc), V,

@@ -275,3 +275,44 @@ def test_writes_the_version_counter_cannot_see():
     out3[0][n, y, x, 0] = 0
     got = _C.rasterize_meshes_backward(fv, out3[0], gz, gb, gd, True, True)
     assert float(((got - truth).abs() / scale).max()) < 5e-3
+
+
+@pytest.mark.parametrize("K,size,bin_size", [(8, (96, 80), 32), (8, (50, 37), 16), (4, (64, 64), 0), (1, (33, 130), 32), (12, (40, 40), 16)])
+def test_the_forward_lists_the_words_of_its_cover_and_the_backward_takes_the_list(K, size, bin_size):
+    """include/p3d_amd.h: p3d_rasterize_meshes_with_cover_list (round 6).  The buffer behind the cover that `_C._rasterize_meshes_covered`
+    returns holds the number of non-empty cover words and, in the order the forward's tiles finished, their indices -- each exactly
+    once; the backward that takes the list (no list-builder kernel, no workspace) returns what the backward without any cover returns;
+    a clone of the cover carries no list and takes the old road."""
+    from pytorch3d_amd import _C, _lib
+
+    d = torch.device("cuda:0")
+    _, fv, first, cnt = _batch(3, 21)
+    nbr = torch.full((fv.shape[0],), -1, dtype=torch.int64, device=d)
+    H, W = size
+    M = 5000 if bin_size else 0
+    (p2f, zbuf, bary, dists), cover = _C._rasterize_meshes_covered(fv, first, cnt, nbr, size, 1e-3, K, bin_size, M, True, True, False)
+    N = p2f.shape[0]
+    assert _C.cover_has_list(cover, N, H, W) and not _C.cover_has_list(cover.clone(), N, H, W)
+    assert torch.equal(cover, cover_from_pix_to_face(p2f))
+    words = cover.numel()
+    buf = torch.empty(0, dtype=torch.int32, device=d).set_(cover.untyped_storage(), 0, (2 * words + 16,))
+    count = int(buf[words])
+    listed = buf[words + 16: words + 16 + count].cpu().tolist()
+    want = torch.nonzero(cover.reshape(-1) != 0).flatten().cpu().tolist()
+    assert count == len(want) and sorted(listed) == want, (count, len(want))
+    gen = torch.Generator().manual_seed(8)
+    gz, gd = (torch.randn(zbuf.shape, generator=gen).to(d) for _ in range(2))
+    gb = torch.randn(bary.shape, generator=gen).to(d)
+    truth = _C.rasterize_meshes_backward(fv, p2f.clone(), gz, gb, gd, True, True)  # no cover at all: every row is read
+    scale = truth.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1e-6)
+    lib = _lib.load()
+    _lib.load().p3d_profile_reset()
+    lib.p3d_profile_enable(1)
+    with_list = _C.rasterize_meshes_backward(fv, p2f, gz, gb, gd, True, True, _cover=cover)
+    torch.cuda.synchronize()
+    lib.p3d_profile_enable(0)
+    launched = set(_lib.profile_snapshot())
+    assert "mesh_backward" in launched and ("mesh_backward_areas" not in launched or K not in (4, 8, 16, 32)), launched
+    without_list = _C.rasterize_meshes_backward(fv, p2f, gz, gb, gd, True, True, _cover=cover.clone())
+    for got in (with_list, without_list):
+        assert float(((got - truth).abs() / scale).max()) < 5e-3
