@@ -38,6 +38,9 @@ def main():
                     help="patched: shim.install(patch_python=True) -- PointsRasterizer.forward transforms the PACKED points in one launch, "
                          "the compositing functions run as one autograd node without clones")
     ap.add_argument("--check", action="store_true", help="compare with the reference's own device kernels under the same Python")
+    ap.add_argument("--graph", action="store_true",
+                    help="also: the same step on a Pointclouds built once, eager and captured in a HIP graph (torch.cuda.graph) and replayed -- "
+                         "what is left of the step when the host side and the launch gaps are taken out")
     args = ap.parse_args()
     stage = os.path.join(ROOT, "oracle", "_ref", "reference_py")
     ref_root = None
@@ -106,6 +109,49 @@ def main():
            "reference": ref_root if ref_root != stage else "oracle/_ref/reference_py (staged copy)"}
     if args.mode == "patched":
         out["patched_calls"] = {k: v for k, v in shim.PATCH_CALLS.items()}
+    if args.graph:
+        try:
+            want_img, want_gp = image.detach().clone(), pts.grad.clone()
+            clouds = Pointclouds(points=[pts], features=[feats])
+            clouds.points_packed(), clouds.features_packed(), clouds.cloud_to_packed_first_idx(), clouds.num_points_per_cloud()  # the cloud's caches, built once
+
+            def step_built():
+                pts.grad.zero_()
+                feats.grad.zero_()
+                img = renderer(clouds)
+                (img * g_img).sum().backward(retain_graph=True)  # (the cat of the cloud's packed tensors was recorded once, outside)
+                return img
+
+            def wall_of(fn, n):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / n * 1e3
+
+            eager_built = wall_of(step_built, args.steps)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step_built()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                img_g = step_built()
+            replay = wall_of(graph.replay, max(args.steps, 50))
+            graph.replay()
+            torch.cuda.synchronize()
+            out["graph"] = {"eager_cloud_built_once_ms": eager_built, "graph_replay_ms": replay,
+                            "image_equal_to_eager": bool(torch.equal(img_g.detach(), want_img)),
+                            "grad_points_max_rel_diff": float((pts.grad - want_gp).abs().max() / want_gp.abs().max().clamp_min(1e-12)),
+                            "note": "forward + backward of the patched chain on a Pointclouds object built once; torch.cuda.graph capture of the whole "
+                                    "step (zeroing the .grad tensors included), replayed"}
+        except Exception as e:
+            out["graph"] = {"error": repr(e)[:400]}
     if args.check and args.mode == "patched":
         # the patched chain against the un-patched one (the reference's own Python over the same `_C`) in this process
         mine = {"image": image.detach().clone(), "gp": pts.grad.clone(), "gf": feats.grad.clone()}

@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 O=gpurun_out/r06c15
 mkdir -p $O
-for i in 1 2 3; do
+for i in 1 2; do
 for L in 1 0; do
 P3D_COVER_LIST=$L timeout 600 python bench.py --steps 100 --warmup 5 --no-cpu-baseline --no-dropin --no-reference-device --no-other-configs > $O/bench_${L}_$i.json 2> $O/bench.err
 python - <<PY

@@ -70,6 +70,10 @@ struct MeshArgs {
   // (its atomicOr returns 0): area_count[0] entries of area_list, zeroed with the cover.  Null without.
   int* area_count;
   int* area_list;
+  // ... or, when the tiles are the bins of a tile plan and coincide with the cover's words (image sides multiples of 16): every active
+  // tile writes its word into slot arank[tile] of the list at its START (a plain store, no atomic, nothing to wait for) and the count is
+  // the plan's number of active tiles -- a tile whose faces hit no pixel is listed too (the backward's wave finds no row and returns)
+  int list_by_plan;
   // short workspaces (binning.h): the device flag "the lists did not fit", or null.  A binned launch returns at once when
   // it is up, the naive launch that follows it returns at once when it is not: exactly one of the two writes the output.
   const int* overflow;
@@ -602,9 +606,13 @@ __device__ __forceinline__ void cover_mark(const MeshArgs& a, int n, int sy0, bo
     rem &= ~same;
     if (lane == 0) {
       const int word = (n * a.CY) * a.CX + w0;
-      const int before = atomicOr(a.cover + word, (int)bits);
-      // the first to mark this word lists it for the backward (which then needs no pass over the cover to find its work)
-      if (a.area_list != nullptr && before == 0 && bits != 0u) a.area_list[atomicAdd(a.area_count, 1)] = word;
+      if (a.area_list != nullptr && !a.list_by_plan) {
+        // the first to mark this word lists it for the backward (which then needs no pass over the cover to find its work)
+        const int before = atomicOr(a.cover + word, (int)bits);
+        if (before == 0 && bits != 0u) a.area_list[atomicAdd(a.area_count, 1)] = word;
+      } else {
+        atomicOr(a.cover + word, (int)bits);
+      }
     }
   }
 }
@@ -825,6 +833,13 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
     int row;
     if (blk < A) {
       row = a.csr.plan.order[blk];
+      if (a.list_by_plan && threadIdx.x == 0) {
+        // this tile's word of the cover into slot `blk` of the list: the backward then walks the areas longest list first, as this launch does
+        const int per = a.tm.BH * a.tm.BW;
+        const int ln = row / per, lrem = row - ln * per, lby = lrem / a.tm.BW, lbx = lrem - lby * a.tm.BW;
+        a.area_list[blk] = (ln * a.CY + (a.CY - 1 - lby)) * a.CX + (a.CX - 1 - lbx);
+        if (blk == 0) *a.area_count = (int)A;
+      }
     } else if (blk < A + B) {
       if (EXACT && (KT & 3) == 0 && A > 0) return;  // piggyback fill (below): the active workgroups write this tile
       row = a.csr.plan.bg_list[blk - A];
@@ -888,6 +903,12 @@ __global__ __launch_bounds__(kStage, WAVES) void mesh_raster_kernel(MeshArgs a) 
   if (piggy) {
     plan_a = a.csr.plan.hdr[0];
     plan_b = a.csr.plan.hdr[1];
+  }
+  if (BINNED && !SPLIT && a.list_by_plan && !listed && tid == 0) {
+    // (a plan without a tile order -- small launches: the slot is the tile's rank among the active tiles)
+    const int64_t row = ((int64_t)n * a.tm.BH + by) * a.tm.BW + bx;
+    if (count > 0) a.area_list[a.csr.plan.arank[row]] = (n * a.CY + (a.CY - 1 - by)) * a.CX + (a.CX - 1 - bx);
+    if (blockIdx.x == 0) *a.area_count = a.csr.plan.hdr[0];
   }
   if (count <= 0) {
     if (piggy && plan_a > 0) return;  // an active workgroup writes this tile (uniform)
@@ -1377,6 +1398,9 @@ int launch_mesh_raster_t(const MeshArgs& a0, hipStream_t stream) {
   const bool split = BINNED && !TIES && grid <= (unsigned)kSplitMaxTiles;
   // tiles in the plan's order: when the lists carry a tile plan and a tile is a bin (grid = bins = active + background rows)
   a.walk_plan = BINNED && !split && a.csr.plan.hdr != nullptr && a.csr.plan.order != nullptr && a.tm.Ty == 1 && a.tm.Tx == 1;
+  // the list of the cover's non-empty words from the plan instead of from atomics: tiles = bins = cover words
+  a.list_by_plan = a.walk_plan && a.area_list != nullptr && a.overflow == nullptr && a.tm.bin_size == kTile && a.H % kTile == 0 && a.W % kTile == 0 &&
+                   a.csr.plan.arank != nullptr;
   const size_t dyn_lds = 0;
 #define P3D_LAUNCH_FINE(KT_, REGS_, EXACT_, Q_) launch_fine_variant<Q_, KT_, REGS_, BINNED, EXACT_, TIES>(a, grid, split, dyn_lds, stream)
 #define P3D_LAUNCH_FINE_W(KT_, WAVES_, Q_) mesh_raster_kernel<Q_, KT_, true, BINNED, false, WAVES_, false, false, TIES><<<grid, kStage, 0, stream>>>(a)
