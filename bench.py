@@ -636,7 +636,7 @@ def dropin_points_timing():
     out = {}
     for mode in ("c_only", "patched"):
         try:
-            res = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "dropin_points_timing.py"), "--mode", mode] + (["--graph"] if mode == "patched" else []), capture_output=True,
+            res = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "dropin_points_timing.py"), "--mode", mode], capture_output=True,
                                  text=True, timeout=300, cwd=ROOT, env=_child_env())
             lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
             out[mode] = json.loads(lines[-1]) if lines else {"value": None, "reason": (res.stderr or res.stdout)[-400:]}

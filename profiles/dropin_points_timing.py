@@ -40,7 +40,9 @@ def main():
     ap.add_argument("--check", action="store_true", help="compare with the reference's own device kernels under the same Python")
     ap.add_argument("--graph", action="store_true",
                     help="also: the same step on a Pointclouds built once, eager and captured in a HIP graph (torch.cuda.graph) and replayed -- "
-                         "what is left of the step when the host side and the launch gaps are taken out")
+                         "what is left of the step when the host side and the launch gaps are taken out.  EXPERIMENTAL: on this image "
+                         "(ROCm 7.2, torch 2.10) capture_end of the forward + backward capture dies with a segmentation fault inside "
+                         "the graph instantiation (profiles/r06/c18/err.txt); bench.py does not pass this flag")
     args = ap.parse_args()
     stage = os.path.join(ROOT, "oracle", "_ref", "reference_py")
     ref_root = None
