@@ -174,6 +174,20 @@ int p3d_rasterize_meshes_backward_verts_with_cover_list(const float* face_verts,
                                                         int K, int perspective_correct, int clip_barycentric_coords,
                                                         float* grad_verts, p3d_stream_t stream);
 
+/* Per-face reciprocals for the backward (round 6; the reference has no counterpart: its backward re-derives them per sample,
+ * geometry_utils.cuh:101-161, 365-385).  p3d_gather_face_verts_pre is p3d_gather_face_verts with a thread per face that also writes
+ * face_pre (F, 4) f32, 16-byte aligned: 1 / (barycentric area), 1 / |v1 - v0|^2, 1 / |v2 - v0|^2, 1 / |v2 - v1|^2 (-1 where the squared
+ * length is <= 1e-8: the degenerate-edge rule).  p3d_rasterize_meshes_backward_verts_pre is
+ * p3d_rasterize_meshes_backward_verts_with_cover_list (cover_and_list may be null: then every row is read) reading those instead of
+ * forming them per sample; face_pre null: identical to the _with_cover_list form.  face_pre must belong to THESE face_verts. */
+int p3d_gather_face_verts_pre(const float* verts, const int64_t* faces, int64_t V, int64_t F, float* face_verts, float* face_pre,
+                              p3d_stream_t stream);
+int p3d_rasterize_meshes_backward_verts_pre(const float* face_verts, const float* face_pre, const int64_t* faces,
+                                            const int64_t* pix_to_face, const float* grad_zbuf, const float* grad_bary,
+                                            const float* grad_dists, const int32_t* cover_and_list, int64_t F, int64_t V, int N, int H,
+                                            int W, int K, int perspective_correct, int clip_barycentric_coords, float* grad_verts,
+                                            p3d_stream_t stream);
+
 /* CUDA tie order -- p3d_rasterize_meshes_with_cover, then a replay that makes pix_to_face (and the rows that go with it) what
  * the reference's CUDA kernels return where faces tie EXACTLY in depth at a pixel's K-th place.  The kernels of this library keep
  * the K nearest under the total order (depth, face index), as the reference's CPU and Python implementations do

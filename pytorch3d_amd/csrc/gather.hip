@@ -8,6 +8,7 @@
 // in LDS before it touches memory with hardware f32 atomics.
 // SURVEY section 8(f) row 3; optional entry points, `pytorch3d._C` is unchanged.
 #include "p3d_common.h"
+#include "p3d_geom.h"
 #include "wave_table.h"
 
 namespace p3d {
@@ -29,6 +30,32 @@ __global__ __launch_bounds__(256) void gather_faces_kernel(const float* __restri
     d[0] = ok ? s[0] : nan;
     d[1] = ok ? s[1] : nan;
     d[2] = ok ? s[2] : nan;
+  }
+}
+
+// The same gather with a thread per FACE, which also writes what the rasterizer's backward needs of the face alone
+// (p3d_geom.h: BwdFacePre -- 1 / area and 1 / |edge|^2 x 3, 16 bytes): p3d_gather_face_verts_pre.
+__global__ __launch_bounds__(256) void gather_faces_pre_kernel(const float* __restrict__ verts, const int64_t* __restrict__ faces,
+                                                               int64_t V, int64_t F, float* __restrict__ face_verts,
+                                                               float4* __restrict__ face_pre) {
+  for (int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x; f < F; f += (int64_t)gridDim.x * 256) {
+    float c[9];
+    const float nan = __int_as_float(0x7fc00000);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      int64_t v = faces[f * 3 + k];
+      if (v < 0) v += V;
+      const bool ok = v >= 0 && v < V;
+      const float* s = verts + (ok ? v : 0) * 3;
+      c[3 * k + 0] = ok ? s[0] : nan;
+      c[3 * k + 1] = ok ? s[1] : nan;
+      c[3 * k + 2] = ok ? s[2] : nan;
+    }
+    float* d = face_verts + f * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) d[k] = c[k];
+    const BwdFacePre r = bwd_face_pre_make(mk3(c[0], c[1], c[2]), mk3(c[3], c[4], c[5]), mk3(c[6], c[7], c[8]));
+    face_pre[f] = make_float4(r.inv_area, r.inv_l01, r.inv_l02, r.inv_l12);
   }
 }
 
@@ -82,6 +109,19 @@ P3D_API int p3d_gather_face_verts(const float* verts, const int64_t* faces, int6
   if (blocks > 256 * 16) blocks = 256 * 16;
   LaunchScope ls("gather_face_verts", s);
   gather_faces_kernel<<<(unsigned)blocks, 256, 0, s>>>(verts, faces, V, n, face_verts);
+  return launch_status();
+}
+
+P3D_API int p3d_gather_face_verts_pre(const float* verts, const int64_t* faces, int64_t V, int64_t F, float* face_verts,
+                                      float* face_pre, p3d_stream_t stream) {
+  if (V < 0 || F < 0) return P3D_ERR_INVALID_ARG;
+  if (F == 0) return P3D_OK;
+  if (!verts || !faces || !face_verts || !face_pre || ((uintptr_t)face_pre & 15u)) return P3D_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t blocks = ceil_div(F, 256);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  LaunchScope ls("gather_face_verts", s);
+  gather_faces_pre_kernel<<<(unsigned)blocks, 256, 0, s>>>(verts, faces, V, F, face_verts, reinterpret_cast<float4*>(face_pre));
   return launch_status();
 }
 

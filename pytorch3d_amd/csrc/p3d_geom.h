@@ -480,17 +480,12 @@ struct TriGrad {
 
 P3D_HD f2 add2(f2 a, f2 b) { return mk2(a.x + b.x, a.y + b.y); }
 
-P3D_HD TriGrad bary_coords_bwd(f2 p, f2 v0, f2 v1, f2 v2, f3 g) {
+// e: the three edge functions of p, inv_area = 1 / bary_area, inv_area2 = 1 / area^2 -- formed by the caller (face_sample_bwd), once
+P3D_HD TriGrad bary_coords_bwd(f2 p, f2 v0, f2 v1, f2 v2, f3 g, f3 e, float inv_area, float inv_area2) {
 #if defined(__clang__)
 #pragma clang fp contract(fast)  // gradient-only arithmetic (tolerance-gated): let mul+add fuse into FMA
 #endif
-  const float area = bary_area(v0, v1, v2);
-  const float area2 = area * area;
-  const float e0 = edge_fn(p, v1, v2);
-  const float e1 = edge_fn(p, v2, v0);
-  const float e2 = edge_fn(p, v0, v1);
-  const float inv_area = qdiv<true>(1.0f, area);
-  const float inv_area2 = qdiv<true>(1.0f, area2);
+  const float e0 = e.x, e1 = e.y, e2 = e.z;
 
   // w_k = e_k / area with e0 = edge_fn(p, v1, v2), e1 = edge_fn(p, v2, v0), e2 = edge_fn(p, v0, v1), area = edge_fn(v2, v0, v1)
   // (geometry_utils.cuh:101-161).  Numerators: one edge_fn_bwd each.  Denominator: the reference runs edge_fn_bwd(v2, v0, v1, .)
@@ -551,8 +546,37 @@ struct FaceGrad {
   float g[9];
 };
 
+// What a sample's gradient needs of its FACE alone (round 6): the reciprocal of the barycentric area and of the three squared edge
+// lengths (negative: the edge is degenerate, squared length <= 1e-8, geometry_utils.cuh:345).  The backward formed them per SAMPLE
+// -- five v_rcp_f32 (quarter rate), the area's double-precision epsilon add, three compares: a tenth of a step's vector time at the
+// bench workload, where a face is sampled ~230 times.  The face gather of the forward writes one 16-byte record per face
+// (p3d_gather_face_verts_pre), the backward gathers it beside the 36 bytes of vertices.  Same instructions on the same operands as
+// the per-sample form (v_rcp_f32 is deterministic); 1 / area^2 becomes (1 / area)^2 (gradient arithmetic, tolerance-gated).
+struct BwdFacePre {
+  float inv_area, inv_l01, inv_l02, inv_l12;
+};
+
+P3D_HD BwdFacePre bwd_face_pre_make(f3 v0, f3 v1, f3 v2) {
+  const f2 a = mk2(v0.x, v0.y), b = mk2(v1.x, v1.y), c = mk2(v2.x, v2.y);
+  BwdFacePre r;
+  r.inv_area = qdiv<true>(1.0f, bary_area(a, b, c));
+  const f2 es[3] = {a, a, b}, ee[3] = {b, c, c};
+  float inv[3];
+  for (int i = 0; i < 3; ++i) {
+    const float bax = ee[i].x - es[i].x, bay = ee[i].y - es[i].y;
+    const float l2 = bax * bax + bay * bay;
+    inv[i] = (l2 <= 1e-8f) ? -1.0f : qdiv<true>(1.0f, l2);
+  }
+  r.inv_l01 = inv[0];
+  r.inv_l02 = inv[1];
+  r.inv_l12 = inv[2];
+  return r;
+}
+
+template <bool PRE = false>
 P3D_HD FaceGrad face_sample_bwd(f3 v0, f3 v1, f3 v2, f2 p, float g_zbuf, f3 g_bary, float g_dist,
-                                bool perspective_correct, bool clip_bary, bool clip_bwd_on_corrected) {
+                                bool perspective_correct, bool clip_bary, bool clip_bwd_on_corrected,
+                                BwdFacePre pre = BwdFacePre()) {
 #if defined(__clang__)
 #pragma clang fp contract(fast)  // gradient-only arithmetic (tolerance-gated): let mul+add fuse into FMA
 #endif
@@ -567,7 +591,17 @@ P3D_HD FaceGrad face_sample_bwd(f3 v0, f3 v1, f3 v2, f2 p, float g_zbuf, f3 g_ba
   const float z0 = v0.z, z1 = v1.z, z2 = v2.z;
   // ---- forward recompute: only signs of bw / bp decide anything here (inside test, clip masks), and the sign of a quotient does
   // not depend on how the division rounds
-  const f3 bw = bary_coords<true>(p, a, b, c);
+  const f3 e = mk3(edge_fn(p, b, c), edge_fn(p, c, a), edge_fn(p, a, b));
+  float inv_area, inv_area2;
+  if (PRE) {
+    inv_area = pre.inv_area;
+    inv_area2 = inv_area * inv_area;
+  } else {
+    const float area = bary_area(a, b, c);
+    inv_area = qdiv<true>(1.0f, area);
+    inv_area2 = qdiv<true>(1.0f, area * area);
+  }
+  const f3 bw = mk3(e.x * inv_area, e.y * inv_area, e.z * inv_area);
   f3 bp = bw;
   float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, inv_denom = 0.0f;
   if (perspective_correct) {
@@ -592,14 +626,24 @@ P3D_HD FaceGrad face_sample_bwd(f3 v0, f3 v1, f3 v2, f2 p, float g_zbuf, f3 g_ba
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const float bax = ee[i].x - es[i].x, bay = ee[i].y - es[i].y;
-    const float l2 = bax * bax + bay * bay;
-    const float t = sat01(qdiv<true>(bax * (p.x - es[i].x) + bay * (p.y - es[i].y), l2));
+    const float dot = bax * (p.x - es[i].x) + bay * (p.y - es[i].y);
+    float t;
+    bool degenerate;
+    if (PRE) {
+      const float inv = i == 0 ? pre.inv_l01 : (i == 1 ? pre.inv_l02 : pre.inv_l12);
+      degenerate = inv < 0.0f;
+      t = sat01(dot * inv);
+    } else {
+      const float l2 = bax * bax + bay * bay;
+      degenerate = l2 <= 1e-8f;
+      t = sat01(qdiv<true>(dot, l2));
+    }
     const float qx = (es[i].x + t * bax) - p.x, qy = (es[i].y + t * bay) - p.y;
     const float px = p.x - ee[i].x, py = p.y - ee[i].y;
     et[i] = t;
     ex[i] = qx;
     ey[i] = qy;
-    ed[i] = (l2 <= 1e-8f) ? px * px + py * py : qx * qx + qy * qy;
+    ed[i] = degenerate ? px * px + py * py : qx * qx + qy * qy;
   }
   // which edge is closest; 3 = none (NaN distances).  The three candidate branches of the reference are folded into ONE
   // evaluation on selected values: lanes of a wave pick different edges, and divergent branches would run it three times.
@@ -631,7 +675,7 @@ P3D_HD FaceGrad face_sample_bwd(f3 v0, f3 v1, f3 v2, f2 p, float g_zbuf, f3 g_ba
     dz2 = g0 * bw.x * z1 + g1 * bw.y * z0;
     gb = mk3(g0 * z1 * z2, g1 * z0 * z2, g2p * z0 * z1);
   }
-  const TriGrad dbw = bary_coords_bwd(p, a, b, c, gb);
+  const TriGrad dbw = bary_coords_bwd(p, a, b, c, gb, e, inv_area, inv_area2);
 
   FaceGrad r;
   r.g[0] = dbw.d0.x + dd0.x;

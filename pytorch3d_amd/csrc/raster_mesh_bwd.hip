@@ -60,6 +60,7 @@ struct BwdArgs {
   int persp, clip;
   const int* cover;  // row cover written by the forward (p3d_rasterize_meshes_with_cover) or null; (N, CY, CX) words
   int CY, CX;
+  const float4* face_pre;  // (F) per-face reciprocals (p3d_geom.h: BwdFacePre, written by p3d_gather_face_verts_pre) or null
 };
 
 // Rows of the wave's 16 x 16 area that may hold a sample (bit r: row ay + r); all of them without a cover.
@@ -382,7 +383,8 @@ __device__ __forceinline__ void run_reduce(int& f, float (&g)[9], int lane) {
 
 // PC: perspective_correct && clip_barycentric_coords are known to be set (what the renderer uses for perspective cameras with blur,
 // as in the forward's PC kernels): the step's arithmetic is one basic block instead of five behind uniform flag branches.
-template <int KT, bool TO_VERTS, bool PC = false>
+// PRE: the per-face reciprocals come from a.face_pre (one 16-byte gather per sample) instead of five v_rcp_f32 per sample.
+template <int KT, bool TO_VERTS, bool PC = false, bool PRE = false>
 __global__ __launch_bounds__(256, RowsCfg<KT>::kWaves) void mesh_backward_rows_kernel(BwdArgs a) {
   constexpr int SPR = KT / 4;  // steps per 16-pixel row segment
   constexpr int PIX = RowsCfg<KT>::kPix;
@@ -476,7 +478,15 @@ __global__ __launch_bounds__(256, RowsCfg<KT>::kWaves) void mesh_backward_rows_k
 #pragma unroll
       for (int c = 1; c < SPR; ++c) pxs = s == c ? px[c] : pxs;
       const f2 p = mk2(pxs, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py_rows), r)));
-      g = face_sample_bwd(mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), mk3(q[6], q[7], q[8]), p, gz, gb, gd, persp, clip, false);
+      BwdFacePre pre = BwdFacePre();
+      if constexpr (PRE) {
+        const float4 r = a.face_pre[f];
+        pre.inv_area = r.x;
+        pre.inv_l01 = r.y;
+        pre.inv_l02 = r.z;
+        pre.inv_l12 = r.w;
+      }
+      g = face_sample_bwd<PRE>(mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), mk3(q[6], q[7], q[8]), p, gz, gb, gd, persp, clip, false, pre);
     } else {
 #pragma unroll
       for (int j = 0; j < 9; ++j) g.g[j] = 0.0f;  // read by the neighbours' shifts, never added
@@ -514,8 +524,9 @@ unsigned scatter_multiplier(uint64_t items) {
 int launch_mesh_backward(const float* face_verts, const int64_t* faces, int64_t V, const int64_t* p2f, const float* grad_zbuf,
                          const float* grad_bary, const float* grad_dists, int N, int H, int W, int K, int persp, int clip,
                          float* grad_out, const int32_t* cover, void* workspace, size_t workspace_bytes, hipStream_t s,
-                         bool cover_has_list = false) {
+                         bool cover_has_list = false, const float* face_pre = nullptr) {
   BwdArgs a;
+  a.face_pre = reinterpret_cast<const float4*>(face_pre);
   a.V = V;
   a.face_verts = face_verts;
   a.p2f = p2f;
@@ -568,11 +579,13 @@ int launch_mesh_backward(const float* face_verts, const int64_t* faces, int64_t 
     case 1: mesh_backward_kernel<1, TV><<<grid, 256, 0, s>>>(a); break;          \
     case 2: mesh_backward_kernel<2, TV><<<grid, 256, 0, s>>>(a); break;          \
     case 4:                                                                      \
-      if (pc) mesh_backward_rows_kernel<4, TV, true><<<grid, 256, 0, s>>>(a);    \
+      if (pc && a.face_pre) mesh_backward_rows_kernel<4, TV, true, true><<<grid, 256, 0, s>>>(a); \
+      else if (pc) mesh_backward_rows_kernel<4, TV, true><<<grid, 256, 0, s>>>(a); \
       else mesh_backward_rows_kernel<4, TV><<<grid, 256, 0, s>>>(a);             \
       break;                                                                     \
     case 8:                                                                      \
-      if (pc) mesh_backward_rows_kernel<8, TV, true><<<grid, 256, 0, s>>>(a);    \
+      if (pc && a.face_pre) mesh_backward_rows_kernel<8, TV, true, true><<<grid, 256, 0, s>>>(a); \
+      else if (pc) mesh_backward_rows_kernel<8, TV, true><<<grid, 256, 0, s>>>(a); \
       else mesh_backward_rows_kernel<8, TV><<<grid, 256, 0, s>>>(a);             \
       break;                                                                     \
     case 16: mesh_backward_rows_kernel<16, TV><<<grid, 256, 0, s>>>(a); break;   \
@@ -687,4 +700,19 @@ P3D_API int p3d_rasterize_meshes_backward_verts_with_cover_list(const float* fac
   if (!face_verts || !faces || !p2f || !grad_zbuf || !grad_bary || !grad_dists) return P3D_ERR_INVALID_ARG;
   return launch_mesh_backward(face_verts, faces, V, p2f, grad_zbuf, grad_bary, grad_dists, N, H, W, K, persp, clip, grad_verts,
                               cover_and_list, nullptr, 0, s, cover_and_list != nullptr);
+}
+
+P3D_API int p3d_rasterize_meshes_backward_verts_pre(const float* face_verts, const float* face_pre, const int64_t* faces, const int64_t* p2f,
+                                                    const float* grad_zbuf, const float* grad_bary, const float* grad_dists,
+                                                    const int32_t* cover_and_list, int64_t F, int64_t V, int N, int H, int W, int K,
+                                                    int persp, int clip, float* grad_verts, p3d_stream_t stream) {
+  if (F < 0 || V < 0 || N < 0 || H < 0 || W < 0 || K < 0) return P3D_ERR_INVALID_ARG;
+  if (V == 0) return P3D_OK;
+  if (!grad_verts) return P3D_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(grad_verts, 0, (size_t)V * 3 * sizeof(float), s) != hipSuccess) return P3D_ERR_LAUNCH;
+  if (F == 0 || (int64_t)N * H * W * K == 0) return P3D_OK;
+  if (!face_verts || !faces || !p2f || !grad_zbuf || !grad_bary || !grad_dists || ((uintptr_t)face_pre & 15u)) return P3D_ERR_INVALID_ARG;
+  return launch_mesh_backward(face_verts, faces, V, p2f, grad_zbuf, grad_bary, grad_dists, N, H, W, K, persp, clip, grad_verts,
+                              cover_and_list, nullptr, 0, s, cover_and_list != nullptr, face_pre);
 }

@@ -7,10 +7,15 @@ runs on the HIP kernels of pytorch3d_amd.clip.
 """
 from typing import List, Optional, Tuple, Union
 
+import os
+
 import numpy as np
 import torch
 
 from . import _C
+
+# the fused gather also writes the backward's per-face reciprocals (P3D_FACE_PRE=0: the backward forms them per sample)
+FACE_PRE = os.environ.get("P3D_FACE_PRE", "1") not in ("", "0")
 
 kMaxFacesPerBin = 22  # rasterize_meshes.py:29
 
@@ -211,14 +216,20 @@ class _RasterizeMeshVerts(torch.autograd.Function):
         V, F = verts_c.shape[0], faces_c.shape[0]
         with torch.cuda.device(verts.device):
             face_verts = torch.empty((F, 3, 3), dtype=torch.float32, device=verts.device)
-            if F:
+            # per-face reciprocals for the backward (include/p3d_amd.h: p3d_gather_face_verts_pre), written by the gather
+            face_pre = torch.empty((F, 4), dtype=torch.float32, device=verts.device) if (FACE_PRE and ctx.needs_input_grad[0]) else None
+            if F and face_pre is not None:
+                rc = lib.p3d_gather_face_verts_pre(_C._ptr(verts_c), _C._ptr(faces_c), V, F, _C._ptr(face_verts), _C._ptr(face_pre),
+                                                   _C._stream(verts.device))
+                _lib.check(rc, "gather_face_verts_pre")
+            elif F:
                 rc = lib.p3d_gather_face_verts(_C._ptr(verts_c), _C._ptr(faces_c), V, F, _C._ptr(face_verts),
                                                _C._stream(verts.device))
                 _lib.check(rc, "gather_face_verts")
         (pix_to_face, zbuf, barycentric_coords, dists), cover = _C._rasterize_meshes_covered(
             face_verts, mesh_to_face_first_idx, num_faces_per_mesh, clipped_faces_neighbor_idx, image_size, blur_radius,
             faces_per_pixel, bin_size, max_faces_per_bin, perspective_correct, clip_barycentric_coords, cull_backfaces)
-        ctx.save_for_backward(face_verts, faces_c, pix_to_face, cover)
+        ctx.save_for_backward(face_verts, faces_c, pix_to_face, cover, face_pre)
         ctx.mark_non_differentiable(pix_to_face)
         ctx.set_materialize_grads(False)
         ctx.V = V
@@ -229,7 +240,7 @@ class _RasterizeMeshVerts(torch.autograd.Function):
     def backward(ctx, grad_pix_to_face, grad_zbuf, grad_barycentric_coords, grad_dists):
         from . import _lib
 
-        face_verts, faces, pix_to_face, cover = ctx.saved_tensors
+        face_verts, faces, pix_to_face, cover, face_pre = ctx.saved_tensors
 
         cover = _C.checked_cover(pix_to_face, cover)  # (P3D_CHECK=1: verified on the device before it is trusted)
         if grad_zbuf is None and grad_barycentric_coords is None and grad_dists is None:
@@ -244,7 +255,13 @@ class _RasterizeMeshVerts(torch.autograd.Function):
         lib = _lib.load()
         with torch.cuda.device(dev):
             grad_verts = torch.empty((ctx.V, 3), dtype=torch.float32, device=dev)
-            if _C.cover_has_list(cover, N, H, W):  # the forward listed the areas that hold a face: no list builder, no workspace
+            has_list = _C.cover_has_list(cover, N, H, W)
+            if face_pre is not None and (has_list or cover is None):
+                rc = lib.p3d_rasterize_meshes_backward_verts_pre(
+                    _C._ptr(face_verts), _C._ptr(face_pre), _C._ptr(faces), _C._ptr(pix_to_face), _C._ptr(gz), _C._ptr(gb), _C._ptr(gd),
+                    _C.cover_ptr(cover, N, H, W), faces.shape[0], ctx.V, N, H, W, K, ctx.flags[0], ctx.flags[1], _C._ptr(grad_verts),
+                    _C._stream(dev))
+            elif has_list:  # the forward listed the areas that hold a face: no list builder, no workspace
                 rc = lib.p3d_rasterize_meshes_backward_verts_with_cover_list(
                     _C._ptr(face_verts), _C._ptr(faces), _C._ptr(pix_to_face), _C._ptr(gz), _C._ptr(gb), _C._ptr(gd),
                     _C.cover_ptr(cover, N, H, W), faces.shape[0], ctx.V, N, H, W, K, ctx.flags[0], ctx.flags[1], _C._ptr(grad_verts),

@@ -350,6 +350,79 @@ def test_backward_every_kernel_vs_oracle(K):
         U.assert_face_grads_vs_truth(f"backward K={K} {tag}", got.cpu(), fv, p2f.cpu(), gz.cpu(), gb.cpu(), gd.cpu(), True, True, rtol=2e-3)
 
 
+@pytest.mark.parametrize("K", [4, 8])
+def test_backward_with_per_face_reciprocals(K):
+    """p3d_gather_face_verts_pre + p3d_rasterize_meshes_backward_verts_pre (round 6): the gather writes 1 / area and 1 / |edge|^2 per
+    face (-1 for an edge of squared length <= 1e-8: geometry_utils.cuh:345), the perspective + clip backward reads them instead of
+    forming them per sample.  A soup with needles (one degenerate edge each) and slivers: the records against torch, the gradient
+    against the float64 restatement and against the backward that forms them per sample, with and without the cover list."""
+    from pytorch3d_amd import _C, _lib
+
+    d = _dev()
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(900 + K)
+    F = 700
+    fv = U.smooth_soup(F, gen, size=3.0)
+    for j, i in enumerate(torch.randperm(F, generator=gen)[:60].tolist()):
+        a, b = (0, 1) if j % 3 == 0 else ((1, 2) if j % 3 == 1 else (2, 0))
+        step = (torch.rand(2, generator=gen) - 0.5) * (3e-4 if j % 2 else 2e-5)  # both sides of the 1e-4 threshold
+        fv[i, b, :2] = fv[i, a, :2] + step
+    verts = fv.reshape(-1, 3).contiguous().to(d)  # every face owns its vertices: grad_verts IS grad_face_verts
+    faces = torch.arange(3 * F, dtype=torch.int64).reshape(F, 3).to(d)
+    faces[5] = faces[5] - 3 * F  # negative ids wrap once, as torch indexing
+    first, count = U.split_counts(F, 2)
+    nbr = torch.full((F,), -1, dtype=torch.int64)
+    face_verts = torch.empty((F, 3, 3), device=d)
+    pre = torch.empty((F, 4), device=d)
+    _lib.check(lib.p3d_gather_face_verts_pre(_C._ptr(verts), _C._ptr(faces), 3 * F, F, _C._ptr(face_verts), _C._ptr(pre),
+                                             _C._stream(d)), "gather_face_verts_pre")
+    assert torch.equal(face_verts.cpu(), fv)
+    v0, v1, v2 = fv[:, 0, :2], fv[:, 1, :2], fv[:, 2, :2]
+    cross = lambda a, b: a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]  # float32, product by product: geometry_utils.cuh:63
+    area = (cross(v2 - v0, v1 - v0).double() + 1e-8).float().double()  # edge function of (v2; v0, v1) + kEpsilon, :108
+    want = [1.0 / area]
+    for a, b in ((v0, v1), (v0, v2), (v1, v2)):
+        l2 = ((b - a) ** 2).sum(1)
+        want.append(torch.where(l2 <= 1e-8, torch.full_like(l2, -1.0), 1.0 / l2).double())
+    got = pre.cpu().double()
+    assert int((got[:, 1:] == -1).sum()) > 20, "no degenerate edge in the soup"
+    for c in range(4):
+        sel = (want[c] == -1) | (got[:, c] == -1)
+        assert torch.equal(got[sel, c], want[c][sel]), f"record column {c}: the degenerate edges differ"
+        rel = ((got[~sel, c] - want[c][~sel]).abs() / want[c][~sel].abs()).max()
+        assert float(rel) < 2e-6, (c, float(rel))
+
+    size, blur = (40, 56), 2e-3
+    (p2f, zbuf, bary, dists), cover = _C._rasterize_meshes_covered(face_verts, first.to(d), count.to(d), nbr.to(d), size, blur, K, 8, 1000,
+                                                                    True, True, False)
+    assert _C.cover_has_list(cover, 2, *size)
+    gz = torch.randn(zbuf.shape, generator=gen).to(d)
+    gb = torch.randn(bary.shape, generator=gen).to(d)
+    gd = torch.randn(dists.shape, generator=gen).to(d)
+
+    def backward(with_pre, with_cover):
+        out = torch.full((3 * F, 3), float("nan"), device=d)
+        rc = lib.p3d_rasterize_meshes_backward_verts_pre(
+            _C._ptr(face_verts), _C._ptr(pre) if with_pre else None, _C._ptr(faces), _C._ptr(p2f), _C._ptr(gz), _C._ptr(gb), _C._ptr(gd),
+            _C.cover_ptr(cover, 2, *size) if with_cover else None, F, 3 * F, 2, size[0], size[1], K, 1, 1, _C._ptr(out), _C._stream(d))
+        _lib.check(rc, "backward_verts_pre")
+        return out.cpu().reshape(F, 3, 3)  # (face 5's wrapped ids address its own rows)
+
+    plain = backward(False, True)
+    for with_cover in (True, False):
+        got = backward(True, with_cover)
+        U.assert_face_grads_vs_truth(f"backward with face records K={K} cover={with_cover}", got, fv, p2f.cpu(), gz.cpu(), gb.cpu(),
+                                     gd.cpu(), True, True, rtol=2e-3, reference=plain)
+    # not perspective + clip: the records are ignored, not misread
+    out = torch.empty((3 * F, 3), device=d)
+    _lib.check(lib.p3d_rasterize_meshes_backward_verts_pre(
+        _C._ptr(face_verts), _C._ptr(pre), _C._ptr(faces), _C._ptr(p2f), _C._ptr(gz), _C._ptr(gb), _C._ptr(gd), None, F, 3 * F, 2,
+        size[0], size[1], K, 0, 0, _C._ptr(out), _C._stream(d)), "backward_verts_pre")
+    want_ff = _C.rasterize_meshes_backward(face_verts, p2f.clone(), gz, gb, gd, False, False)
+    U.assert_face_grads_vs_truth(f"backward with face records K={K}, flat", out.cpu().reshape(F, 3, 3), fv, p2f.cpu(), gz.cpu(), gb.cpu(),
+                                 gd.cpu(), False, False, rtol=2e-3, reference=want_ff.cpu())
+
+
 def test_autograd_mirror_and_reference_cpu_build():
     """The L2 mirror end to end (verts -> loss -> grad), against the reference's own CPU kernels when
     oracle/_ref is present (idx exact, floats 1e-5, grads rtol 5e-3 as tests/test_rasterize_meshes.py:317-319)."""
