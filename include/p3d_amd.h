@@ -299,6 +299,27 @@ int p3d_rasterize_points_fine(const float* points, const int32_t* bin_points, co
                               int BH, int BW, int M, int H, int W, int bin_size, int points_per_pixel, int32_t* idxs,
                               float* zbuf, float* dists, void* workspace, size_t workspace_bytes, p3d_stream_t stream);
 
+/* PointsRenderer's chain as two launches (round 6; renderer/points/renderer.py:56-76: fragments = rasterize_points(...),
+ * weights = 1 - dists / r^2, images = alpha_composite(idx, weights, features)).  The reference has no single operator for it; the
+ * patched PointsRenderer (pytorch3d_amd.shim) and pytorch3d_amd.render_points call these.
+ *   p3d_rasterize_points_composite: p3d_rasterize_points (same arguments, same workspace, same idxs / zbuf / dists) that also writes
+ *     images (N, H, W, C) f32 = the alpha compositing (alpha_composite.cu:24-68) of features (P, C) f32 rows, C in 1..4, with
+ *     alpha = 1 - dists * inv_r2, inv_r2 = float(1) / float(r * r) (how torch evaluates `dists / (r * r)`): the pixel is formed in the
+ *     fine kernel's epilogue while its K entries are in LDS (K <= 28, binned, full workspace), else by a pass behind the rasterizer.
+ *     Bit-equal to the three operators run one after the other.
+ *   p3d_rasterize_points_composite_backward: grad_points (P, 3) [z column zero: the chain does not expose zbuf] and grad_features
+ *     (P, C), both fully written, from grad_images (N, H, W, C): alphaCompositeCudaBackwardKernel (alpha_composite.cu:72-141),
+ *     grad_dists = -grad_alphas * inv_r2 and RasterizePointsBackwardCudaKernel (rasterize_points.cu:366-411) as ONE kernel whose two
+ *     scatters share a wave-private table.  K <= 16, C in 1..4 (P3D_ERR_INVALID_ARG otherwise: run the three operators instead). */
+int p3d_rasterize_points_composite(const float* points, const int64_t* cloud_to_packed_first_idx, const int64_t* num_points_per_cloud,
+                                   const float* radius, const float* features, int64_t P, int C, int N, int H, int W,
+                                   int points_per_pixel, int bin_size, int max_points_per_bin, float inv_r2, int32_t* idxs,
+                                   float* zbuf, float* dists, float* images, void* workspace, size_t workspace_bytes,
+                                   p3d_stream_t stream);
+int p3d_rasterize_points_composite_backward(const float* points, const float* features, const int32_t* idxs, const float* dists,
+                                            const float* grad_images, int64_t P, int C, int N, int H, int W, int points_per_pixel,
+                                            float inv_r2, float* grad_points, float* grad_features, p3d_stream_t stream);
+
 /* replaces RasterizePointsBackward, rasterize_points.h:281-305 (_C.rasterize_points_backward). */
 int p3d_rasterize_points_backward(const float* points, const int32_t* idxs, const float* grad_zbuf,
                                   const float* grad_dists, int64_t P, int N, int H, int W, int K, float* grad_points,

@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--mode", default="c_only", choices=["c_only", "patched"],
                     help="patched: shim.install(patch_python=True) -- PointsRasterizer.forward transforms the PACKED points in one launch, "
                          "the compositing functions run as one autograd node without clones")
+    ap.add_argument("--no-fuse", action="store_true",
+                    help="patched mode without the fused PointsRenderer node (pytorch3d_amd.render_points): the operator chain of rounds 4-5")
     ap.add_argument("--check", action="store_true", help="compare with the reference's own device kernels under the same Python")
     ap.add_argument("--graph", action="store_true",
                     help="also: the same step on a Pointclouds built once, eager and captured in a HIP graph (torch.cuda.graph) and replayed -- "
@@ -68,6 +70,7 @@ def main():
 
     if args.mode == "patched":
         shim.patch_reference_python()
+        shim.FUSE_POINTS_RENDERER = not args.no_fuse
     from pytorch3d_amd import _lib
 
     d = torch.device("cuda:0")
@@ -102,7 +105,7 @@ def main():
     wall = (time.perf_counter() - t0) / args.steps * 1e3
     lib.p3d_profile_enable(0)
     kern = {k: round(ms / args.steps, 4) for k, (n, ms) in sorted(_lib.profile_snapshot().items())}
-    out = {"mode": args.mode, "chain": "PointsRenderer(PointsRasterizer, AlphaCompositor) fwd + sum(image*g).backward() to points and features, "
+    out = {"mode": args.mode + ("" if args.mode != "patched" or args.no_fuse else " (fused PointsRenderer node)"), "chain": "PointsRenderer(PointsRasterizer, AlphaCompositor) fwd + sum(image*g).backward() to points and features, "
                     "unmodified reference classes over pytorch3d._C = pytorch3d_amd",
            "points": P, "image_size": H, "points_per_pixel": K, "radius": r, "ms_per_step": wall, "steps": args.steps,
            "Mpix_s": H * H / (wall * 1e-3) / 1e6, "our_kernels_ms_per_step": kern, "our_kernels_sum_ms": round(sum(kern.values()), 4),

@@ -617,6 +617,74 @@ def rasterize_points_backward(points, idxs, grad_zbuf, grad_dists):
     return out
 
 
+def inv_r2_of(radius):
+    """float32(1) / float32(r * r): `dists / (r * r)` with a Python scalar is a multiplication by this on the device
+    (renderer/points/renderer.py:62-64 under torch's div-by-scalar kernel)."""
+    import numpy as np
+
+    return float(np.float32(1.0) / np.float32(float(radius) * float(radius)))
+
+
+def rasterize_points_composite(points, cloud_to_packed_first_idx, num_points_per_cloud, image_size, radius, features, inv_r2,
+                               points_per_pixel, bin_size, max_points_per_bin):
+    """include/p3d_amd.h: p3d_rasterize_points_composite.  rasterize_points's arguments + features (P, C), C in 1..4, and inv_r2
+    (inv_r2_of).  Returns (idxs int32, zbuf, dists2, images (N, H, W, C))."""
+    dev = _same_device(("points", points), ("cloud_to_packed_first_idx", cloud_to_packed_first_idx),
+                       ("num_points_per_cloud", num_points_per_cloud), ("radius", radius), ("features", features))
+    _check_points(points)
+    if radius.dim() != 1 or radius.size(0) != points.size(0):
+        raise RuntimeError("radius must be of shape (P,)")
+    if features.dim() != 2 or features.size(0) != points.size(0) or not 1 <= features.size(1) <= 4:
+        raise RuntimeError("features must be of shape (P, C) with C in 1..4")
+    K = int(points_per_pixel)
+    _check_k(K)
+    H, W = _hw(image_size)
+    bin_size, M = int(bin_size), int(max_points_per_bin)
+    binned = bin_size > 0 and M > 0
+    if binned:
+        _num_bins(H, W, bin_size, "RasterizeCoarseCuda")
+    pts, rad, feats = _c(points, torch.float32), _c(radius, torch.float32), _c(features, torch.float32)
+    first, count = _c(cloud_to_packed_first_idx, torch.int64), _c(num_points_per_cloud, torch.int64)
+    N, P, C = count.size(0), pts.size(0), feats.size(1)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        out = _point_outputs(N, H, W, K, dev)
+        images = torch.empty((N, H, W, C), dtype=torch.float32, device=dev)
+        if images.numel() == 0:
+            return out + (images,)
+        ws, need, need_at, entries = _mesh_workspace(lib, P, N, H, W, bin_size, M, dev, "points") if binned else (_workspace(0, dev), None, 0, None)
+        rc = lib.p3d_rasterize_points_composite(_ptr(pts), _ptr(first), _ptr(count), _ptr(rad), _ptr(feats), P, C, N, H, W, K,
+                                                bin_size if binned else 0, M if binned else 0, float(inv_r2), _ptr(out[0]), _ptr(out[1]),
+                                                _ptr(out[2]), _ptr(images), _ptr(ws), ws.numel(), _stream(dev))
+        _lib.check(rc, "rasterize_points_composite")
+        if need is not None:
+            need.report_later(ws, need_at, entries)
+    return out + (images,)
+
+
+def rasterize_points_composite_backward(points, features, idxs, dists, grad_images, inv_r2):
+    """include/p3d_amd.h: p3d_rasterize_points_composite_backward.  Returns (grad_points (P, 3), grad_features (P, C))."""
+    dev = _same_device(("points", points), ("features", features), ("idxs", idxs), ("dists", dists), ("grad_images", grad_images))
+    if torch.are_deterministic_algorithms_enabled() and not torch.is_deterministic_algorithms_warn_only_enabled():
+        raise RuntimeError("RasterizePointsBackwardCuda does not have a deterministic implementation")
+    pts, feats = _c(points, torch.float32), _c(features, torch.float32)
+    ix, ds, gi = _c(idxs, torch.int32), _c(dists, torch.float32), _c(grad_images, torch.float32)
+    N, H, W, K = ix.shape
+    P, C = pts.size(0), feats.size(1)
+    if tuple(gi.shape) != (N, H, W, C):
+        raise RuntimeError("grad_images must be of shape (N, H, W, C)")
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        gp = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        gf = torch.empty((P, C), dtype=torch.float32, device=dev)
+        if P == 0:
+            return gp, gf
+        rc = lib.p3d_rasterize_points_composite_backward(_ptr(pts), _ptr(feats), _ptr(ix), _ptr(ds), _ptr(gi), P, C, N, H, W, K,
+                                                         float(inv_r2), _ptr(gp), _ptr(gf), _stream(dev))
+        _lib.check(rc, "rasterize_points_composite_backward")
+    return gp, gf
+
+
 # ----------------------------------------------------------------------------------------------
 # compositors
 # ----------------------------------------------------------------------------------------------

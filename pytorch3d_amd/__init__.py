@@ -17,6 +17,7 @@ from .compositing import alpha_composite, norm_weighted_sum, weighted_sum  # noq
 from .interp_face_attrs import interpolate_face_attributes  # noqa: F401
 from .rasterize_meshes import rasterize_meshes, rasterize_meshes_world  # noqa: F401
 from .rasterize_points import rasterize_points  # noqa: F401
+from .render_points import render_points_alpha  # noqa: F401
 from .shading import (flat_shading, gouraud_shading, phong_shading, phong_shading_vertex_colors,  # noqa: F401
                       soft_phong_shading)
 from .structures import PackedMeshes, PackedPointclouds  # noqa: F401

@@ -20,7 +20,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.environ.get("P3D_LIB_PATH") or os.path.join(HERE, "libp3d_amd.so")
 ARCH = "gfx950"
 
-SOURCES = ["binning.hip", "raster_mesh.hip", "raster_mesh_bwd.hip", "gather.hip", "transform.hip", "raster_points.hip", "composite.hip", "blend.hip", "clip.hip", "interp.hip", "shade.hip", "soft_phong.hip", "texture.hip", "texture_multi.hip", "atlas.hip", "profile.cpp"]
+SOURCES = ["binning.hip", "raster_mesh.hip", "raster_mesh_bwd.hip", "gather.hip", "transform.hip", "raster_points.hip", "render_points.hip", "composite.hip", "blend.hip", "clip.hip", "interp.hip", "shade.hip", "soft_phong.hip", "texture.hip", "texture_multi.hip", "atlas.hip", "profile.cpp"]
 HEADERS = ["binning.h", "p3d_common.h", "p3d_geom.h", "topk.h", "topk_insert_asm.h", "wave_table.h", "tile_map.h", "chunk_order.h", "atlas_cell.h", "uvm_sample.h", "shade_sample.h", os.path.join("..", "..", "include", "p3d_amd.h")]
 
 FLAGS = [

@@ -37,6 +37,62 @@ struct PointArgs {
   // short workspaces (binning.h): the device flag "the lists did not fit", or null.  A binned launch returns at once when it
   // is up, the naive launch behind it returns at once when it is not (as in raster_mesh.hip: MeshArgs::overflow).
   const int* overflow;
+  // The compositor behind the fine stage (p3d_rasterize_points_composite; null features: plain rasterization).  PointsRenderer
+  // (renderer/points/renderer.py:56-76) turns the fragments into weights = 1 - dists / r^2 and alpha-composites the points' features
+  // front to back (alpha_composite.cu:24-68): when a pixel's K entries are final they are in the workgroup's LDS, so the pixel of the
+  // image is formed there instead of by three more launches that read idx and dists back.
+  const float* features;  // (P, C) rows
+  float* images;          // (N, H, W, C), every element written
+  int C;                  // 1..4
+  float inv_r2;           // float(1) / float(r * r): torch evaluates `dists / (r * r)` as dists * that
+};
+
+// 12 / 16 adjacent bytes at 4-byte alignment: one global_load_dwordx3 / x4
+struct __attribute__((packed, aligned(4))) PFeat3 {
+  float x, y, z;
+};
+struct __attribute__((packed, aligned(4))) PFeat4 {
+  float x, y, z, w;
+};
+
+// One entry of a pixel, front to back (alpha_composite.cu:47-62 with alpha = 1 - dist2 * inv_r2; every product and difference a
+// separate float32 operation, in composite.hip's order: the same bits as the operators run one after the other).
+struct SplatPixel {
+  float acc[4];
+  float cum;
+  __device__ __forceinline__ void init() {
+    acc[0] = acc[1] = acc[2] = acc[3] = 0.0f;
+    cum = 1.0f;
+  }
+  __device__ __forceinline__ void add(const float* __restrict__ features, int C, int id, float d2, float inv_r2) {
+    if (id < 0) return;
+    const float al = 1.0f - d2 * inv_r2;
+    float fv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float* fp = features + (int64_t)id * C;
+    if (C == 3) {  // uniform
+      const PFeat3 v = *reinterpret_cast<const PFeat3*>(fp);
+      fv[0] = v.x, fv[1] = v.y, fv[2] = v.z;
+    } else if (C == 4) {
+      const PFeat4 v = *reinterpret_cast<const PFeat4*>(fp);
+      fv[0] = v.x, fv[1] = v.y, fv[2] = v.z, fv[3] = v.w;
+    } else {
+      fv[0] = fp[0];
+      if (C > 1) fv[1] = fp[1];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] += fv[c] * cum * al;
+    cum = cum * (1 - al);
+  }
+  __device__ __forceinline__ void store(float* __restrict__ px, int C) const {
+    if (C == 3) {  // uniform
+      *reinterpret_cast<PFeat3*>(px) = PFeat3{acc[0], acc[1], acc[2]};
+    } else if (C == 4) {
+      *reinterpret_cast<PFeat4*>(px) = PFeat4{acc[0], acc[1], acc[2], acc[3]};
+    } else {
+      px[0] = acc[0];
+      if (C > 1) px[1] = acc[1];
+    }
+  }
 };
 
 // PAYLOAD: the queue carries dist2 next to (z, idx).  Without it (long queues: 2 registers per entry instead of 3) the
@@ -869,7 +925,8 @@ __global__ __launch_bounds__(kStage, 2) void point_tile_sorted_kernel(PointArgs 
   }
 
   if (pix_ok) {
-    const int64_t base = (((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi)) * K;
+    const int64_t pixel = ((int64_t)n * H + (H - 1 - yi)) * W + (W - 1 - xi);
+    const int64_t base = pixel * K;
     auto entry = [&](int k, int* id, float* z, float* d2) {
       *id = -1;
       *z = -1.0f;
@@ -884,6 +941,9 @@ __global__ __launch_bounds__(kStage, 2) void point_tile_sorted_kernel(PointArgs 
         *d2 = dx * dx + dy * dy;
       }
     };
+    const bool splat = a.features != nullptr;  // uniform
+    SplatPixel sp;
+    sp.init();
     if ((K & 1) == 0) {
       for (int k = 0; k < K; k += 2) {
         int id[2];
@@ -893,6 +953,10 @@ __global__ __launch_bounds__(kStage, 2) void point_tile_sorted_kernel(PointArgs 
         *reinterpret_cast<int2*>(a.idxs + base + k) = make_int2(id[0], id[1]);
         *reinterpret_cast<float2*>(a.zbuf + base + k) = make_float2(z[0], z[1]);
         *reinterpret_cast<float2*>(a.dists + base + k) = make_float2(d2[0], d2[1]);
+        if (splat) {
+          sp.add(a.features, a.C, id[0], d2[0], a.inv_r2);
+          sp.add(a.features, a.C, id[1], d2[1], a.inv_r2);
+        }
       }
     } else {
       for (int k = 0; k < K; ++k) {
@@ -902,8 +966,22 @@ __global__ __launch_bounds__(kStage, 2) void point_tile_sorted_kernel(PointArgs 
         a.idxs[base + k] = id;
         a.zbuf[base + k] = z;
         a.dists[base + k] = d2;
+        if (splat) sp.add(a.features, a.C, id, d2, a.inv_r2);
       }
     }
+    if (splat) sp.store(a.images + pixel * a.C, a.C);
+  }
+}
+
+// The compositor as a pass of its own over finished fragments: what p3d_rasterize_points_composite launches behind the rasterizer
+// kernels that do not carry it in their epilogue (K beyond the tile-sorted kernel, naive launches, short workspaces).
+__global__ __launch_bounds__(256) void splat_composite_kernel(PointArgs a) {
+  const int64_t npix = (int64_t)a.N * a.H * a.W;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < npix; t += (int64_t)gridDim.x * 256) {
+    SplatPixel sp;
+    sp.init();
+    for (int k = 0; k < a.K; ++k) sp.add(a.features, a.C, a.idxs[t * a.K + k], a.dists[t * a.K + k], a.inv_r2);
+    sp.store(a.images + t * a.C, a.C);
   }
 }
 
@@ -1249,10 +1327,39 @@ static int point_cuda_order_replay(const PointArgs& fine, bool binned, const int
   return launch_status();
 }
 
+struct SplatArgs {
+  const float* features;
+  float* images;
+  int C;
+  float inv_r2;
+};
+
+static int splat_composite_pass(const PointArgs& fine, const SplatArgs& sp, hipStream_t s) {
+  PointArgs a = fine;
+  a.features = sp.features;
+  a.images = sp.images;
+  a.C = sp.C;
+  a.inv_r2 = sp.inv_r2;
+  const int64_t npix = (int64_t)a.N * a.H * a.W;
+  int64_t blocks = ceil_div(npix, 256);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  LaunchScope ls("points_composite", s);
+  splat_composite_kernel<<<(unsigned)blocks, 256, 0, s>>>(a);
+  return launch_status();
+}
+
 static int raster_points_impl(const float* points, const int64_t* first, const int64_t* count, const float* radius, int64_t P, int N,
                               int H, int W, int K, int bin_size, int max_points_per_bin, int32_t* idxs, float* zbuf, float* dists,
-                              void* workspace, size_t workspace_bytes, p3d_stream_t stream, bool cuda_order) {
+                              void* workspace, size_t workspace_bytes, p3d_stream_t stream, bool cuda_order,
+                              const SplatArgs* splat = nullptr) {
   hipStream_t s = (hipStream_t)stream;
+  if (splat && (bin_size <= 0 || max_points_per_bin <= 0)) {
+    const int st = p3d_rasterize_points_naive(points, first, count, radius, P, N, H, W, K, idxs, zbuf, dists, stream);
+    if (st != P3D_OK || (int64_t)N * H * W == 0) return st;
+    PointArgs a{};
+    fill_args(&a, points, radius, N, H, W, K, idxs, zbuf, dists);
+    return splat_composite_pass(a, *splat, s);
+  }
   if (bin_size <= 0 || max_points_per_bin <= 0) {
     const int st = p3d_rasterize_points_naive(points, first, count, radius, P, N, H, W, K, idxs, zbuf, dists, stream);
     if (st != P3D_OK || !cuda_order || (int64_t)N * H * W * K == 0) return st;
@@ -1283,7 +1390,28 @@ static int raster_points_impl(const float* points, const int64_t* first, const i
   a.csr = BinCSR{ws.offset, ws.total, ws.list, TilePlan{ws.arank, ws.bg_list, ws.plan_hdr, ws.order}, ws.stride};
   a.overflow = overflow;
   set_tiles(&a, g.bin_size, g.BH, g.BW);
+  // the compositor rides in the tile-sorted kernel's epilogue when that kernel writes every pixel; otherwise it is a pass behind
+  const bool splat_fused = splat && !is_short && !cuda_order && K <= kTileSortedMaxK;
+  if (splat_fused) {
+    a.features = splat->features;
+    a.images = splat->images;
+    a.C = splat->C;
+    a.inv_r2 = splat->inv_r2;
+  }
   st = launch_point_raster<true>(a, s);
+  if (splat && !splat_fused) {
+    if (st == P3D_OK && is_short) {
+      PointArgs b{};
+      fill_args(&b, points, radius, N, H, W, K, idxs, zbuf, dists);
+      b.first = first;
+      b.count = count;
+      b.overflow = overflow;
+      set_tiles(&b, H > W ? H : W, 1, 1);
+      st = launch_point_raster<false>(b, s);
+    }
+    if (st != P3D_OK) return st;
+    return splat_composite_pass(a, *splat, s);
+  }
   if (st == P3D_OK && is_short) {
     PointArgs b{};
     fill_args(&b, points, radius, N, H, W, K, idxs, zbuf, dists);
@@ -1305,6 +1433,26 @@ P3D_API int p3d_rasterize_points(const float* points, const int64_t* first, cons
                                  p3d_stream_t stream) {
   return raster_points_impl(points, first, count, radius, P, N, H, W, K, bin_size, max_points_per_bin, idxs, zbuf, dists, workspace,
                             workspace_bytes, stream, false);
+}
+
+P3D_API int p3d_rasterize_points_composite(const float* points, const int64_t* first, const int64_t* count, const float* radius,
+                                           const float* features, int64_t P, int C, int N, int H, int W, int K, int bin_size,
+                                           int max_points_per_bin, float inv_r2, int32_t* idxs, float* zbuf, float* dists,
+                                           float* images, void* workspace, size_t workspace_bytes, p3d_stream_t stream) {
+  if (C < 1 || C > 4) return P3D_ERR_INVALID_ARG;
+  const int rc = check_common(N, H, W, K);
+  if (rc != P3D_OK) return rc;
+  if ((int64_t)N * H * W == 0) return P3D_OK;
+  if (!images || (P > 0 && !features)) return P3D_ERR_INVALID_ARG;
+  if (K == 0 || P == 0) {  // nothing to composite: the fragments (K > 0: all empty) and a black image
+    const int st = raster_points_impl(points, first, count, radius, P, N, H, W, K, bin_size, max_points_per_bin, idxs, zbuf, dists,
+                                      workspace, workspace_bytes, stream, false);
+    if (st != P3D_OK) return st;
+    return hipMemsetAsync(images, 0, (size_t)N * H * W * C * sizeof(float), (hipStream_t)stream) == hipSuccess ? P3D_OK : P3D_ERR_LAUNCH;
+  }
+  const SplatArgs sp{features, images, C, inv_r2};
+  return raster_points_impl(points, first, count, radius, P, N, H, W, K, bin_size, max_points_per_bin, idxs, zbuf, dists, workspace,
+                            workspace_bytes, stream, false, &sp);
 }
 
 P3D_API int p3d_rasterize_points_cuda_order(const float* points, const int64_t* first, const int64_t* count, const float* radius,

@@ -31,8 +31,10 @@ constexpr int kEmptyKey = -1;
 //   kChunk  out[f * plane + (j / 4) * pitch + j % 4], j % 4 < nlive
 //           a 4-wide column chunk of (P, NV/4, pitch) records, e.g. channels c0..c0+3 of (F, 3, D) face attributes
 //   kCorners out[index[f * (NV/3) + j / 3] * 3 + j % 3]         per-corner xyz partials of face f sent to its vertices
+//   kSplit  j < split_at: out[f * split_row + j]; else out2[f * (NV - split_at) + j - split_at]
+//           one table for two outputs of the same primitive, e.g. a point's xy gradient (P, 3) and its feature gradient (P, C)
 // SPILL: see kFlushAt.
-enum { kRows = 0, kPlanar = 1, kChunk = 2, kCorners = 3 };
+enum { kRows = 0, kPlanar = 1, kChunk = 2, kCorners = 3, kSplit = 4 };
 // BUCKET: the keys are probed four at a time (one 16-byte LDS load per bucket of four slots instead of one load per slot;
 // SLOTS % 4 == 0).  A step's probe is a chain of dependent LDS round trips whose length is that of the longest chain among
 // the wave's primitives -- a fresh primitive in a table that is 3/4 full walks ~8 slots -- and in the rasterizer's
@@ -61,6 +63,9 @@ struct WaveTable {
   int64_t fstride = 1;      // kPlanar: floats between the entries of consecutive primitives inside a plane (interleaved outputs: plane 1, fstride NV)
   int pitch = 0;            // kChunk: floats between the NV/4 sub-rows of a record
   int nlive = NV;           // kPlanar: planes that exist; kChunk: live columns of the chunk (others are never flushed)
+  float* out2 = nullptr;    // kSplit: the second output
+  int split_at = 0;         // kSplit: values [0, split_at) go to `out`, the rest to `out2`
+  int split_row = 0;        // kSplit: floats per primitive in `out`
   const int64_t* index = nullptr;  // kCorners: (P, NV/3) vertex ids
   int64_t index_limit = -1;        // kCorners: number of vertices; ids outside [0, limit) have no destination (negative
                                    // ids wrap once, as torch indexing does).  -1: unchecked
@@ -68,6 +73,8 @@ struct WaveTable {
   // address of value j of primitive f, or nullptr when that value has no destination
   __device__ __forceinline__ float* dest(float* __restrict__ out, int f, int j) const {
     if constexpr (LAYOUT == kPlanar) return j < nlive ? out + j * plane + (int64_t)f * fstride : nullptr;
+    if constexpr (LAYOUT == kSplit)
+      return j < split_at ? out + (int64_t)f * split_row + j : out2 + (int64_t)f * (NV - split_at) + (j - split_at);
     if constexpr (LAYOUT == kChunk) return (j & 3) < nlive ? out + (int64_t)f * plane + (j >> 2) * pitch + (j & 3) : nullptr;
     if constexpr (LAYOUT == kCorners) {
       int64_t v = index[(int64_t)f * (NV / 3) + j / 3];

@@ -424,49 +424,141 @@ def _patch_points_rasterizer(our_rm):
     cameras, ONE kernel on the packed points (csrc/transform.hip: p3d_transform_verts_forward / _backward, the kernel
     MeshRasterizer.forward uses for vertices: x, y to NDC, z = view depth, as rasterizer.py:140-141 keeps it) and the
     rasterizer's own autograd node.  Falls back to the reference's forward when the cameras have no matrix form, need an
-    `eps`, or their matrices require grad."""
+    `eps`, or their matrices require grad.
+
+    PointsRenderer.forward (renderer/points/renderer.py:56-76) with the plain (PointsRasterizer, AlphaCompositor) pair, float32
+    (P, C <= 4) features, one scalar radius and K <= 16: the whole chain is pytorch3d_amd.render_points' fused node -- the image is
+    formed in the fine kernel's epilogue, the backward is one kernel.  The packed tensors are taken from the cloud's lists when it has
+    not packed them yet: `Pointclouds.points_packed()` builds a cloud-index entry per point with arange + bucketize, twice (points and
+    features, structures/utils.py:119-154) -- ~30 launches per freshly built cloud for tensors this chain never reads."""
     import importlib
 
+    import torch
+
     pr = importlib.import_module("pytorch3d.renderer.points.rasterizer")
+    rr = importlib.import_module("pytorch3d.renderer.points.renderer")
+    pc = importlib.import_module("pytorch3d.renderer.points.compositor")
     our_rp = importlib.import_module(__package__ + ".rasterize_points")
+    our_rd = importlib.import_module(__package__ + ".render_points")
     orig = pr.PointsRasterizer.forward
+    orig_render = rr.PointsRenderer.forward
+
+    def packed_of(clouds, want_features):
+        """(points_packed, features_packed or None, first, count) without `_compute_packed` where the cloud still holds its lists."""
+        if getattr(clouds, "_points_packed", None) is None and getattr(clouds, "_points_list", None) is not None:
+            pl = clouds._points_list
+            fl = getattr(clouds, "_features_list", None) if want_features else None
+            if len(pl) > 0 and all(torch.is_tensor(t) and t.dim() == 2 and t.shape[1] == 3 for t in pl) and (
+                    not want_features or (fl is not None and len(fl) == len(pl) and all(torch.is_tensor(t) and t.dim() == 2 for t in fl))):
+                count = clouds.num_points_per_cloud()  # built by the constructor
+                if len(pl) == 1:
+                    first = _small_zeros(pl[0].device)
+                    return pl[0], (fl[0] if want_features else None), first, count
+                first = torch.cumsum(count, 0) - count
+                return torch.cat(pl, 0), (torch.cat(fl, 0) if want_features else None), first, count
+        return (clouds.points_packed(), clouds.features_packed() if want_features else None, clouds.cloud_to_packed_first_idx(),
+                clouds.num_points_per_cloud())
+
+    def prepare(self, point_clouds, kwargs, want_features=False):
+        """(ndc points, features, first, count) when this rasterizer call can run on the package's kernels, else None."""
+        cameras = kwargs.get("cameras", self.cameras)
+        if cameras is None or kwargs.get("eps", None) is not None:
+            return None
+        try:
+            pts, feats, first, count = packed_of(point_clouds, want_features)
+            if not (_is_hip_f32(pts) and pts.dim() == 2 and pts.shape[1] == 3 and len(cameras) in (1, len(point_clouds))):
+                return None
+            cm = camera_matrices(cameras, kwargs)
+            if cm is None:
+                return None
+            w2v, v2n = cm[0], cm[1]
+            if w2v.requires_grad or v2n.requires_grad or w2v.device != pts.device:
+                return None
+        except Exception:
+            return None
+        mats = our_rm._pack_matrices(w2v, v2n, len(point_clouds), pts.device)
+        return our_rm._TransformVerts.apply(pts, first.contiguous(), mats), feats, first, count
 
     def forward(self, point_clouds, **kwargs):
-        cameras = kwargs.get("cameras", self.cameras)
-        ok = cameras is not None and kwargs.get("eps", None) is None
-        if ok:
-            try:
-                pts = point_clouds.points_packed()
-                ok = _is_hip_f32(pts) and pts.dim() == 2 and pts.shape[1] == 3 and len(cameras) in (1, len(point_clouds))
-                if ok:
-                    cm = camera_matrices(cameras, kwargs)
-                    ok = cm is not None
-                    if ok:
-                        w2v, v2n = cm[0], cm[1]
-                        ok = not (w2v.requires_grad or v2n.requires_grad) and w2v.device == pts.device
-            except Exception:
-                ok = False
-        _count("PointsRasterizer.forward", ok)
-        if not ok:
+        got = prepare(self, point_clouds, kwargs)
+        _count("PointsRasterizer.forward", got is not None)
+        if got is None:
             return orig(self, point_clouds, **kwargs)
+        ndc, _, first, count = got
         rs = kwargs.get("raster_settings", self.raster_settings)
-        mats = our_rm._pack_matrices(w2v, v2n, len(point_clouds), pts.device)
-        ndc = our_rm._TransformVerts.apply(pts, point_clouds.cloud_to_packed_first_idx().contiguous(), mats)
-        idx, zbuf, dists2 = our_rp.rasterize_points(_PackedPointsView(point_clouds, ndc), image_size=rs.image_size, radius=rs.radius,
-                                                    points_per_pixel=rs.points_per_pixel, bin_size=rs.bin_size,
+        idx, zbuf, dists2 = our_rp.rasterize_points(_PackedPointsView(point_clouds, ndc, first, count), image_size=rs.image_size,
+                                                    radius=rs.radius, points_per_pixel=rs.points_per_pixel, bin_size=rs.bin_size,
                                                     max_points_per_bin=rs.max_points_per_bin)
         return pr.PointFragments(idx=idx, zbuf=zbuf, dists=dists2)
+
+    def render(self, point_clouds, **kwargs):
+        rz = self.rasterizer
+        ok = FUSE_POINTS_RENDERER and type(self.compositor) is pc.AlphaCompositor and type(rz).forward is forward
+        got = None
+        if ok:
+            rs = kwargs.get("raster_settings", rz.raster_settings)
+            r_w = rz.raster_settings.radius  # renderer.py:62: the weights' radius is the rasterizer's OWN setting
+            ok = (isinstance(rs.radius, (float, int)) and not isinstance(rs.radius, bool) and isinstance(r_w, (float, int))
+                  and not isinstance(r_w, bool) and r_w > 0 and 0 < int(rs.points_per_pixel) <= our_rd.MAX_FUSED_K)
+        if ok:
+            got = prepare(rz, point_clouds, kwargs, want_features=True)
+            ok = got is not None and our_rd.fusable(got[1], r_w, rs.points_per_pixel)
+        _count("PointsRenderer.forward", ok)
+        if not ok:
+            return orig_render(self, point_clouds, **kwargs)
+        ndc, feats, first, count = got
+        view = _PackedPointsView(point_clouds, ndc, first, count)
+        images, idx, _, _ = our_rd.render_points_alpha(view, feats, image_size=rs.image_size, radius=rs.radius,
+                                                       points_per_pixel=rs.points_per_pixel, bin_size=rs.bin_size,
+                                                       max_points_per_bin=rs.max_points_per_bin, weight_radius=r_w,
+                                                       radius_per_point=_scalar_radius(rs.radius, ndc))
+        background_color = kwargs.get("background_color", self.compositor.background_color)
+        if background_color is not None:  # compositor.py:41-46, on (N, C, H, W) views
+            images = pc._add_background_color_to_images(idx.long().permute(0, 3, 1, 2), images.permute(0, 3, 1, 2),
+                                                        background_color).permute(0, 2, 3, 1)
+        return images
 
     forward.__wrapped__ = orig
     pr.PointsRasterizer.forward = forward
     _PATCHED.append((pr.PointsRasterizer, "forward", orig, forward))
+    render.__wrapped__ = orig_render
+    rr.PointsRenderer.forward = render
+    _PATCHED.append((rr.PointsRenderer, "forward", orig_render, render))
+
+
+FUSE_POINTS_RENDERER = True  # (tests and profiles switch the fused PointsRenderer off to time / compare the operator chain)
+_SMALL = {}
+
+
+def _small_zeros(device):
+    """A cached int64 zeros(1) per device: cloud_to_packed_first_idx of a single cloud (read-only here)."""
+    import torch
+
+    key = ("zeros1", str(device))
+    if key not in _SMALL:
+        _SMALL[key] = torch.zeros(1, dtype=torch.int64, device=device)
+    return _SMALL[key]
+
+
+def _scalar_radius(radius, points):
+    """The (P,) radius tensor of a scalar radius; the last one is kept (a renderer is called with the same cloud size over and over,
+    and the tensor is read-only inside the package)."""
+    import torch
+
+    key = ("radius", str(points.device))
+    hit = _SMALL.get(key)
+    if hit is not None and hit[0] == (float(radius), points.shape[0]):
+        return hit[1]
+    t = torch.full((points.shape[0],), float(radius), dtype=torch.float32, device=points.device)
+    _SMALL[key] = ((float(radius), points.shape[0]), t)
+    return t
 
 
 class _PackedPointsView:
     """The accessors pytorch3d_amd.rasterize_points reads, with the packed points replaced (everything else is the cloud's)."""
 
-    def __init__(self, clouds, points_packed):
-        self._clouds, self._points = clouds, points_packed
+    def __init__(self, clouds, points_packed, first=None, count=None):
+        self._clouds, self._points, self._first, self._count = clouds, points_packed, first, count
 
     def __len__(self):
         return len(self._clouds)
@@ -475,10 +567,10 @@ class _PackedPointsView:
         return self._points
 
     def cloud_to_packed_first_idx(self):
-        return self._clouds.cloud_to_packed_first_idx()
+        return self._first if self._first is not None else self._clouds.cloud_to_packed_first_idx()
 
     def num_points_per_cloud(self):
-        return self._clouds.num_points_per_cloud()
+        return self._count if self._count is not None else self._clouds.num_points_per_cloud()
 
     def padded_to_packed_idx(self):
         return self._clouds.padded_to_packed_idx()

@@ -57,6 +57,26 @@ def test_patched_points_renderer_chain_equals_the_unpatched_one():
     assert res.returncode == 0, res.stderr[-3000:]
     j = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     print(json.dumps(j, indent=1))
+    # round 6: the whole chain is the fused node of pytorch3d_amd.render_points (two launches) -- the rasterizer's and the compositor's
+    # own patches are not reached
+    assert j["grad_finite"] and j["patched_calls"]["PointsRenderer.forward"][0] > 0 and j["patched_calls"]["PointsRenderer.forward"][1] == 0, j
+    assert set(j["our_kernels_ms_per_step"]) >= {"points_fine", "points_composite_bwd"}, j
+    assert not set(j["our_kernels_ms_per_step"]) & {"alpha_composite_fwd", "alpha_composite_bwd", "points_backward"}, j
+    c = j["check"]
+    assert c["image_max_abs_diff"] <= 1e-5
+    assert c["grad_points_max_abs_diff"] <= 1e-4 * c["grad_points_max_abs"]
+    assert c["grad_features_max_abs_diff"] <= 1e-4 * c["grad_features_max_abs"]
+
+
+def test_patched_points_renderer_operator_chain_when_the_fused_node_is_switched_off():
+    """The same with shim.FUSE_POINTS_RENDERER = False (--no-fuse): PointsRasterizer.forward's and the compositing functions' patches,
+    the form of rounds 4-5 -- still what a renderer with another compositor, K > 16 or more than four channels gets."""
+    if not os.path.isdir(os.path.join(STAGE, "pytorch3d", "renderer")):
+        pytest.skip("oracle/_ref/reference_py is not staged (run __graft_entry__.build() where /root/reference exists)")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "dropin_points_timing.py"), "--mode", "patched", "--no-fuse", "--check",
+                          "--steps", "5"], capture_output=True, text=True, timeout=240, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    j = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
     assert j["grad_finite"] and j["patched_calls"]["PointsRasterizer.forward"][0] > 0 and j["patched_calls"]["alpha_composite"][0] > 0, j
     c = j["check"]
     assert c["image_max_abs_diff"] <= 1e-5
