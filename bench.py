@@ -372,6 +372,31 @@ def other_configs(lib, _lib, device):
                                                     "frac_of_peak_kernel_sum": total / (sum(kern.values()) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                                     "note": "wall includes the torch glue between the operators (alphas, permutes); 219 MB "
                                                             "on one image: latency / binning bound, not bandwidth bound (SURVEY 8(d))"}
+        # the same chain as PointsRenderer writes it (weights = 1 - dists / r^2, no clamp; features (P, C); image (N, H, W, C)) on the
+        # two fused launches of round 6 (include/p3d_amd.h: p3d_rasterize_points_composite / _composite_backward)
+        feats_pc = feats.t().contiguous()
+        gi_nhwc = gi.permute(0, 2, 3, 1).contiguous()
+        inv = _C.inv_r2_of(r)
+
+        def c4_fused():
+            idx, zbuf, dists, img = _C.rasterize_points_composite(pts, first, count, (H, H), radius, feats_pc, inv, K, 32, 200000)
+            gp, gf = _C.rasterize_points_composite_backward(pts, feats_pc, idx, dists, gi_nhwc, inv)
+            return img, gf, gp
+
+        wall_f, kern_f = _timed(lib, _lib, c4_fused)
+        alg4f = {
+            "points_fine": px * K * 12 + P * 16 + min(px * K, P) * C * 4 + px * C * 4,
+            "points_composite_bwd": px * K * 8 + px * C * 4 + min(px * K, P) * (C * 4 + 8) + P * (3 + C) * 4,
+        }
+        per_kernel_f = {k: {"avg_ms": kern_f[k], "algorithmic_bytes": b, "algorithmic_gbps": b / (kern_f[k] * 1e-3) / 1e9,
+                            "frac_of_peak": b / (kern_f[k] * 1e-3) / 1e9 / HBM_PEAK_GBPS} for k, b in alg4f.items() if kern_f.get(k)}
+        # (same fragments either way; the operator chain above clamps its alphas, so the images are compared in the tests, not here)
+        out["config4_points_1m_512_k10_fwd_bwd_fused"] = {
+            "wall_ms": round(wall_f, 4), "kernels_ms": kern_f, "kernel_sum_ms": round(sum(kern_f.values()), 4),
+            "algorithmic_bytes": sum(alg4f.values()), "per_kernel": per_kernel_f,
+            "vs_operator_chain": {"wall": round(wall / wall_f, 3), "kernel_sum": round(sum(kern.values()) / sum(kern_f.values()), 3)},
+            "note": "rasterizer + weights + alpha compositor forward as ONE chain of launches (compositing in the fine kernel's epilogue) and "
+                    "their backward as one kernel; gradients to points (x, y) and features; bit-equal image, tests/test_gpu_render_points.py"}
     except Exception as e:
         out["config4_points_1m_512_k10_fwd_bwd"] = {"error": repr(e)}
     return out
@@ -634,9 +659,10 @@ def dropin_points_timing():
     import subprocess
 
     out = {}
-    for mode in ("c_only", "patched"):
+    for mode in ("c_only", "patched", "patched_operators"):  # patched: the fused PointsRenderer node; _operators: with it switched off
         try:
-            res = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "dropin_points_timing.py"), "--mode", mode], capture_output=True,
+            flags = ["--mode", "patched", "--no-fuse"] if mode == "patched_operators" else ["--mode", mode]
+            res = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "dropin_points_timing.py")] + flags, capture_output=True,
                                  text=True, timeout=300, cwd=ROOT, env=_child_env())
             lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
             out[mode] = json.loads(lines[-1]) if lines else {"value": None, "reason": (res.stderr or res.stdout)[-400:]}

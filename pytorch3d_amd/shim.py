@@ -476,7 +476,7 @@ def _patch_points_rasterizer(our_rm):
                 return None
         except Exception:
             return None
-        mats = our_rm._pack_matrices(w2v, v2n, len(point_clouds), pts.device)
+        mats = _packed_matrices(our_rm, cameras, w2v, v2n, len(point_clouds), pts.device)
         return our_rm._TransformVerts.apply(pts, first.contiguous(), mats), feats, first, count
 
     def forward(self, point_clouds, **kwargs):
@@ -524,6 +524,18 @@ def _patch_points_rasterizer(our_rm):
     render.__wrapped__ = orig_render
     rr.PointsRenderer.forward = render
     _PATCHED.append((rr.PointsRenderer, "forward", orig_render, render))
+
+
+def _packed_matrices(our_rm, cameras, w2v, v2n, n, device):
+    """rasterize_meshes._pack_matrices(w2v, v2n) -- one stack + copy per call -- kept on the camera object for as long as
+    camera_matrices hands out the SAME two matrix tensors (its cache: the camera's parameters have not changed)."""
+    hit = cameras.__dict__.get("_p3d_amd_packed")
+    if hit is not None and hit[0] is w2v and hit[1] is v2n and hit[2] == (n, str(device)):
+        return hit[3]
+    mats = our_rm._pack_matrices(w2v, v2n, n, device)
+    if cameras.__dict__.get("_p3d_amd_matrices") is not None and not mats.requires_grad:
+        cameras.__dict__["_p3d_amd_packed"] = (w2v, v2n, (n, str(device)), mats)
+    return mats
 
 
 FUSE_POINTS_RENDERER = True  # (tests and profiles switch the fused PointsRenderer off to time / compare the operator chain)
