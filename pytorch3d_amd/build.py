@@ -34,7 +34,8 @@ FLAGS = [
 
 # Kernels that keep registers in AGPRs (more than 256 live VGPRs at one wave per SIMD).  Round 4 saw kernels of raster_mesh.hip
 # LOSE queue entries whenever VGPRs left the register file inside their candidate loop -- scratch spills, or AGPR copies
-# (profiles/r04/spill_miscompile.md; the cause inside the compiler was not found).  VGPR spills are refused outright; an AGPR
+# (profiles/r04/spill_miscompile.md).  Round 6 found why (profiles/r06/spill_root_cause.md): the kernels read lane-indexed tables with
+# v_readlane inside partially active regions; a spill reload there restores the ACTIVE lanes only.  VGPR spills are refused outright; an AGPR
 # kernel is accepted only if it is listed here with the GPU test that runs it on inputs that make EVERY register row live.
 AGPR_KERNELS_TESTED = {
     "softmax_blend_bwd_kernel<32>": "tests/test_gpu_blending.py::test_blend_kernels_vs_oracle_all_capacities[17|24|32-dense]",
