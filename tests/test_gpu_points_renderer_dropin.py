@@ -82,3 +82,29 @@ def test_patched_points_renderer_operator_chain_when_the_fused_node_is_switched_
     assert c["image_max_abs_diff"] <= 1e-5
     assert c["grad_points_max_abs_diff"] <= 1e-4 * c["grad_points_max_abs"]
     assert c["grad_features_max_abs_diff"] <= 1e-4 * c["grad_features_max_abs"]
+
+
+def test_patched_points_renderer_cases():
+    """tests/shim_points_renderer_cases.py: ragged batches, RGBA, background colours (constructor and keyword), a cloud built from
+    padded tensors, one channel with K = 16 -- through the fused node (counted), bit-equal in the image to the operator chain and within
+    the chain's gates of the reference's own Python; K = 20, five channels and the norm-weighted compositor fall back (counted)."""
+    if not os.path.isdir(os.path.join(STAGE, "pytorch3d", "renderer")):
+        pytest.skip("oracle/_ref/reference_py is not staged (run __graft_entry__.build() where /root/reference exists)")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "shim_points_renderer_cases.py")], capture_output=True, text=True,
+                         timeout=300, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    j = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    if "skipped" in j:
+        pytest.skip(j["skipped"])
+    for name, c in j.items():
+        print(name, json.dumps(c))
+        fused, fallback = c["calls"]["PointsRenderer.forward"]
+        if name.startswith("fallback_"):
+            assert fused == 0 and fallback == 1, (name, c["calls"])
+        else:
+            assert fused == 1 and fallback == 0, (name, c["calls"])
+            assert c["image_equal_to_operator_chain"], name
+        assert c["covered"] > 0.2, (name, c["covered"])
+        assert c["image_vs_reference_python"][0] <= 1e-5, (name, c["image_vs_reference_python"])
+        for key in ("grad_points_vs_reference_python", "grad_features_vs_reference_python", "grad_points_vs_chain", "grad_features_vs_chain"):
+            assert c[key][0] <= 1e-4 * c[key][1], (name, key, c[key])
