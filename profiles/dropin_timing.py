@@ -35,8 +35,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", default="c_only", choices=["c_only", "patched"])
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--prewarm-s", type=float, default=0.4,
+                    help="seconds of the same step, untimed, ahead of the warm-up steps: bench.py's protocol (a fresh box needs ~0.4 s of "
+                         "load before its clocks settle; the few milliseconds of warm-up + timed steps here end before that).  0 = none")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--image-size", type=int, default=512)
     ap.add_argument("--cprofile", action="store_true", help="after the timing: 20 more steps under cProfile, top functions on stderr")
@@ -91,6 +94,11 @@ def main():
         torch.autograd.backward([frag.zbuf, frag.bary_coords, frag.dists], [g_z, g_b, g_d])
         return frag
 
+    t_pre, n_pre = time.perf_counter(), 0
+    while args.prewarm_s > 0 and time.perf_counter() - t_pre < args.prewarm_s:
+        frag = step()
+        torch.cuda.synchronize()
+        n_pre += 1
     for _ in range(args.warmup):
         frag = step()
     torch.cuda.synchronize()
@@ -106,7 +114,7 @@ def main():
     kern = {k: round(ms / n * (n / args.steps), 4) for k, (n, ms) in sorted(_lib.profile_snapshot().items())}
     from pytorch3d_amd import _C as ours_C
 
-    out = {"mode": args.mode, "torus_div": args.torus_div, "cover_recalls_hit_miss": list(ours_C.COVER_RECALLS), "ms_per_step": wall, "Mpix_s": B * H * H / (wall * 1e-3) / 1e6, "steps": args.steps,
+    out = {"mode": args.mode, "torus_div": args.torus_div, "cover_recalls_hit_miss": list(ours_C.COVER_RECALLS), "ms_per_step": wall, "Mpix_s": B * H * H / (wall * 1e-3) / 1e6, "steps": args.steps, "prewarm_s": args.prewarm_s, "prewarm_steps": n_pre,
            "our_kernels_ms_per_step": kern, "our_kernels_sum_ms": round(sum(kern.values()), 4),
            "covered": float((frag.pix_to_face[..., 0] >= 0).float().mean()),
            "grad_finite": bool(torch.isfinite(deform.grad).all()),

@@ -648,6 +648,15 @@ __device__ __forceinline__ int stage_chunk(const MeshArgs& a, const StageLds& l,
   FaceSetup fs;
   int fid = -1, nb = -1;
   unsigned cm = 0, rm = 0;
+  // The tile's 16 column and 16 row centres as wave-uniform values, read HERE, with every lane of the wave active: inside the branch
+  // below the lanes past the end of the list are inactive, and a lane table may only be read where its source lanes cannot have been
+  // restored under a narrower exec mask (profiles/r06/spill_root_cause.md: what cost round 4's spilling kernels their last faces).
+  float xs[16], ys[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    xs[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l.pxy), c));
+    ys[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l.pxy), 16 + c));
+  }
   if (i < count) {
     fid = BINNED ? a.csr.list[src_base + i] : (int)(src_base + i);
     const float* g = a.face_verts + (int64_t)fid * 9;
@@ -662,12 +671,10 @@ __device__ __forceinline__ int stage_chunk(const MeshArgs& a, const StageLds& l,
     int xb = 0, xa = 0, yb = 0, ya = 0;  // centres below the box's low edge / above its high edge
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-      const float xs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l.pxy), c));
-      const float ys = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l.pxy), 16 + c));
-      xb += xs < fs.xlo ? 1 : 0;
-      xa += xs > fs.xhi ? 1 : 0;
-      yb += ys < fs.ylo ? 1 : 0;
-      ya += ys > fs.yhi ? 1 : 0;
+      xb += xs[c] < fs.xlo ? 1 : 0;
+      xa += xs[c] > fs.xhi ? 1 : 0;
+      yb += ys[c] < fs.ylo ? 1 : 0;
+      ya += ys[c] > fs.yhi ? 1 : 0;
     }
     cm = range_mask16(xb, xa) & l.valid_c;
     rm = range_mask16(yb, ya) & l.valid_r;
