@@ -438,6 +438,7 @@ def _patch_points_rasterizer(our_rm):
     pr = importlib.import_module("pytorch3d.renderer.points.rasterizer")
     rr = importlib.import_module("pytorch3d.renderer.points.renderer")
     pc = importlib.import_module("pytorch3d.renderer.points.compositor")
+    structures = importlib.import_module("pytorch3d.structures")
     our_rp = importlib.import_module(__package__ + ".rasterize_points")
     our_rd = importlib.import_module(__package__ + ".render_points")
     orig = pr.PointsRasterizer.forward
@@ -445,7 +446,7 @@ def _patch_points_rasterizer(our_rm):
 
     def packed_of(clouds, want_features):
         """(points_packed, features_packed or None, first, count) without `_compute_packed` where the cloud still holds its lists."""
-        if getattr(clouds, "_points_packed", None) is None and getattr(clouds, "_points_list", None) is not None:
+        if type(clouds) is structures.Pointclouds and clouds._points_packed is None and clouds._points_list is not None:
             pl = clouds._points_list
             fl = getattr(clouds, "_features_list", None) if want_features else None
             if len(pl) > 0 and all(torch.is_tensor(t) and t.dim() == 2 and t.shape[1] == 3 for t in pl) and (
