@@ -67,6 +67,8 @@ inline BinGeom make_internal_geom(int H, int W, int user_bin_size) {
 // background rows [r * q, (r + 1) * q), q = ceil(B / A).
 constexpr int kPlanClasses = 64;  // list-length classes of the tile order
 constexpr int kPlanHdr = 4;       // first class counter in plan_hdr
+constexpr int kPlanTicket = kPlanHdr + 2 * kPlanClasses;  // arrival counter of the row scan's workgroups (bin_scan_rows_tail_kernel)
+constexpr int kPlanHdrInts = kPlanTicket + 4;
 struct TilePlan {
   const int* arank;
   const int* bg_list;
@@ -93,7 +95,7 @@ struct BinWorkspace {
   long long* blocksum;  // (ceil(N*nbins / 1024) + 1) scratch of the offsets scan
   int* arank;        // (N*nbins)  TilePlan
   int* bg_list;      // (N*nbins)
-  int* plan_hdr;     // (4 + 2 * kPlanClasses)
+  int* plan_hdr;     // (kPlanHdrInts: 4 + 2 * kPlanClasses + the ticket)
   int* order;        // (N*nbins)
   int* list;         // (capacity) -- last, so that a short workspace shortens only this
   int stride;        // ints per list entry: 1, or 2 = (id, depth bits) (bin_carve with_z: points)

@@ -251,7 +251,9 @@ def test_coarse_bins_vs_oracle():
 @pytest.mark.parametrize("N,F,size,bin_size", [(70, 2100, (32, 32), 8),     # > 64 elements: the plan kernel, thread-per-row scan
                                                (65, 9000, (48, 40), 8),      # ragged, with empty elements
                                                (3, 150000, (64, 64), 16),    # 49+ chunks per element: the wave-per-row scan
-                                               (64, 1900, (32, 32), 16)])    # 64 elements: count pass publishes the plan
+                                               (64, 1900, (32, 32), 16),     # 64 elements: count pass publishes the plan
+                                               (1, 150000, (80, 48), 16),    # one image, 147 chunks: the row scan with the offsets scan
+                                               (1, 140000, (336, 336), 16)]) # as its tail (round 6); 15 rows in 4 workgroups / 441 rows in 111
 def test_coarse_bins_of_the_launch_shapes_of_bin_build(N, F, size, bin_size):
     """binning.hip: bin_build picks its launches by batch size (plan kernel above 64 elements, otherwise the count pass's first
     workgroup publishes the chunk table), by rows / chunks (single-workgroup scan for small launches) and by chunks per element

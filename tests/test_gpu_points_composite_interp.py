@@ -143,6 +143,29 @@ def test_points_coarse_and_fine_ops():
         assert all(torch.equal(a.cpu(), b) for a, b in zip(fine, naive))
 
 
+
+def test_one_image_scan_tail_is_race_free():
+    """binning.hip: bin_scan_rows_tail_kernel (one image, more than 128 chunks: the workgroup that draws the last ticket runs the offsets
+    scan on totals other workgroups -- on other XCDs -- have just written).  300k points, 336 x 336 (441 rows, 111 workgroups), the
+    coarse operator 200 times: every run must give the bins of the first, and the first the oracle's."""
+    from pytorch3d_amd import _C
+
+    d = _dev()
+    gen = torch.Generator().manual_seed(77)
+    P = 300_000
+    pts = _cloud(P, gen, zlo=0.1)
+    first, count = torch.tensor([0]), torch.tensor([P])
+    radius = torch.full((P,), 0.004)
+    size, bin_size, M = (336, 336), 16, 1200
+    ref = orc.rasterize_points_coarse(pts, first, count, size, radius, bin_size, M)[0]
+    args = (pts.to(d), first.to(d), count.to(d), size, radius.to(d), bin_size, M)
+    want = _C._rasterize_points_coarse(*args)
+    assert torch.equal(want.cpu(), ref)
+    for it in range(200):
+        got = _C._rasterize_points_coarse(*args)
+        assert torch.equal(got, want), f"run {it}: {(got != want).sum().item()} entries differ"
+
+
 @pytest.mark.parametrize("size", [(40, 56), (45, 59)])  # whole / ragged 8x8 tiles of the backward kernel
 def test_points_backward_and_autograd(size):
     import pytorch3d_amd as p3d
