@@ -648,16 +648,10 @@ __device__ __forceinline__ int stage_chunk(const MeshArgs& a, const StageLds& l,
   FaceSetup fs;
   int fid = -1, nb = -1;
   unsigned cm = 0, rm = 0;
-  // The tile's 16 column and 16 row centres as wave-uniform values, read HERE, with every lane of the wave active: inside the branch
-  // below the lanes past the end of the list are inactive, and a lane table may only be read where its source lanes cannot have been
-  // restored under a narrower exec mask (profiles/r06/spill_root_cause.md: what cost round 4's spilling kernels their last faces).
-  float xs[16], ys[16];
-#pragma unroll
-  for (int c = 0; c < 16; ++c) {
-    xs[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l.pxy), c));
-    ys[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l.pxy), 16 + c));
-  }
-  if (i < count) {
+  const bool has = i < count;  // this lane stages a face of the chunk
+  fs.xlo = fs.xhi = fs.ylo = fs.yhi = 0.0f;
+  fs.reject = true;
+  if (has) {
     fid = BINNED ? a.csr.list[src_base + i] : (int)(src_base + i);
     const float* g = a.face_verts + (int64_t)fid * 9;
     nb = (int)a.neighbor[fid];  // requested together with the vertices: one memory round trip, not two
@@ -665,17 +659,27 @@ __device__ __forceinline__ int stage_chunk(const MeshArgs& a, const StageLds& l,
     v1 = mk3(g[3], g[4], g[5]);
     v2 = mk3(g[6], g[7], g[8]);
     fs = face_setup(v0, v1, v2, a.sqrt_blur, cull);
-    // the tile's pixel columns / rows whose centres lie inside the blur-expanded box: the per-pixel bbox test of the
-    // reference (rasterize_meshes.cu:94-97, strict comparisons) done once per (face, column) and (face, row)
-    // (the centres are monotone in the pixel index, so the pixels inside form the range [#(centre < lo), 15 - #(centre > hi)])
-    int xb = 0, xa = 0, yb = 0, ya = 0;  // centres below the box's low edge / above its high edge
+  }
+  // the tile's pixel columns / rows whose centres lie inside the blur-expanded box: the per-pixel bbox test of the
+  // reference (rasterize_meshes.cu:94-97, strict comparisons) done once per (face, column) and (face, row)
+  // (the centres are monotone in the pixel index, so the pixels inside form the range [#(centre < lo), 15 - #(centre > hi)]).
+  // The 32 centres are read from the lanes of `pxy` BETWEEN the two halves of the staging branch, under a scalar branch ("some lane of
+  // this wave stages a face"): every lane of the wave is active here.  Inside `if (has)` the lanes past the end of the list are not,
+  // and a lane table may only be read where its source lanes cannot have been restored under a narrower exec mask
+  // (profiles/r06/spill_root_cause.md: what cost round 4's spilling kernels their last faces).  Lanes without a face compare zeros.
+  int xb = 0, xa = 0, yb = 0, ya = 0;  // centres below the box's low edge / above its high edge
+  if (__ballot(has) != 0) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-      xb += xs[c] < fs.xlo ? 1 : 0;
-      xa += xs[c] > fs.xhi ? 1 : 0;
-      yb += ys[c] < fs.ylo ? 1 : 0;
-      ya += ys[c] > fs.yhi ? 1 : 0;
+      const float xs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l.pxy), c));
+      const float ys = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l.pxy), 16 + c));
+      xb += xs < fs.xlo ? 1 : 0;
+      xa += xs > fs.xhi ? 1 : 0;
+      yb += ys < fs.ylo ? 1 : 0;
+      ya += ys > fs.yhi ? 1 : 0;
     }
+  }
+  if (has) {
     cm = range_mask16(xb, xa) & l.valid_c;
     rm = range_mask16(yb, ya) & l.valid_r;
     keep = !fs.reject && cm != 0 && rm != 0;  // some pixel centre of the tile is inside the box
