@@ -167,3 +167,35 @@ def test_fused_backward_refuses_what_it_does_not_take():
     dists = torch.full((1, 8, 8, 20), -1.0, device=d)
     with pytest.raises(RuntimeError):
         _C.rasterize_points_composite_backward(pts, torch.rand(10, 3, device=d), idx, dists, torch.zeros(1, 8, 8, 3, device=d), 1.0)  # K > 16
+
+
+@pytest.mark.parametrize("K", [4, 10, 40])
+def test_fused_forward_with_short_workspaces(K):
+    """include/p3d_amd.h "Short workspaces": the lists of the binned launch sized from a guess.  With lists that do NOT fit the naive
+    kernel writes the fragments, with lists that fit (the call after) the binned kernel does -- in both cases the compositor runs as a
+    pass behind them (the epilogue is taken only when the binned kernel is sure to write every pixel): same fragments, same image."""
+    from pytorch3d_amd import _C
+
+    d = _dev()
+    gen = torch.Generator().manual_seed(31 + K)
+    P, r, size = 1500, 0.15, (48, 80)
+    pts = _cloud(P, gen).to(d)
+    first, count = torch.tensor([0, 600], device=d), torch.tensor([600, 900], device=d)
+    feats = torch.rand(P, 3, generator=gen).to(d)
+    radius_t = torch.full((P,), r, device=d)
+    inv = _C.inv_r2_of(r)
+    saved = (_C.SHORT_WORKSPACE, _C.SHORT_WORKSPACE_FIRST_GUESS)
+    try:
+        _C.SHORT_WORKSPACE = "never"
+        want = _C.rasterize_points_composite(pts, first, count, size, radius_t, feats, inv, K, 16, 1000)
+        _C.SHORT_WORKSPACE, _C.SHORT_WORKSPACE_FIRST_GUESS = "always", 1
+        _C._NEEDS.clear()
+        for what in ("lists do not fit", "learned size"):
+            got = _C.rasterize_points_composite(pts, first, count, size, radius_t, feats, inv, K, 16, 1000)
+            assert _C.WORKSPACE_STATS["last_entries"] is not None
+            for name, a, b in zip(("idx", "zbuf", "dists", "image"), got, want):
+                assert torch.equal(a, b), (what, name)
+            torch.cuda.synchronize()
+    finally:
+        _C.SHORT_WORKSPACE, _C.SHORT_WORKSPACE_FIRST_GUESS = saved
+        _C._NEEDS.clear()
