@@ -305,7 +305,8 @@ int p3d_rasterize_points_fine(const float* points, const int32_t* bin_points, co
  *   p3d_rasterize_points_composite: p3d_rasterize_points (same arguments, same workspace, same idxs / zbuf / dists) that also writes
  *     images (N, H, W, C) f32 = the alpha compositing (alpha_composite.cu:24-68) of features (P, C) f32 rows, C in 1..4, with
  *     alpha = 1 - dists * inv_r2, inv_r2 = float(1) / float(r * r) (how torch evaluates `dists / (r * r)`): the pixel is formed in the
- *     fine kernel's epilogue while its K entries are in LDS (K <= 28, binned, full workspace), else by a pass behind the rasterizer.
+ *     fine kernel's epilogue while its K entries are in LDS (K <= 28, binned; with a short workspace whose lists did not fit: by a pass
+ *     behind the stand-by kernel, decided on the device), else by a pass behind the rasterizer.
  *     Bit-equal to the three operators run one after the other.
  *   p3d_rasterize_points_composite_backward: grad_points (P, 3) [z column zero: the chain does not expose zbuf] and grad_features
  *     (P, C), both fully written, from grad_images (N, H, W, C): alphaCompositeCudaBackwardKernel (alpha_composite.cu:72-141),

@@ -976,6 +976,8 @@ __global__ __launch_bounds__(kStage, 2) void point_tile_sorted_kernel(PointArgs 
 // The compositor as a pass of its own over finished fragments: what p3d_rasterize_points_composite launches behind the rasterizer
 // kernels that do not carry it in their epilogue (K beyond the tile-sorted kernel, naive launches, short workspaces).
 __global__ __launch_bounds__(256) void splat_composite_kernel(PointArgs a) {
+  // short workspaces: the binned kernel carried the compositor in its epilogue and wrote the image unless the lists did not fit
+  if (a.overflow != nullptr && *a.overflow == 0) return;  // uniform (scalar load)
   const int64_t npix = (int64_t)a.N * a.H * a.W;
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < npix; t += (int64_t)gridDim.x * 256) {
     SplatPixel sp;
@@ -1334,8 +1336,10 @@ struct SplatArgs {
   float inv_r2;
 };
 
-static int splat_composite_pass(const PointArgs& fine, const SplatArgs& sp, hipStream_t s) {
+// only_if: device flag; the pass runs when it is set (null: always)
+static int splat_composite_pass(const PointArgs& fine, const SplatArgs& sp, hipStream_t s, const int* only_if = nullptr) {
   PointArgs a = fine;
+  a.overflow = only_if;
   a.features = sp.features;
   a.images = sp.images;
   a.C = sp.C;
@@ -1391,7 +1395,9 @@ static int raster_points_impl(const float* points, const int64_t* first, const i
   a.overflow = overflow;
   set_tiles(&a, g.bin_size, g.BH, g.BW);
   // the compositor rides in the tile-sorted kernel's epilogue when that kernel writes every pixel; otherwise it is a pass behind
-  const bool splat_fused = splat && !is_short && !cuda_order && K <= kTileSortedMaxK;
+  // (short workspaces: the binned kernel returns at once when its lists did not fit; the naive kernel then writes the fragments and the
+  // pass behind it, gated by the same device flag, the image)
+  const bool splat_fused = splat && !cuda_order && K <= kTileSortedMaxK;
   if (splat_fused) {
     a.features = splat->features;
     a.images = splat->images;
@@ -1399,7 +1405,7 @@ static int raster_points_impl(const float* points, const int64_t* first, const i
     a.inv_r2 = splat->inv_r2;
   }
   st = launch_point_raster<true>(a, s);
-  if (splat && !splat_fused) {
+  if (splat) {
     if (st == P3D_OK && is_short) {
       PointArgs b{};
       fill_args(&b, points, radius, N, H, W, K, idxs, zbuf, dists);
@@ -1410,7 +1416,8 @@ static int raster_points_impl(const float* points, const int64_t* first, const i
       st = launch_point_raster<false>(b, s);
     }
     if (st != P3D_OK) return st;
-    return splat_composite_pass(a, *splat, s);
+    if (splat_fused && !is_short) return st;
+    return splat_composite_pass(a, *splat, s, splat_fused ? overflow : nullptr);
   }
   if (st == P3D_OK && is_short) {
     PointArgs b{};

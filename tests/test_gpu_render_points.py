@@ -172,8 +172,8 @@ def test_fused_backward_refuses_what_it_does_not_take():
 @pytest.mark.parametrize("K", [4, 10, 40])
 def test_fused_forward_with_short_workspaces(K):
     """include/p3d_amd.h "Short workspaces": the lists of the binned launch sized from a guess.  With lists that do NOT fit the naive
-    kernel writes the fragments, with lists that fit (the call after) the binned kernel does -- in both cases the compositor runs as a
-    pass behind them (the epilogue is taken only when the binned kernel is sure to write every pixel): same fragments, same image."""
+    kernel writes the fragments and a pass behind it, gated by the same device flag, the image; with lists that fit (the call after) the
+    binned kernel writes both (K <= 28: its epilogue; the gated pass returns at once) -- same fragments, same image either way."""
     from pytorch3d_amd import _C
 
     d = _dev()
