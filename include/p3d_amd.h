@@ -301,7 +301,9 @@ int p3d_rasterize_points_fine(const float* points, const int32_t* bin_points, co
 
 /* PointsRenderer's chain as two launches (round 6; renderer/points/renderer.py:56-76: fragments = rasterize_points(...),
  * weights = 1 - dists / r^2, images = alpha_composite(idx, weights, features)).  The reference has no single operator for it; the
- * patched PointsRenderer (pytorch3d_amd.shim) and pytorch3d_amd.render_points call these.
+ * patched PointsRenderer (pytorch3d_amd.shim) and pytorch3d_amd.render_points call these.  mode: P3D_COMPOSITE_ALPHA (AlphaCompositor) or
+ * P3D_COMPOSITE_NORM_SUM (NormWeightedCompositor: norm_weighted_sum.cu:24-154 in place of alpha_composite.cu below; the constants are
+ * defined further down with the compositing operators).
  *   p3d_rasterize_points_composite: p3d_rasterize_points (same arguments, same workspace, same idxs / zbuf / dists) that also writes
  *     images (N, H, W, C) f32 = the alpha compositing (alpha_composite.cu:24-68) of features (P, C) f32 rows, C in 1..4, with
  *     alpha = 1 - dists * inv_r2, inv_r2 = float(1) / float(r * r) (how torch evaluates `dists / (r * r)`): the pixel is formed in the
@@ -312,14 +314,15 @@ int p3d_rasterize_points_fine(const float* points, const int32_t* bin_points, co
  *     (P, C), both fully written, from grad_images (N, H, W, C): alphaCompositeCudaBackwardKernel (alpha_composite.cu:72-141),
  *     grad_dists = -grad_alphas * inv_r2 and RasterizePointsBackwardCudaKernel (rasterize_points.cu:366-411) as ONE kernel whose two
  *     scatters share a wave-private table.  K <= 16, C in 1..4 (P3D_ERR_INVALID_ARG otherwise: run the three operators instead). */
-int p3d_rasterize_points_composite(const float* points, const int64_t* cloud_to_packed_first_idx, const int64_t* num_points_per_cloud,
-                                   const float* radius, const float* features, int64_t P, int C, int N, int H, int W,
-                                   int points_per_pixel, int bin_size, int max_points_per_bin, float inv_r2, int32_t* idxs,
-                                   float* zbuf, float* dists, float* images, void* workspace, size_t workspace_bytes,
+int p3d_rasterize_points_composite(int mode, const float* points, const int64_t* cloud_to_packed_first_idx,
+                                   const int64_t* num_points_per_cloud, const float* radius, const float* features, int64_t P, int C,
+                                   int N, int H, int W, int points_per_pixel, int bin_size, int max_points_per_bin, float inv_r2,
+                                   int32_t* idxs, float* zbuf, float* dists, float* images, void* workspace, size_t workspace_bytes,
                                    p3d_stream_t stream);
-int p3d_rasterize_points_composite_backward(const float* points, const float* features, const int32_t* idxs, const float* dists,
-                                            const float* grad_images, int64_t P, int C, int N, int H, int W, int points_per_pixel,
-                                            float inv_r2, float* grad_points, float* grad_features, p3d_stream_t stream);
+int p3d_rasterize_points_composite_backward(int mode, const float* points, const float* features, const int32_t* idxs,
+                                            const float* dists, const float* grad_images, int64_t P, int C, int N, int H, int W,
+                                            int points_per_pixel, float inv_r2, float* grad_points, float* grad_features,
+                                            p3d_stream_t stream);
 
 /* replaces RasterizePointsBackward, rasterize_points.h:281-305 (_C.rasterize_points_backward). */
 int p3d_rasterize_points_backward(const float* points, const int32_t* idxs, const float* grad_zbuf,

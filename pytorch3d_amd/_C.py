@@ -625,10 +625,13 @@ def inv_r2_of(radius):
     return float(np.float32(1.0) / np.float32(float(radius) * float(radius)))
 
 
+_SPLAT_MODES = {"alpha": 0, "norm": 1}  # P3D_COMPOSITE_ALPHA / _NORM_SUM: AlphaCompositor / NormWeightedCompositor
+
+
 def rasterize_points_composite(points, cloud_to_packed_first_idx, num_points_per_cloud, image_size, radius, features, inv_r2,
-                               points_per_pixel, bin_size, max_points_per_bin):
-    """include/p3d_amd.h: p3d_rasterize_points_composite.  rasterize_points's arguments + features (P, C), C in 1..4, and inv_r2
-    (inv_r2_of).  Returns (idxs int32, zbuf, dists2, images (N, H, W, C))."""
+                               points_per_pixel, bin_size, max_points_per_bin, mode="alpha"):
+    """include/p3d_amd.h: p3d_rasterize_points_composite.  rasterize_points's arguments + features (P, C), C in 1..4, inv_r2
+    (inv_r2_of) and the compositor ("alpha" / "norm").  Returns (idxs int32, zbuf, dists2, images (N, H, W, C))."""
     dev = _same_device(("points", points), ("cloud_to_packed_first_idx", cloud_to_packed_first_idx),
                        ("num_points_per_cloud", num_points_per_cloud), ("radius", radius), ("features", features))
     _check_points(points)
@@ -653,7 +656,7 @@ def rasterize_points_composite(points, cloud_to_packed_first_idx, num_points_per
         if images.numel() == 0:
             return out + (images,)
         ws, need, need_at, entries = _mesh_workspace(lib, P, N, H, W, bin_size, M, dev, "points") if binned else (_workspace(0, dev), None, 0, None)
-        rc = lib.p3d_rasterize_points_composite(_ptr(pts), _ptr(first), _ptr(count), _ptr(rad), _ptr(feats), P, C, N, H, W, K,
+        rc = lib.p3d_rasterize_points_composite(_SPLAT_MODES[mode], _ptr(pts), _ptr(first), _ptr(count), _ptr(rad), _ptr(feats), P, C, N, H, W, K,
                                                 bin_size if binned else 0, M if binned else 0, float(inv_r2), _ptr(out[0]), _ptr(out[1]),
                                                 _ptr(out[2]), _ptr(images), _ptr(ws), ws.numel(), _stream(dev))
         _lib.check(rc, "rasterize_points_composite")
@@ -662,7 +665,7 @@ def rasterize_points_composite(points, cloud_to_packed_first_idx, num_points_per
     return out + (images,)
 
 
-def rasterize_points_composite_backward(points, features, idxs, dists, grad_images, inv_r2):
+def rasterize_points_composite_backward(points, features, idxs, dists, grad_images, inv_r2, mode="alpha"):
     """include/p3d_amd.h: p3d_rasterize_points_composite_backward.  Returns (grad_points (P, 3), grad_features (P, C))."""
     dev = _same_device(("points", points), ("features", features), ("idxs", idxs), ("dists", dists), ("grad_images", grad_images))
     if torch.are_deterministic_algorithms_enabled() and not torch.is_deterministic_algorithms_warn_only_enabled():
@@ -679,7 +682,7 @@ def rasterize_points_composite_backward(points, features, idxs, dists, grad_imag
         gf = torch.empty((P, C), dtype=torch.float32, device=dev)
         if P == 0:
             return gp, gf
-        rc = lib.p3d_rasterize_points_composite_backward(_ptr(pts), _ptr(feats), _ptr(ix), _ptr(ds), _ptr(gi), P, C, N, H, W, K,
+        rc = lib.p3d_rasterize_points_composite_backward(_SPLAT_MODES[mode], _ptr(pts), _ptr(feats), _ptr(ix), _ptr(ds), _ptr(gi), P, C, N, H, W, K,
                                                          float(inv_r2), _ptr(gp), _ptr(gf), _stream(dev))
         _lib.check(rc, "rasterize_points_composite_backward")
     return gp, gf

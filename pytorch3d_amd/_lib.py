@@ -81,9 +81,9 @@ _SIGNATURES = {
                                             c_ptr, c_size, c_ptr]),
     "p3d_rasterize_points_fine": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                           c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
-    "p3d_rasterize_points_composite": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+    "p3d_rasterize_points_composite": (c_int, [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                                ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
-    "p3d_rasterize_points_composite_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_int,
+    "p3d_rasterize_points_composite_backward": (c_int, [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_int,
                                                         ctypes.c_float, c_ptr, c_ptr, c_ptr]),
     "p3d_rasterize_points_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr,
                                               c_ptr]),

@@ -45,6 +45,7 @@ struct PointArgs {
   float* images;          // (N, H, W, C), every element written
   int C;                  // 1..4
   float inv_r2;           // float(1) / float(r * r): torch evaluates `dists / (r * r)` as dists * that
+  int comp_mode;          // P3D_COMPOSITE_ALPHA (alpha_composite.cu:24-68) or P3D_COMPOSITE_NORM_SUM (norm_weighted_sum.cu:24-78)
 };
 
 // 12 / 16 adjacent bytes at 4-byte alignment: one global_load_dwordx3 / x4
@@ -57,12 +58,24 @@ struct __attribute__((packed, aligned(4))) PFeat4 {
 
 // One entry of a pixel, front to back (alpha_composite.cu:47-62 with alpha = 1 - dist2 * inv_r2; every product and difference a
 // separate float32 operation, in composite.hip's order: the same bits as the operators run one after the other).
+constexpr float kSplatEpsNorm = 1e-4f;  // norm_weighted_sum.cu:20
 struct SplatPixel {
   float acc[4];
   float cum;
-  __device__ __forceinline__ void init() {
+  float norm;  // NORM_SUM: the clamped sum of the pixel's weights (set by the caller before the first add), else unused
+  bool norm_mode;
+  __device__ __forceinline__ void init(int mode = P3D_COMPOSITE_ALPHA) {
     acc[0] = acc[1] = acc[2] = acc[3] = 0.0f;
     cum = 1.0f;
+    norm = 0.0f;
+    norm_mode = mode == P3D_COMPOSITE_NORM_SUM;
+  }
+  // NORM_SUM's first walk over the pixel's entries: norm += alpha of the valid ones, in k order (norm_weighted_sum.cu:47-55)
+  __device__ __forceinline__ void weigh(int id, float d2, float inv_r2) {
+    if (id >= 0) norm += 1.0f - d2 * inv_r2;
+  }
+  __device__ __forceinline__ void clamp_norm() {
+    if (norm < kSplatEpsNorm) norm = kSplatEpsNorm;
   }
   __device__ __forceinline__ void add(const float* __restrict__ features, int C, int id, float d2, float inv_r2) {
     if (id < 0) return;
@@ -78,6 +91,11 @@ struct SplatPixel {
     } else {
       fv[0] = fp[0];
       if (C > 1) fv[1] = fp[1];
+    }
+    if (norm_mode) {  // uniform
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] += fv[c] * al / norm;
+      return;
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] += fv[c] * cum * al;
@@ -943,7 +961,16 @@ __global__ __launch_bounds__(kStage, 2) void point_tile_sorted_kernel(PointArgs 
     };
     const bool splat = a.features != nullptr;  // uniform
     SplatPixel sp;
-    sp.init();
+    sp.init(a.comp_mode);
+    if (splat && sp.norm_mode) {  // uniform: the weights' sum first (the entries are in LDS, their points in the L1)
+      for (int k = 0; k < K; ++k) {
+        int id;
+        float z, d2;
+        entry(k, &id, &z, &d2);
+        sp.weigh(id, d2, a.inv_r2);
+      }
+      sp.clamp_norm();
+    }
     if ((K & 1) == 0) {
       for (int k = 0; k < K; k += 2) {
         int id[2];
@@ -981,7 +1008,11 @@ __global__ __launch_bounds__(256) void splat_composite_kernel(PointArgs a) {
   const int64_t npix = (int64_t)a.N * a.H * a.W;
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < npix; t += (int64_t)gridDim.x * 256) {
     SplatPixel sp;
-    sp.init();
+    sp.init(a.comp_mode);
+    if (sp.norm_mode) {  // uniform
+      for (int k = 0; k < a.K; ++k) sp.weigh(a.idxs[t * a.K + k], a.dists[t * a.K + k], a.inv_r2);
+      sp.clamp_norm();
+    }
     for (int k = 0; k < a.K; ++k) sp.add(a.features, a.C, a.idxs[t * a.K + k], a.dists[t * a.K + k], a.inv_r2);
     sp.store(a.images + t * a.C, a.C);
   }
@@ -1334,6 +1365,7 @@ struct SplatArgs {
   float* images;
   int C;
   float inv_r2;
+  int mode;
 };
 
 // only_if: device flag; the pass runs when it is set (null: always)
@@ -1344,6 +1376,7 @@ static int splat_composite_pass(const PointArgs& fine, const SplatArgs& sp, hipS
   a.images = sp.images;
   a.C = sp.C;
   a.inv_r2 = sp.inv_r2;
+  a.comp_mode = sp.mode;
   const int64_t npix = (int64_t)a.N * a.H * a.W;
   int64_t blocks = ceil_div(npix, 256);
   if (blocks > 256 * 32) blocks = 256 * 32;
@@ -1403,6 +1436,7 @@ static int raster_points_impl(const float* points, const int64_t* first, const i
     a.images = splat->images;
     a.C = splat->C;
     a.inv_r2 = splat->inv_r2;
+    a.comp_mode = splat->mode;
   }
   st = launch_point_raster<true>(a, s);
   if (splat) {
@@ -1442,11 +1476,11 @@ P3D_API int p3d_rasterize_points(const float* points, const int64_t* first, cons
                             workspace_bytes, stream, false);
 }
 
-P3D_API int p3d_rasterize_points_composite(const float* points, const int64_t* first, const int64_t* count, const float* radius,
-                                           const float* features, int64_t P, int C, int N, int H, int W, int K, int bin_size,
-                                           int max_points_per_bin, float inv_r2, int32_t* idxs, float* zbuf, float* dists,
+P3D_API int p3d_rasterize_points_composite(int mode, const float* points, const int64_t* first, const int64_t* count,
+                                           const float* radius, const float* features, int64_t P, int C, int N, int H, int W, int K,
+                                           int bin_size, int max_points_per_bin, float inv_r2, int32_t* idxs, float* zbuf, float* dists,
                                            float* images, void* workspace, size_t workspace_bytes, p3d_stream_t stream) {
-  if (C < 1 || C > 4) return P3D_ERR_INVALID_ARG;
+  if (C < 1 || C > 4 || (mode != P3D_COMPOSITE_ALPHA && mode != P3D_COMPOSITE_NORM_SUM)) return P3D_ERR_INVALID_ARG;
   const int rc = check_common(N, H, W, K);
   if (rc != P3D_OK) return rc;
   if ((int64_t)N * H * W == 0) return P3D_OK;
@@ -1457,7 +1491,7 @@ P3D_API int p3d_rasterize_points_composite(const float* points, const int64_t* f
     if (st != P3D_OK) return st;
     return hipMemsetAsync(images, 0, (size_t)N * H * W * C * sizeof(float), (hipStream_t)stream) == hipSuccess ? P3D_OK : P3D_ERR_LAUNCH;
   }
-  const SplatArgs sp{features, images, C, inv_r2};
+  const SplatArgs sp{features, images, C, inv_r2, mode};
   return raster_points_impl(points, first, count, radius, P, N, H, W, K, bin_size, max_points_per_bin, idxs, zbuf, dists, workspace,
                             workspace_bytes, stream, false, &sp);
 }

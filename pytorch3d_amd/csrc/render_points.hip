@@ -16,6 +16,7 @@ namespace p3d {
 namespace {
 
 constexpr float kEpsAlpha = 1e-9f;  // alpha_composite.cu:20
+constexpr float kEpsNorm = 1e-4f;   // norm_weighted_sum.cu:20
 constexpr int kSplatKT = 16;        // entries per pixel held in registers
 constexpr int kSplatSlots = 240;    // 4 waves x 240 x 40 B = 38.4 KB: four workgroups per CU (one 512^2 image is 1024 of them)
 
@@ -43,7 +44,8 @@ struct SplatBwdArgs {
 };
 
 // KT: entries per pixel held in registers (K <= KT); up to 12 the kernel is held to 128 registers: four workgroups per CU
-template <int C, int KT>
+// MODE: P3D_COMPOSITE_ALPHA, or P3D_COMPOSITE_NORM_SUM (NormWeightedCompositor: norm_weighted_sum.cu:82-154 in composite.hip's form)
+template <int C, int KT, int MODE>
 __global__ __launch_bounds__(256, KT <= 12 ? 4 : 2) void splat_backward_kernel(SplatBwdArgs a) {
   using Tab = WaveTable<2 + C, kSplatSlots, kSplit>;
   // (the tile's entries are transposed through the table's memory before the table is in use)
@@ -110,6 +112,14 @@ __global__ __launch_bounds__(256, KT <= 12 ? 4 : 2) void splat_backward_kernel(S
     }
   }
 
+  float sum_alpha = 0.0f;
+  if constexpr (MODE == P3D_COMPOSITE_NORM_SUM) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+      if (id[k] >= 0) sum_alpha += al[k];
+    if (sum_alpha < kEpsNorm) sum_alpha = kEpsNorm;
+  }
+
   // ---- grad_alphas in registers: alpha_composite.cu:120-139 in composite_bwd_tile_kernel's form (one reciprocal per entry, the
   // terms behind an entry as one running sum; tolerance-gated, tests/test_compositing.py:207)
   {
@@ -128,27 +138,40 @@ __global__ __launch_bounds__(256, KT <= 12 ? 4 : 2) void splat_backward_kernel(S
         for (int c = 0; c < C; ++c) fv[c][k] = k < K ? fp[c] : 0.0f;
       }
     }
-    float inv[KT];
+    if constexpr (MODE == P3D_COMPOSITE_ALPHA) {
+      float inv[KT];
 #pragma unroll
-    for (int k = 0; k < KT; ++k) inv[k] = 1.0f / (1 - al[k] + kEpsAlpha);
+      for (int k = 0; k < KT; ++k) inv[k] = 1.0f / (1 - al[k] + kEpsAlpha);
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-      float cum = 1.0f;
-      float back[KT];
+      for (int c = 0; c < C; ++c) {
+        float cum = 1.0f;
+        float back[KT];
 #pragma unroll
-      for (int k = 0; k < KT; ++k) {
-        back[k] = 0.0f;
-        if (id[k] >= 0) {
-          ga[k] += cum * fv[c][k] * go[c];
-          back[k] = -go[c] * fv[c][k] * cum * al[k];
-          cum = cum * (1 - al[k]);
+        for (int k = 0; k < KT; ++k) {
+          back[k] = 0.0f;
+          if (id[k] >= 0) {
+            ga[k] += cum * fv[c][k] * go[c];
+            back[k] = -go[c] * fv[c][k] * cum * al[k];
+            cum = cum * (1 - al[k]);
+          }
+        }
+        float behind = 0.0f;
+#pragma unroll
+        for (int k = KT - 1; k >= 0; --k) {
+          if (id[k] >= 0) ga[k] += behind * inv[k];
+          behind += back[k];
         }
       }
-      float behind = 0.0f;
+    } else {
 #pragma unroll
-      for (int k = KT - 1; k >= 0; --k) {
-        if (id[k] >= 0) ga[k] += behind * inv[k];
-        behind += back[k];
+      for (int c = 0; c < C; ++c) {
+        float sum_af = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+          if (id[k] >= 0) sum_af += al[k] * fv[c][k];
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+          if (id[k] >= 0) ga[k] += (fv[c][k] * sum_alpha - sum_af) / (sum_alpha * sum_alpha) * go[c];
       }
     }
   }
@@ -179,11 +202,16 @@ __global__ __launch_bounds__(256, KT <= 12 ? 4 : 2) void splat_backward_kernel(S
       const float gd = -ga[k] * a.inv_r2;
       g[0] = 2.0f * gd * (qx[k] - xf);
       g[1] = 2.0f * gd * (qy[k] - yf);
-      const float wgt = cum * al[k];
+      if constexpr (MODE == P3D_COMPOSITE_ALPHA) {
+        const float wgt = cum * al[k];
 #pragma unroll
-      for (int c = 0; c < C; ++c) g[2 + c] = wgt * go[c];
+        for (int c = 0; c < C; ++c) g[2 + c] = wgt * go[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; ++c) g[2 + c] = al[k] * go[c] / sum_alpha;
+      }
       tab.add(a.grad_points, lane, id[k], g);
-      if (id[k] >= 0) cum = cum * (1 - al[k]);
+      if (MODE == P3D_COMPOSITE_ALPHA && id[k] >= 0) cum = cum * (1 - al[k]);
     }
   }
   if (tab.used > 0) tab.flush(a.grad_points, lane);
@@ -194,10 +222,11 @@ __global__ __launch_bounds__(256, KT <= 12 ? 4 : 2) void splat_backward_kernel(S
 
 using namespace p3d;
 
-P3D_API int p3d_rasterize_points_composite_backward(const float* points, const float* features, const int32_t* idxs, const float* dists,
-                                                    const float* grad_images, int64_t P, int C, int N, int H, int W, int K, float inv_r2,
-                                                    float* grad_points, float* grad_features, p3d_stream_t stream) {
+P3D_API int p3d_rasterize_points_composite_backward(int mode, const float* points, const float* features, const int32_t* idxs,
+                                                    const float* dists, const float* grad_images, int64_t P, int C, int N, int H, int W,
+                                                    int K, float inv_r2, float* grad_points, float* grad_features, p3d_stream_t stream) {
   if (P < 0 || N < 0 || H < 0 || W < 0 || K < 0 || C < 1 || C > 4 || K > kSplatKT) return P3D_ERR_INVALID_ARG;
+  if (mode != P3D_COMPOSITE_ALPHA && mode != P3D_COMPOSITE_NORM_SUM) return P3D_ERR_INVALID_ARG;
   if (P == 0) return P3D_OK;
   if (!grad_points || !grad_features) return P3D_ERR_INVALID_ARG;
   hipStream_t s = (hipStream_t)stream;
@@ -219,11 +248,17 @@ P3D_API int p3d_rasterize_points_composite_backward(const float* points, const f
   const int64_t blocks = ceil_div((int64_t)N * a.tiles_y * a.tiles_x, 4);
   if (blocks > 0x7fffffff) return P3D_ERR_INVALID_ARG;
   LaunchScope ls("points_composite_bwd", s);
-#define P3D_SPLAT_BWD(C_)                                                                   \
-  if (K <= 4) splat_backward_kernel<C_, 4><<<(unsigned)blocks, 256, 0, s>>>(a);             \
-  else if (K <= 8) splat_backward_kernel<C_, 8><<<(unsigned)blocks, 256, 0, s>>>(a);        \
-  else if (K <= 12) splat_backward_kernel<C_, 12><<<(unsigned)blocks, 256, 0, s>>>(a);      \
-  else splat_backward_kernel<C_, 16><<<(unsigned)blocks, 256, 0, s>>>(a);
+#define P3D_SPLAT_BWD_M(C_, M_)                                                                  \
+  if (K <= 4) splat_backward_kernel<C_, 4, M_><<<(unsigned)blocks, 256, 0, s>>>(a);              \
+  else if (K <= 8) splat_backward_kernel<C_, 8, M_><<<(unsigned)blocks, 256, 0, s>>>(a);         \
+  else if (K <= 12) splat_backward_kernel<C_, 12, M_><<<(unsigned)blocks, 256, 0, s>>>(a);       \
+  else splat_backward_kernel<C_, 16, M_><<<(unsigned)blocks, 256, 0, s>>>(a);
+#define P3D_SPLAT_BWD(C_)                                                         \
+  if (mode == P3D_COMPOSITE_ALPHA) {                                              \
+    P3D_SPLAT_BWD_M(C_, P3D_COMPOSITE_ALPHA)                                      \
+  } else {                                                                        \
+    P3D_SPLAT_BWD_M(C_, P3D_COMPOSITE_NORM_SUM)                                   \
+  }
   switch (C) {
     case 1: P3D_SPLAT_BWD(1) break;
     case 2: P3D_SPLAT_BWD(2) break;
@@ -231,5 +266,6 @@ P3D_API int p3d_rasterize_points_composite_backward(const float* points, const f
     default: P3D_SPLAT_BWD(4) break;
   }
 #undef P3D_SPLAT_BWD
+#undef P3D_SPLAT_BWD_M
   return launch_status();
 }

@@ -1,4 +1,5 @@
-"""PointsRenderer's chain -- rasterize_points, weights = 1 - dists / r^2, alpha_composite -- as ONE autograd node on two launches.
+"""PointsRenderer's chain -- rasterize_points, weights = 1 - dists / r^2, alpha_composite (or norm_weighted_sum) -- as ONE autograd
+node on two launches.
 
 The reference (pytorch3d/renderer/points/renderer.py:56-76) runs the rasterizer, two element-wise kernels, two permuted copies and the
 compositor, and in the backward the compositor's backward, the element-wise backwards and the rasterizer's backward.  Here the pixel of
@@ -32,13 +33,16 @@ def fusable(features_packed, radius, points_per_pixel) -> bool:
 
 def render_points_alpha(pointclouds, features_packed, image_size: Union[int, Sequence[int]] = 256, radius: float = 0.01,
                         points_per_pixel: int = 8, bin_size: Optional[int] = None, max_points_per_bin: Optional[int] = None,
-                        weight_radius: Optional[float] = None, radius_per_point: Optional[torch.Tensor] = None
-                        ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+                        weight_radius: Optional[float] = None, radius_per_point: Optional[torch.Tensor] = None,
+                        compositor: str = "alpha") -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """(images (N, H, W, C), idx int32, zbuf, dists2) of `pointclouds` (NDC points; the accessors of pytorch3d_amd.structures.
     PackedPointclouds) with `features_packed` (P, C).  image_size .. max_points_per_bin as rasterize_points (rasterize_points.py:24-132:
     same heuristics, same error).  weight_radius: the r of `weights = 1 - dists / r^2` when it is not the rasterization radius
     (PointsRenderer reads it from the rasterizer's own settings, renderer.py:62).  Gradients reach the points (x, y: the chain does
-    not use zbuf) and the features."""
+    not use zbuf) and the features.  compositor: "alpha" (AlphaCompositor, compositing.py:68-123) or "norm" (NormWeightedCompositor:
+    norm_weighted_sum, compositing.py:126-185)."""
+    if compositor not in ("alpha", "norm"):
+        raise ValueError("compositor must be 'alpha' or 'norm'")
     size = parse_image_size(image_size)
     longest = max(size)
     if bin_size is None:
@@ -55,7 +59,12 @@ def render_points_alpha(pointclouds, features_packed, image_size: Union[int, Seq
     inv_r2 = _C.inv_r2_of(radius if weight_radius is None else weight_radius)
     return _SplatAlpha.apply(pointclouds.points_packed(), features_packed, rad, pointclouds.cloud_to_packed_first_idx(),
                              pointclouds.num_points_per_cloud(),
-                             (size, int(points_per_pixel), int(bin_size), int(max_points_per_bin), inv_r2))
+                             (size, int(points_per_pixel), int(bin_size), int(max_points_per_bin), inv_r2, compositor))
+
+
+def render_points(*args, **kwargs):
+    """render_points_alpha under its general name (the compositor is an argument)."""
+    return render_points_alpha(*args, **kwargs)
 
 
 class _SplatAlpha(torch.autograd.Function):
@@ -64,8 +73,10 @@ class _SplatAlpha(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, points, features, radius, first, count, static):
-        size, k, bin_size, cap, inv_r2 = static
-        idx, zbuf, dists2, images = _C.rasterize_points_composite(points, first, count, size, radius, features, inv_r2, k, bin_size, cap)
+        size, k, bin_size, cap, inv_r2, mode = static
+        idx, zbuf, dists2, images = _C.rasterize_points_composite(points, first, count, size, radius, features, inv_r2, k, bin_size, cap,
+                                                                  mode)
+        ctx.mode = mode
         ctx.save_for_backward(points, features, idx, dists2)
         ctx.mark_non_differentiable(idx, zbuf, dists2)
         ctx.set_materialize_grads(False)
@@ -77,5 +88,5 @@ class _SplatAlpha(torch.autograd.Function):
         if g_images is None:
             return (None,) * 6
         points, features, idx, dists2 = ctx.saved_tensors
-        gp, gf = _C.rasterize_points_composite_backward(points, features, idx, dists2, g_images.contiguous(), ctx.inv_r2)
+        gp, gf = _C.rasterize_points_composite_backward(points, features, idx, dists2, g_images.contiguous(), ctx.inv_r2, ctx.mode)
         return (gp if ctx.needs_input_grad[0] else None), (gf if ctx.needs_input_grad[1] else None), None, None, None, None

@@ -426,7 +426,7 @@ def _patch_points_rasterizer(our_rm):
     rasterizer's own autograd node.  Falls back to the reference's forward when the cameras have no matrix form, need an
     `eps`, or their matrices require grad.
 
-    PointsRenderer.forward (renderer/points/renderer.py:56-76) with the plain (PointsRasterizer, AlphaCompositor) pair, float32
+    PointsRenderer.forward (renderer/points/renderer.py:56-76) with the plain PointsRasterizer and AlphaCompositor or NormWeightedCompositor, float32
     (P, C <= 4) features, one scalar radius and K <= 16: the whole chain is pytorch3d_amd.render_points' fused node -- the image is
     formed in the fine kernel's epilogue, the backward is one kernel.  The packed tensors are taken from the cloud's lists when it has
     not packed them yet: `Pointclouds.points_packed()` builds a cloud-index entry per point with arange + bucketize, twice (points and
@@ -494,7 +494,8 @@ def _patch_points_rasterizer(our_rm):
 
     def render(self, point_clouds, **kwargs):
         rz = self.rasterizer
-        ok = FUSE_POINTS_RENDERER and type(self.compositor) is pc.AlphaCompositor and type(rz).forward is forward
+        mode = {pc.AlphaCompositor: "alpha", pc.NormWeightedCompositor: "norm"}.get(type(self.compositor))
+        ok = FUSE_POINTS_RENDERER and mode is not None and type(rz).forward is forward
         got = None
         if ok:
             rs = kwargs.get("raster_settings", rz.raster_settings)
@@ -512,7 +513,7 @@ def _patch_points_rasterizer(our_rm):
         images, idx, _, _ = our_rd.render_points_alpha(view, feats, image_size=rs.image_size, radius=rs.radius,
                                                        points_per_pixel=rs.points_per_pixel, bin_size=rs.bin_size,
                                                        max_points_per_bin=rs.max_points_per_bin, weight_radius=r_w,
-                                                       radius_per_point=_scalar_radius(rs.radius, ndc))
+                                                       radius_per_point=_scalar_radius(rs.radius, ndc), compositor=mode)
         background_color = kwargs.get("background_color", self.compositor.background_color)
         if background_color is not None:  # compositor.py:41-46, on (N, C, H, W) views
             images = pc._add_background_color_to_images(idx.long().permute(0, 3, 1, 2), images.permute(0, 3, 1, 2),

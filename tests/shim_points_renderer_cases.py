@@ -86,7 +86,8 @@ def main():
         # not taken by the fused node: the operator chain's own patches (or the reference) run
         "fallback_k_above_16": case([2500], 3, 20, 0.08, AlphaCompositor(), ortho),
         "fallback_five_channels": case([2500], 5, 8, 0.05, AlphaCompositor(), ortho),
-        "fallback_norm_weighted": case([2500], 3, 8, 0.05, NormWeightedCompositor(), ortho),
+        "norm_weighted_compositor": case([2500, 800], 3, 8, 0.05, NormWeightedCompositor(), ortho),
+        "norm_weighted_background": case([2500], 4, 10, 0.05, NormWeightedCompositor(background_color=(0.3, 0.3, 0.3, 1.0)), persp),
     }
     print(json.dumps(out))
 

@@ -87,7 +87,7 @@ def test_patched_points_renderer_operator_chain_when_the_fused_node_is_switched_
 def test_patched_points_renderer_cases():
     """tests/shim_points_renderer_cases.py: ragged batches, RGBA, background colours (constructor and keyword), a cloud built from
     padded tensors, one channel with K = 16 -- through the fused node (counted), bit-equal in the image to the operator chain and within
-    the chain's gates of the reference's own Python; K = 20, five channels and the norm-weighted compositor fall back (counted)."""
+    the chain's gates of the reference's own Python, with either stock compositor; K = 20 and five channels fall back (counted)."""
     if not os.path.isdir(os.path.join(STAGE, "pytorch3d", "renderer")):
         pytest.skip("oracle/_ref/reference_py is not staged (run __graft_entry__.build() where /root/reference exists)")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "shim_points_renderer_cases.py")], capture_output=True, text=True,
