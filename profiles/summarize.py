@@ -21,6 +21,7 @@ OURS = {"mesh_raster_kernel": "mesh_fine", "area_list_kernel": "mesh_backward_ar
         "bin_scan_rows": "bin_scan_rows", "bin_scan_small": "bin_scan_small", "bin_plan": "bin_plan", "gather_faces": "gather_face_verts",
         "scatter_face": "scatter_face_grads", "point_raster_kernel": "points_fine (register queues, naive launch)", "point_tile_sorted": "points_fine (tile-sorted kernel, LDS queues)",
         "point_sorted_kernel": "points_fine (sorted kernel, LDS queues)", "point_backward": "points_backward",
+        "splat_backward": "points_composite_bwd (compositor + rasterizer backward, one kernel)", "splat_composite": "points_composite (pass)",
         "composite_fwd": "composite_fwd", "composite_bwd": "composite_bwd", "transform_verts": "transform_verts",
         "interp_fwd": "interp_fwd", "interp_bwd": "interp_bwd", "softmax_blend": "softmax_blend", "phong": "phong", "soft_phong": "soft_phong"}
 
