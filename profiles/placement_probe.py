@@ -97,6 +97,72 @@ def main():
         print(f"{name:<52} mesh_fine ms per round: {v}   mean {sum(v) / len(v):.4f}")
     print(json.dumps(res))
 
+    # Second question: do two independent ALLOCATIONS differ (physical pages), with the same code and the same relative layout?
+    # Six allocations of outputs + workspace + cover, made one after the other and all kept alive; measured in turn, three rounds.
+    sets = []
+    for i in range(6):
+        o = torch.empty((sum(sizes) + 4096,), dtype=torch.uint8, device=d)
+        w = torch.empty_like(ws)
+        c = torch.empty_like(cover)
+        sets.append((o, w, c))
+        _pad = torch.empty((37 << 20) * (i + 1), dtype=torch.uint8, device=d)  # (shifts the next allocation; freed at once)
+        del _pad
+    res2 = {i: [] for i in range(len(sets))}
+    for r in range(3):
+        for i, (o, w, c) in enumerate(sets):
+            off, ptrs = (-o.data_ptr()) % 256, []
+            for sz in sizes:
+                ptrs.append(o.data_ptr() + off)
+                off += sz
+            def go():
+                rc = lib.p3d_rasterize_meshes_with_cover(fv.data_ptr(), first.data_ptr(), count.data_ptr(), nbr.data_ptr(), F, B, H, H, blur, K,
+                                                         bin_size, M, 1, 1, 0, ptrs[0], ptrs[1], ptrs[2], ptrs[3], c.data_ptr(), w.data_ptr(),
+                                                         w.numel(), stream)
+                assert rc == 0, rc
+            for _ in range(3):
+                go()
+            torch.cuda.synchronize()
+            lib.p3d_profile_reset()
+            lib.p3d_profile_enable(1)
+            for _ in range(args.iters):
+                go()
+            torch.cuda.synchronize()
+            lib.p3d_profile_enable(0)
+            res2[i].append(round(E.snapshot(lib)["mesh_fine"], 4))
+    # Third: which of the three buffers carries the effect?  One buffer from allocation i, the other two from allocation 0.
+    def measure(o, w, c):
+        off, ptrs = (-o.data_ptr()) % 256, []
+        for sz in sizes:
+            ptrs.append(o.data_ptr() + off)
+            off += sz
+        def go():
+            rc = lib.p3d_rasterize_meshes_with_cover(fv.data_ptr(), first.data_ptr(), count.data_ptr(), nbr.data_ptr(), F, B, H, H, blur, K,
+                                                     bin_size, M, 1, 1, 0, ptrs[0], ptrs[1], ptrs[2], ptrs[3], c.data_ptr(), w.data_ptr(),
+                                                     w.numel(), stream)
+            assert rc == 0, rc
+        for _ in range(3):
+            go()
+        torch.cuda.synchronize()
+        lib.p3d_profile_reset()
+        lib.p3d_profile_enable(1)
+        for _ in range(args.iters):
+            go()
+        torch.cuda.synchronize()
+        lib.p3d_profile_enable(0)
+        return round(E.snapshot(lib)["mesh_fine"], 4)
+
+    res3 = {"outputs": [], "workspace": [], "cover": []}
+    for i in range(len(sets)):
+        res3["outputs"].append(measure(sets[i][0], sets[0][1], sets[0][2]))
+        res3["workspace"].append(measure(sets[0][0], sets[i][1], sets[0][2]))
+        res3["cover"].append(measure(sets[0][0], sets[0][1], sets[i][2]))
+    for k, v in res3.items():
+        print(f"only the {k} from allocation i = 0..5 (rest from allocation 0): {v}")
+    print(json.dumps({"one_buffer_swapped": res3}))
+    for i, v in res2.items():
+        print(f"allocation {i} (outputs at {sets[i][0].data_ptr():#x}, workspace at {sets[i][1].data_ptr():#x}): mesh_fine ms per round {v}")
+    print(json.dumps({"allocations": res2}))
+
 
 if __name__ == "__main__":
     main()
