@@ -24,6 +24,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--reserve-gb", type=float, default=0.0, help="hold a dummy allocation of this size, made before anything else")
+    ap.add_argument("--image-size", type=int, default=512, help="square image side (512: a row of pix_to_face is 32 KiB, a power of two; 496: 31 KiB)")
     args = ap.parse_args()
     import _util as U
     import exp_measure as E
@@ -31,7 +33,11 @@ def main():
     from pytorch3d_amd import _lib
 
     d = torch.device("cuda:0")
-    B, H, K = 64, 512, 8
+    reserve = torch.empty((int(args.reserve_gb * (1 << 30)),), dtype=torch.uint8, device=d) if args.reserve_gb > 0 else None  # noqa: F841
+    # the very first allocations of the process: one set of outputs (3.76 GB + 4 KB) and, behind it, a workspace-sized block
+    n0 = 64 * args.image_size * args.image_size * 8
+    first_out = torch.empty((n0 * 28 + 4096,), dtype=torch.uint8, device=d)
+    B, H, K = 64, args.image_size, 8
     blur = math.log(1.0 / 1e-4 - 1.0) * 1e-4
     verts, faces = U.hetero_batch(B, seed=0, torus_div=1.0)
     m = p3d.PackedMeshes([v.to(d) for v in verts], [f.to(d) for f in faces])
@@ -42,7 +48,7 @@ def main():
     lib = _lib.load()
     bin_size, M = 32, int(max(10000, F / 5))
     ws = torch.empty((int(lib.p3d_rasterize_meshes_workspace_bytes(F, B, H, H, bin_size, M)),), dtype=torch.uint8, device=d)
-    cover = torch.empty((B, H // 16, H // 16), dtype=torch.int32, device=d)
+    cover = torch.empty((B, (H + 15) // 16, (H + 15) // 16), dtype=torch.int32, device=d)
     stream = ctypes.c_void_p(torch.cuda.current_stream(d).cuda_stream)
     n = B * H * H * K
     sizes = [n * 8, n * 4, n * 12, n * 4]  # pix_to_face, zbuf, bary, dists
@@ -99,8 +105,8 @@ def main():
 
     # Second question: do two independent ALLOCATIONS differ (physical pages), with the same code and the same relative layout?
     # Six allocations of outputs + workspace + cover, made one after the other and all kept alive; measured in turn, three rounds.
-    sets = []
-    for i in range(6):
+    sets = [(first_out, torch.empty_like(ws), torch.empty_like(cover))]
+    for i in range(5):
         o = torch.empty((sum(sizes) + 4096,), dtype=torch.uint8, device=d)
         w = torch.empty_like(ws)
         c = torch.empty_like(cover)
@@ -151,6 +157,20 @@ def main():
         lib.p3d_profile_enable(0)
         return round(E.snapshot(lib)["mesh_fine"], 4)
 
+    # Is a slow allocation slow for a plain streaming fill too?  (then: a property of its pages; else: of the kernel's write ORDER on them)
+    fills = []
+    for o, _, _ in sets:
+        for _ in range(2):
+            o.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(10):
+            o.zero_()
+        e1.record()
+        torch.cuda.synchronize()
+        fills.append(round(e0.elapsed_time(e1) / 10, 4))
+    print(f"streaming fill of the outputs of allocation i = 0..5 ({sum(sizes) / 1e9:.2f} GB), ms: {fills}")
     res3 = {"outputs": [], "workspace": [], "cover": []}
     for i in range(len(sets)):
         res3["outputs"].append(measure(sets[i][0], sets[0][1], sets[0][2]))
@@ -160,7 +180,7 @@ def main():
         print(f"only the {k} from allocation i = 0..5 (rest from allocation 0): {v}")
     print(json.dumps({"one_buffer_swapped": res3}))
     for i, v in res2.items():
-        print(f"allocation {i} (outputs at {sets[i][0].data_ptr():#x}, workspace at {sets[i][1].data_ptr():#x}): mesh_fine ms per round {v}")
+        print(f"allocation {i}{' (outputs allocated FIRST in the process)' if i == 0 else ''} (outputs at {sets[i][0].data_ptr():#x}, workspace at {sets[i][1].data_ptr():#x}): mesh_fine ms per round {v}")
     print(json.dumps({"allocations": res2}))
 
 
