@@ -24,6 +24,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--only-allocations", action="store_true", help="skip the layout patterns, the fills and the one-buffer swaps (for counter runs: "
+                    "60 warm-up launches, then rounds x 6 allocations x (3 + iters) launches in that order)")
     ap.add_argument("--reserve-gb", type=float, default=0.0, help="hold a dummy allocation of this size, made before anything else")
     ap.add_argument("--image-size", type=int, default=512, help="square image side (512: a row of pix_to_face is 32 KiB, a power of two; 496: 31 KiB)")
     args = ap.parse_args()
@@ -85,7 +87,7 @@ def main():
         run(carve(patterns["packed (as torch: 2 MB-aligned, back to back)"]))
     torch.cuda.synchronize()
     res = {k: [] for k in patterns}
-    for r in range(args.rounds):
+    for r in range(0 if args.only_allocations else args.rounds):
         order = list(patterns) if r % 2 == 0 else list(patterns)[::-1]
         for name in order:
             ptrs = carve(patterns[name])
@@ -100,7 +102,8 @@ def main():
             lib.p3d_profile_enable(0)
             res[name].append(round(E.snapshot(lib)["mesh_fine"], 4))
     for name, v in res.items():
-        print(f"{name:<52} mesh_fine ms per round: {v}   mean {sum(v) / len(v):.4f}")
+        if v:
+            print(f"{name:<52} mesh_fine ms per round: {v}   mean {sum(v) / len(v):.4f}")
     print(json.dumps(res))
 
     # Second question: do two independent ALLOCATIONS differ (physical pages), with the same code and the same relative layout?
@@ -157,6 +160,10 @@ def main():
         lib.p3d_profile_enable(0)
         return round(E.snapshot(lib)["mesh_fine"], 4)
 
+    if args.only_allocations:
+        for i, v in res2.items():
+            print(f"allocation {i}: mesh_fine ms per round {v}")
+        return
     # Is a slow allocation slow for a plain streaming fill too?  (then: a property of its pages; else: of the kernel's write ORDER on them)
     fills = []
     for o, _, _ in sets:
