@@ -94,3 +94,36 @@ def test_points_render_matches_reference_renderer(tag):
     img.backward(t(f"{tag}_grad_image").to(d))
     rg = t(f"{tag}_grad_features")
     assert torch.allclose(feats.grad.cpu(), rg, rtol=2e-3, atol=2e-4 * rg.abs().max().item())
+
+
+@pytest.mark.parametrize("bin_size", [0, None])
+@pytest.mark.parametrize("tag", ["alpha", "norm"])
+def test_fused_points_render_matches_reference_renderer(tag, bin_size):
+    """The same fixture through the fused node of round 6 (pytorch3d_amd.render_points: the compositor in the fine kernel's epilogue /
+    as a pass behind the naive launch, one backward kernel): image and feature gradient against the reference's PointsRenderer on CPU,
+    and bit-equal to the operator chain above."""
+    import pytorch3d_amd as p3d
+
+    g = np.load(os.path.join(U.GOLDEN, "render_points_ref.npz"))
+    t = lambda k: torch.from_numpy(g[k])
+    d = torch.device("cuda:0")
+    npts = [int(x) for x in g["num_points"]]
+    pc = p3d.PackedPointclouds([p.to(d) for p in t("points_ndc").split(npts)])
+    H, W = (int(x) for x in g["image_size"])
+    r, K = float(g["radius"]), int(g["K"])
+    feats = t("features").to(d).requires_grad_(True)
+    img, idx, zbuf, dists = p3d.render_points_alpha(pc, feats, image_size=(H, W), radius=r, points_per_pixel=K, bin_size=bin_size,
+                                                    compositor=tag)
+    assert (idx.cpu() == t("idx")).float().mean().item() > 0.999
+    chain = (p3d.alpha_composite if tag == "alpha" else p3d.norm_weighted_sum)(
+        idx.long().permute(0, 3, 1, 2), 1 - dists.permute(0, 3, 1, 2) / (r * r), feats.detach().permute(1, 0)).permute(0, 2, 3, 1)
+    assert torch.equal(img.detach(), chain)
+    out = img
+    if tag == "alpha":  # compositor.py:66-110 (_add_background_color_to_images), plain torch glue
+        bg = torch.tensor([0.1, 0.2, 0.3, 1.0], device=d)
+        out = torch.where((idx[..., 0] < 0)[..., None], bg[None, None, None, :], img)
+    ref = t(f"{tag}_image")
+    assert ((out.detach().cpu() - ref).abs() > 1e-5).float().mean() < 2e-3, (out.detach().cpu() - ref).abs().max()
+    out.backward(t(f"{tag}_grad_image").to(d))
+    rg = t(f"{tag}_grad_features")
+    assert torch.allclose(feats.grad.cpu(), rg, rtol=2e-3, atol=2e-4 * rg.abs().max().item())
