@@ -319,14 +319,19 @@ __global__ __launch_bounds__(256) void cover_check_kernel(const int64_t* __restr
   if (any && !((word >> (y & 15)) & 1)) atomicOr(flag, 1);
 }
 
-template <int KT>
+template <int KT, bool PRE = false>
 struct RowsCfg {
-  static constexpr int kWaves = KT >= 16 ? 5 : 6;     // waves per SIMD the kernel is built for (512 / kWaves registers)
+  // Round 6: with the per-face reciprocals gathered (PRE) the K = 8 / K = 4 kernels fit 73 registers, and seven waves per SIMD with
+  // 100-slot tables (7 workgroups x 22.4 KB of LDS per CU) run the bench launch 5.4 % faster than six with 116 (0.885 / 0.899 / 0.894
+  // -> 0.837 / 0.853 / 0.844 ms alternating on one box, profiles/r06/c42; the light batch 0.555 -> 0.532).  Round 4 had tried seven
+  // waves on the kernel of its day: +3..5 % on config 3, -6 % on the light batch, not taken.
+  static constexpr bool kSeven = PRE && KT <= 8;
+  static constexpr int kWaves = KT >= 16 ? 5 : (kSeven ? 7 : 6);     // waves per SIMD the kernel is built for (512 / kWaves registers)
   // 4 waves x kSlots x 56 B of LDS per workgroup (a multiple of 4: bucket probing).  The LDS, not the 70 registers, is what
   // holds K = 8 at six waves per SIMD: with 100 slots (seven waves) the launch measured 1.036 -> 0.98 / 1.00 ms on config 3 in
   // two runs but 0.654 -> 0.694 on the light batch, 104 and 92 slots no change (profiles/r04/r04c10/bwd_occ*.txt): not taken.
   // At eight waves (88 slots, 64 registers) the kernel spills and returns NaN -- the build refuses it.
-  static constexpr int kSlots = KT >= 16 ? 136 : 116;
+  static constexpr int kSlots = KT >= 16 ? 136 : (kSeven ? 100 : 116);
   static constexpr int kPix = 64 / KT;                 // pixels per 64-sample step
 };
 
@@ -385,11 +390,11 @@ __device__ __forceinline__ void run_reduce(int& f, float (&g)[9], int lane) {
 // as in the forward's PC kernels): the step's arithmetic is one basic block instead of five behind uniform flag branches.
 // PRE: the per-face reciprocals come from a.face_pre (one 16-byte gather per sample) instead of five v_rcp_f32 per sample.
 template <int KT, bool TO_VERTS, bool PC = false, bool PRE = false>
-__global__ __launch_bounds__(256, RowsCfg<KT>::kWaves) void mesh_backward_rows_kernel(BwdArgs a) {
+__global__ __launch_bounds__(256, (RowsCfg<KT, PRE>::kWaves)) void mesh_backward_rows_kernel(BwdArgs a) {
   constexpr int SPR = KT / 4;  // steps per 16-pixel row segment
   constexpr int PIX = RowsCfg<KT>::kPix;
   static_assert(KT == 4 || KT == 8 || KT == 16 || KT == 32, "16 K samples per row segment, 64 per step");
-  using Table = WaveTable<9, RowsCfg<KT>::kSlots, TO_VERTS ? kCorners : kRows, true, true>;
+  using Table = WaveTable<9, RowsCfg<KT, PRE>::kSlots, TO_VERTS ? kCorners : kRows, true, true>;
   __shared__ __align__(16) int s_table[4][Table::kLdsInts];
 
   const int tid = threadIdx.x;
