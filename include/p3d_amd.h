@@ -188,6 +188,15 @@ int p3d_rasterize_meshes_backward_verts_pre(const float* face_verts, const float
                                             int W, int K, int perspective_correct, int clip_barycentric_coords, float* grad_verts,
                                             p3d_stream_t stream);
 
+/* The same for callers that arrive with face_verts already made (the reference's own signature, `_C.rasterize_meshes_backward`):
+ * p3d_rasterize_meshes_backward_with_cover / _with_cover_list (cover null: every row is read; cover_has_list != 0: the list behind the
+ * cover is taken and the workspace ignored) that first writes the per-face reciprocals into face_pre_scratch (F x 4 f32, 16-byte aligned;
+ * null: the per-sample form) with one small launch. */
+int p3d_rasterize_meshes_backward_pre(const float* face_verts, const int64_t* pix_to_face, const float* grad_zbuf, const float* grad_bary,
+                                      const float* grad_dists, const int32_t* cover, int cover_has_list, int64_t F, int N, int H, int W,
+                                      int K, int perspective_correct, int clip_barycentric_coords, float* grad_face_verts,
+                                      float* face_pre_scratch, void* workspace, size_t workspace_bytes, p3d_stream_t stream);
+
 /* CUDA tie order -- p3d_rasterize_meshes_with_cover, then a replay that makes pix_to_face (and the rows that go with it) what
  * the reference's CUDA kernels return where faces tie EXACTLY in depth at a pixel's K-th place.  The kernels of this library keep
  * the K nearest under the total order (depth, face index), as the reference's CPU and Python implementations do

@@ -254,6 +254,8 @@ RECALL_COVERS = os.environ.get("P3D_RECALL_COVERS", "1") not in ("", "0")
 # the forward appends the non-empty words of its cover to a list behind it (p3d_rasterize_meshes_with_cover_list); 0: the plain cover,
 # the backward builds the list itself (mesh_backward_areas)
 COVER_LIST = os.environ.get("P3D_COVER_LIST", "1") not in ("", "0")
+# the backward of perspective + clip launches with K = 4 / 8 reads per-face reciprocals (include/p3d_amd.h: p3d_rasterize_meshes_backward_pre)
+FACE_PRE = os.environ.get("P3D_FACE_PRE", "1") not in ("", "0")
 CHECK_COVERS = os.environ.get("P3D_CHECK", "0") not in ("", "0")
 COVER_RECALLS = [0, 0]  # backward calls without an explicit cover: [found the forward's, found none] (read by tests / profiles)
 COVER_CHECKS = [0, 0]   # CHECK_COVERS: [covers verified, of which stale]
@@ -480,7 +482,15 @@ def rasterize_meshes_backward(face_verts, pix_to_face, grad_zbuf, grad_bary, gra
         out = torch.empty((F, 3, 3), dtype=torch.float32, device=dev)
         if F == 0:
             return out
-        if cover_has_list(_cover, N, H, W):
+        if FACE_PRE and perspective_correct and clip_barycentric_coords and K in (4, 8):
+            # the per-face reciprocals first (one small launch into a scratch tensor), then the kernel that gathers them per sample
+            has_list = cover_has_list(_cover, N, H, W)
+            ws = _workspace(0, dev) if has_list else backward_workspace(_cover, N, H, W, dev)
+            pre = torch.empty((F, 4), dtype=torch.float32, device=dev)
+            rc = lib.p3d_rasterize_meshes_backward_pre(
+                _ptr(fv), _ptr(p2f), _ptr(gz), _ptr(gb), _ptr(gd), cover_ptr(_cover, N, H, W), int(has_list), F, N, H, W, K, 1, 1,
+                _ptr(out), _ptr(pre), _ptr(ws), ws.numel(), _stream(dev))
+        elif cover_has_list(_cover, N, H, W):
             rc = lib.p3d_rasterize_meshes_backward_with_cover_list(
                 _ptr(fv), _ptr(p2f), _ptr(gz), _ptr(gb), _ptr(gd), cover_ptr(_cover, N, H, W), F, N, H, W, K,
                 int(bool(perspective_correct)), int(bool(clip_barycentric_coords)), _ptr(out), _stream(dev))

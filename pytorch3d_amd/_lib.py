@@ -62,6 +62,8 @@ _SIGNATURES = {
                                                                c_ptr]),
     "p3d_gather_face_verts": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),
     "p3d_gather_face_verts_pre": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
+    "p3d_rasterize_meshes_backward_pre": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_i64, c_int, c_int, c_int, c_int, c_int,
+                                                  c_int, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "p3d_rasterize_meshes_backward_verts_pre": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i64,
                                                         c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
     "p3d_scatter_face_grads": (c_int, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr]),

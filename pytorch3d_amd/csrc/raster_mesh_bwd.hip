@@ -319,6 +319,16 @@ __global__ __launch_bounds__(256) void cover_check_kernel(const int64_t* __restr
   if (any && !((word >> (y & 15)) & 1)) atomicOr(flag, 1);
 }
 
+// The per-face reciprocals (p3d_geom.h: BwdFacePre) from face_verts, a thread per face: what p3d_gather_face_verts_pre writes beside its
+// gather, for callers that arrive with face_verts already made (the reference's own signature: p3d_rasterize_meshes_backward_pre).
+__global__ __launch_bounds__(256) void face_pre_kernel(const float* __restrict__ face_verts, int64_t F, float4* __restrict__ face_pre) {
+  for (int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x; f < F; f += (int64_t)gridDim.x * 256) {
+    const float* q = face_verts + f * 9;
+    const BwdFacePre r = bwd_face_pre_make(mk3(q[0], q[1], q[2]), mk3(q[3], q[4], q[5]), mk3(q[6], q[7], q[8]));
+    face_pre[f] = make_float4(r.inv_area, r.inv_l01, r.inv_l02, r.inv_l12);
+  }
+}
+
 template <int KT, bool PRE = false>
 struct RowsCfg {
   // Round 6: with the per-face reciprocals gathered (PRE) the K = 8 / K = 4 kernels fit 73 registers, and seven waves per SIMD with
@@ -720,4 +730,29 @@ P3D_API int p3d_rasterize_meshes_backward_verts_pre(const float* face_verts, con
   if (!face_verts || !faces || !p2f || !grad_zbuf || !grad_bary || !grad_dists || ((uintptr_t)face_pre & 15u)) return P3D_ERR_INVALID_ARG;
   return launch_mesh_backward(face_verts, faces, V, p2f, grad_zbuf, grad_bary, grad_dists, N, H, W, K, persp, clip, grad_verts,
                               cover_and_list, nullptr, 0, s, cover_and_list != nullptr, face_pre);
+}
+
+P3D_API int p3d_rasterize_meshes_backward_pre(const float* face_verts, const int64_t* p2f, const float* grad_zbuf, const float* grad_bary,
+                                              const float* grad_dists, const int32_t* cover, int cover_has_list, int64_t F, int N, int H,
+                                              int W, int K, int persp, int clip, float* grad_face_verts, float* face_pre_scratch,
+                                              void* workspace, size_t workspace_bytes, p3d_stream_t stream) {
+  if (F < 0 || N < 0 || H < 0 || W < 0 || K < 0) return P3D_ERR_INVALID_ARG;
+  if (F == 0) return P3D_OK;
+  if (!grad_face_verts || !face_verts || ((uintptr_t)face_pre_scratch & 15u)) return P3D_ERR_INVALID_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(grad_face_verts, 0, (size_t)F * 9 * sizeof(float), s) != hipSuccess) return P3D_ERR_LAUNCH;
+  if ((int64_t)N * H * W * K == 0) return P3D_OK;
+  if (!p2f || !grad_zbuf || !grad_bary || !grad_dists) return P3D_ERR_INVALID_ARG;
+  const bool use_pre = face_pre_scratch != nullptr && persp && clip && (K == 4 || K == 8);  // (the kernels that read the records)
+  if (use_pre) {
+    int64_t blocks = ceil_div(F, 256);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    LaunchScope ls("face_pre", s);
+    face_pre_kernel<<<(unsigned)blocks, 256, 0, s>>>(face_verts, F, reinterpret_cast<float4*>(face_pre_scratch));
+    const int st = launch_status();
+    if (st != P3D_OK) return st;
+  }
+  const bool list = cover != nullptr && cover_has_list != 0;
+  return launch_mesh_backward(face_verts, nullptr, -1, p2f, grad_zbuf, grad_bary, grad_dists, N, H, W, K, persp, clip, grad_face_verts, cover,
+                              list ? nullptr : workspace, list ? 0 : workspace_bytes, s, list, use_pre ? face_pre_scratch : nullptr);
 }

@@ -425,6 +425,36 @@ def test_backward_with_per_face_reciprocals(K):
                                  gd.cpu(), False, False, rtol=2e-3, reference=want_ff.cpu())
 
 
+@pytest.mark.parametrize("K", [4, 8])
+def test_reference_signature_backward_with_and_without_face_records(K):
+    """`_C.rasterize_meshes_backward` as the reference calls it (face_verts in, grad_face_verts out): with _C.FACE_PRE the call first
+    writes the per-face reciprocals (p3d_rasterize_meshes_backward_pre) -- same gradients as the per-sample form within the gate, with
+    the forward's cover (list), a cloned cover (no list: workspace) and none."""
+    from pytorch3d_amd import _C
+
+    d = _dev()
+    gen = torch.Generator().manual_seed(300 + K)
+    fv = U.smooth_soup(500, gen, size=3.0)
+    first, count = U.split_counts(500, 2)
+    nbr = torch.full((500,), -1, dtype=torch.int64)
+    size = (48, 40)
+    (p2f, zbuf, bary, dists), cover = _C._rasterize_meshes_covered(fv.to(d), first.to(d), count.to(d), nbr.to(d), size, 2e-3, K, 8, 1000,
+                                                                    True, True, False)
+    gz, gb, gd = (torch.randn(t.shape, generator=gen).to(d) for t in (zbuf, bary, dists))
+    saved = _C.FACE_PRE
+    try:
+        res = {}
+        for pre in (True, False):
+            _C.FACE_PRE = pre
+            res[pre] = [_C.rasterize_meshes_backward(fv.to(d), p2f, gz, gb, gd, True, True, _cover=c).cpu()
+                        for c in (cover, cover.clone(), None)]
+    finally:
+        _C.FACE_PRE = saved
+    for got in res[True]:
+        U.assert_face_grads_vs_truth(f"reference-signature backward with face records K={K}", got, fv, p2f.cpu(), gz.cpu(), gb.cpu(), gd.cpu(),
+                                     True, True, rtol=2e-3, reference=res[False][0])
+
+
 def test_autograd_mirror_and_reference_cpu_build():
     """The L2 mirror end to end (verts -> loss -> grad), against the reference's own CPU kernels when
     oracle/_ref is present (idx exact, floats 1e-5, grads rtol 5e-3 as tests/test_rasterize_meshes.py:317-319)."""
